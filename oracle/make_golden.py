@@ -1,0 +1,199 @@
+"""TEST INFRASTRUCTURE ONLY -- generates ``tests/golden/*.npz`` by running the
+REFERENCE's own Python (``/root/reference`` via ``oracle/ref_loader.py``).
+
+Run in the build container only (the reference does not travel):
+
+    cd /tmp && python3 -B /root/repo/oracle/make_golden.py
+
+Each fixture holds inputs (``edge_index`` int64 with duplicates / self-loops as drawn,
+``X``, weights, ``train_idx``, ``train_y``, ``batch_size``) and the reference's outputs
+(``logits`` for all nodes, the dense propagation matrix as COO, ``adj_to_edge_index``
+order, ``kfacs`` blocks of ``KronLaplace.fit``, ``diag`` H of ``DiagLaplace.fit``, full GGN
+of ``FullLaplace``-style ``GGNInterface.full`` on small cases, losses).  Fixtures are data,
+not code.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_loader  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def reference_dense_adj(torch, edge_index, n):
+    """gnn/utils.py:325-330 + gnn/marglik_training.py:404-405.  ``to_scipy_sparse_matrix``
+    of torch_geometric (absent here) is ``scipy.sparse.coo_matrix((ones,(row,col)),(N,N))``;
+    ``.toarray()`` sums duplicates; the driver then clamps to 1."""
+    import scipy.sparse as sp
+
+    row, col = edge_index[0].numpy(), edge_index[1].numpy()
+    dense = sp.coo_matrix((np.ones(len(row)), (row, col)), (n, n)).toarray()
+    adj = torch.tensor(dense, dtype=torch.int64).float()
+    adj[adj > 1] = 1
+    return adj
+
+
+def reference_adj_to_edge_index(adj):
+    """gnn/utils.py:333-336 (the file itself imports torch_geometric/sklearn/GPUtil at
+    module level, so the three-line function is executed on the reference's tensor ops)."""
+    _adj = adj.clone()
+    _adj.fill_diagonal_(0)
+    return _adj.nonzero().t().contiguous()
+
+
+def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch_size, seed,
+              symmetric=False, isolated=0, with_full=False):
+    from torch.utils.data import DataLoader, TensorDataset
+
+    g = torch.Generator().manual_seed(seed)
+    hi = n - isolated  # the last `isolated` nodes get no edges at all
+    ei = torch.randint(0, hi, (2, n_edges), generator=g)
+    # force duplicates and explicit self loops into the raw edge list
+    ei = torch.cat([ei, ei[:, : max(1, n_edges // 10)], torch.arange(0, hi, 7).repeat(2, 1)], 1)
+    X = torch.randn(n, f, generator=g)
+    adj0 = reference_dense_adj(torch, ei, n)
+
+    torch.manual_seed(seed)
+    if kind == "gcn":
+        model = ns.gnn_models.GCN(f, h, c, layers, X, adj0.clone(), dropout_p=0.5,
+                                  symmetric=symmetric)
+    else:
+        model = ns.gnn_models.GraphSAGE(f, h, c, layers, X, adj0.clone(),
+                                        num_sampled_nodes_per_hop=None, dropout_p=0.5,
+                                        symmetric=symmetric)
+    model.eval()
+    perm = torch.randperm(n, generator=g)
+    train_idx = perm[:n_train].clone()
+    if n_train >= 8:
+        train_idx[3] = train_idx[5]  # a duplicated node id inside one batch
+    train_y = torch.randint(0, c, (n_train,), generator=g)
+    loader = DataLoader(TensorDataset(train_idx, train_y), batch_size=batch_size, shuffle=False)
+
+    out = {
+        "kind": kind, "symmetric": symmetric, "num_nodes": n, "batch_size": batch_size,
+        "edge_index": ei.numpy(), "X": X.numpy(), "train_idx": train_idx.numpy(),
+        "train_y": train_y.numpy(), "num_layers": layers,
+    }
+    for l, conv in enumerate(model.convs):
+        out[f"W{l}"] = conv.lin.weight.detach().numpy().copy()
+        out[f"b{l}"] = conv.lin.bias.detach().numpy().copy()
+
+    with torch.no_grad():
+        adj = model.adj.detach()
+        out["adj_edge_index"] = reference_adj_to_edge_index(adj).numpy()
+        nzr, nzc = adj.nonzero(as_tuple=True)  # row-major order of the stored 0/1 matrix
+        out["adj_nz_row"], out["adj_nz_col"] = nzr.numpy(), nzc.numpy()
+        if kind == "gcn":
+            P = model.forward_adj()
+        else:  # what GraphSAGEConv.mean_agg multiplies with (layers.py:18-24)
+            rs = adj.sum(dim=1, keepdims=True)
+            rs[rs == 0] = 1
+            P = adj / rs
+        pr, pc = P.nonzero(as_tuple=True)
+        out["prop_row"], out["prop_col"], out["prop_val"] = pr.numpy(), pc.numpy(), P[pr, pc].numpy()
+        out["logits"] = model(torch.arange(n)).numpy()
+
+    bl = ns.baselaplace
+    la = bl.KronLaplace(model, "classification")
+    la.fit(loader)
+    out["kron_loss"] = np.float32(float(la.loss))
+    out["kron_n_blocks"] = len(la.H_facs.kfacs)
+    for i, Fs in enumerate(la.H_facs.kfacs):
+        for j, Hm in enumerate(Fs):
+            out[f"kron_{i}_{j}"] = Hm.detach().numpy().astype(np.float32)
+    # eigen-decomposition that KronLaplace.fit ends with (matrix.py:118-145): eigenvalues only
+    for i, ls in enumerate(la.H.eigenvalues):
+        for j, lam in enumerate(ls):
+            out[f"kron_eig_{i}_{j}"] = lam.detach().numpy().astype(np.float32)
+
+    ld = bl.DiagLaplace(model, "classification")
+    ld.fit(loader)
+    out["diag_loss"] = np.float32(float(ld.loss))
+    out["diag_H"] = ld.H.detach().numpy().astype(np.float32)
+    out["n_data"], out["n_outputs"], out["n_params"] = ld.n_data, ld.n_outputs, ld.n_params
+
+    if with_full:  # backend-free pin for "full" (SURVEY.md 8(c)): GGNInterface.full einsum
+        be = ns.curvature.GGNInterface(model, "classification")
+        loss, H = 0.0, 0.0
+        for xb, yb in loader:
+            lb, Hb = be.full(xb, yb)
+            loss, H = loss + lb, H + Hb
+        out["full_H"] = H.detach().numpy().astype(np.float32)
+        out["full_loss"] = np.float32(float(loss))
+        # upstream-KFAC seeds (detached sqrt) are not what the fork computes; also pin the
+        # per-batch Jacobians of the first batch for the oracle's generic backward
+        xb, _ = next(iter(loader))
+        Js, fb = be.jacobians(xb, enable_backprop=False)
+        out["jac_first_batch"] = Js.numpy().astype(np.float32)
+        out["f_first_batch"] = fb.numpy().astype(np.float32)
+
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path)/1024:.0f} KiB  kron_loss={out['kron_loss']:.4f}")
+
+
+def make_regression_mlp(ns, torch):
+    """BASELINE config 1: examples/regression_example.py:17-21 model (1-50-1 tanh), data
+    re-stated from examples/helper/dataloaders.py:39-47 (the helper imports torchvision)."""
+    from torch.utils.data import DataLoader, TensorDataset
+
+    torch.manual_seed(711)
+    n = 150
+    X = (torch.rand(n) * 8).unsqueeze(-1)
+    y = torch.sin(X) + torch.randn_like(X) * 0.3
+    model = torch.nn.Sequential(torch.nn.Linear(1, 50), torch.nn.Tanh(), torch.nn.Linear(50, 1))
+    loader = DataLoader(TensorDataset(X, y), batch_size=n)
+    bl = ns.baselaplace
+    ld = bl.DiagLaplace(model, "regression")
+    ld.fit(loader)
+    lk = bl.KronLaplace(model, "regression")
+    lk.fit(loader)
+    out = {
+        "X": X.numpy(), "y": y.numpy(),
+        "W0": model[0].weight.detach().numpy(), "b0": model[0].bias.detach().numpy(),
+        "W1": model[2].weight.detach().numpy(), "b1": model[2].bias.detach().numpy(),
+        "diag_H": ld.H.detach().numpy(), "diag_loss": np.float32(float(ld.loss)),
+        "kron_loss": np.float32(float(lk.loss)), "kron_n_blocks": len(lk.H_facs.kfacs),
+    }
+    for i, Fs in enumerate(lk.H_facs.kfacs):
+        for j, Hm in enumerate(Fs):
+            out[f"kron_{i}_{j}"] = Hm.detach().numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "c1_regression_mlp.npz"), **out)
+    print("c1_regression_mlp written")
+
+
+def main():
+    import torch
+
+    torch.set_num_threads(8)
+    ns = ref_loader.load()
+    small = dict(n=64, f=12, h=8, c=3, layers=2, n_edges=150)
+    mid = dict(n=512, f=64, h=32, c=7, layers=2, n_edges=1800)
+    for seed in (0, 1, 2):
+        make_case(ns, torch, f"gcn_small_1batch_s{seed}", "gcn", **small, n_train=33,
+                  batch_size=10000, seed=seed, with_full=(seed == 0))
+        make_case(ns, torch, f"gcn_small_3batch_s{seed}", "gcn", **small, n_train=33,
+                  batch_size=12, seed=seed, symmetric=(seed == 1))
+    make_case(ns, torch, "gcn_small_isolated_s0", "gcn", **small, n_train=40, batch_size=16,
+              seed=10, isolated=5)
+    make_case(ns, torch, "gcn_mid_1batch_s0", "gcn", **mid, n_train=200, batch_size=10000, seed=0)
+    make_case(ns, torch, "gcn_mid_3batch_sym_s1", "gcn", **mid, n_train=200, batch_size=77,
+              seed=1, symmetric=True)
+    make_case(ns, torch, "sage_small_1batch_s0", "sage", **small, n_train=33, batch_size=10000,
+              seed=0, with_full=True)
+    make_case(ns, torch, "sage_small_3batch_s1", "sage", **small, n_train=33, batch_size=12,
+              seed=1, isolated=4)
+    make_case(ns, torch, "sage_mid_2batch_s2", "sage", **mid, n_train=150, batch_size=100, seed=2)
+    make_regression_mlp(ns, torch)
+
+
+if __name__ == "__main__":
+    main()
