@@ -1,0 +1,155 @@
+/*
+ * laplace_gnn_hip.h -- C ABI of the MI355X (gfx950) curvature-accumulation engine.
+ *
+ * This is the drop-in boundary for ONE path of anitasyang/Laplace-GNN: what
+ * `laplace.curvature.CurvlinopsGGN.kron / .diag / .full` do for a GCN / GraphSAGE model
+ * inside `Laplace(...).fit()`.  The reference is pure Python (no native code), so nothing
+ * in it binds a C library today; each entry point below names the reference interface it
+ * replaces (file:line under the reference tree).  INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP, one GPU per process) unless marked "host";
+ *     tensors are row-major, fp32 / int64 exactly as PyTorch hands them over;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued asynchronously on it, no hidden device synchronisation
+ *     (the two graph-ingest calls that must learn `nnz` on the host are the exception
+ *     and say so);
+ *   - every function returns 0 on success, non-zero on error; the message is available
+ *     from lgnn_last_error() (thread-local).  No C++ exception crosses the boundary;
+ *   - borrowed pointers (weights, features, indices, outputs) are owned by the caller
+ *     and must stay valid until the stream work that uses them has finished;
+ *   - accumulate-style calls ADD into caller-owned fp32 buffers, so one all-reduce of
+ *     those buffers is all a data-parallel caller needs.
+ */
+#ifndef LAPLACE_GNN_HIP_H
+#define LAPLACE_GNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGNN_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define LGNN_API __attribute__((visibility("default")))
+#else
+#define LGNN_API
+#endif
+
+/* graph kinds: which propagation matrix the convolutions use */
+#define LGNN_KIND_GCN 0  /* D^-1/2 A^T D^-1/2, self loops added  (gnn/models/models.py:23-31, utils.py:106-112) */
+#define LGNN_KIND_SAGE 1 /* A / max(rowsum,1), self loops removed (gnn/models/models.py:47, layers.py:18-24)    */
+
+/* activations between layers (gnn/models/base_gnn.py:85, default "relu") */
+#define LGNN_ACT_RELU 0
+#define LGNN_ACT_TANH 1
+
+/* likelihoods (laplace/curvature/curvature.py:63-72) */
+#define LGNN_LIK_CLASSIFICATION 0 /* CrossEntropyLoss(sum), factor 1   */
+#define LGNN_LIK_REGRESSION 1     /* MSELoss(sum), factor 0.5          */
+
+/* flags of lgnn_kfac_accumulate */
+#define LGNN_FLAG_FORK_EXACT_SEED 1u /* back-propagate d/df sum_i f_i S_ic(f) (curvlinops/kfac.py:637-661 as
+                                        modified by the fork) instead of upstream's detached S[:,c]          */
+#define LGNN_FLAG_NO_FUSE 2u         /* debugging: run SpMM^T and the Gram contraction as separate kernels    */
+
+typedef struct lgnn_ctx lgnn_ctx; /* opaque: graph + bound model + forward cache + workspace */
+
+/* ---- library ------------------------------------------------------------------------ */
+LGNN_API int lgnn_abi_version(void);
+LGNN_API const char* lgnn_last_error(void);
+
+/* ---- graph ingest: the integer path (bit exact) ---------------------------------------
+ * Replaces gnn/utils.py:325-330 (edge_index -> dense adj, duplicates summed),
+ * gnn/marglik_training.py:405 (clamp to 1), gnn/models/models.py:23 / :47 (self loops on /
+ * off), gnn/models/base_gnn.py:68-72 (optional symmetrise) and gnn/models/utils.py:106-112 /
+ * gnn/models/layers.py:18-24 (normalisation, done once here instead of on every forward).
+ * edge_index: int64 [2,E] (row 0 = source/row, row 1 = target/col of the dense adj).
+ * Synchronises `stream` once (the deduplicated nnz has to reach the host).                */
+LGNN_API int lgnn_create(lgnn_ctx** out, int64_t num_nodes, const int64_t* edge_index, int64_t num_edges,
+                int kind, int symmetric, void* stream);
+LGNN_API void lgnn_destroy(lgnn_ctx* h);
+
+/* nnz of the stored 0/1 adjacency (incl. self loops for GCN).  host value. */
+LGNN_API int64_t lgnn_nnz(const lgnn_ctx* h);
+LGNN_API int64_t lgnn_num_nodes(const lgnn_ctx* h);
+/* 1 if the stored adjacency equals its transpose (then forward and backward share one CSR) */
+LGNN_API int lgnn_is_symmetric(const lgnn_ctx* h);
+
+/* Export the stored adjacency in the order `model.adj.nonzero()` yields (row-major):
+ * rows,cols int64 [nnz].  (tests: bit-exactness against the reference.)                    */
+LGNN_API int lgnn_export_adj(const lgnn_ctx* h, int64_t* rows, int64_t* cols, void* stream);
+/* gnn/utils.py:333-336 adj_to_edge_index: diagonal dropped, row-major, int64 [2,E'].
+ * Call with edge_index_out = NULL to get E' in *num_out (host); then again with a buffer. */
+LGNN_API int lgnn_adj_to_edge_index(const lgnn_ctx* h, int64_t* edge_index_out, int64_t* num_out, void* stream);
+/* Export the propagation matrix the convs multiply with (A_hat or A_bar) as COO in row-major
+ * order: rows,cols int64 [nnz], vals fp32 [nnz].                                            */
+LGNN_API int lgnn_export_propagation(const lgnn_ctx* h, int64_t* rows, int64_t* cols, float* vals, void* stream);
+
+/* ---- model binding ----------------------------------------------------------------------
+ * Replaces the module state gnn/models/base_gnn.py:62-76 + the parameter filter
+ * laplace/curvature/curvature.py:74-79: L layers `convs.{l}.lin` with weight [dims[l+1], in_l]
+ * and bias [dims[l+1]]; in_l = dims[l] (GCN) or 2*dims[l] (GraphSAGE, cat[x, mean_agg]).
+ * X: [N, dims[0]].  Pointers are borrowed.  Binding (re)sizes the workspace and invalidates the
+ * forward cache; call lgnn_invalidate() after changing weights in place.                     */
+LGNN_API int lgnn_bind_model(lgnn_ctx* h, int num_layers, const int64_t* dims /* host [L+1] */,
+                    const float* const* weights /* host array of L device ptrs */,
+                    const float* const* biases /* host array of L device ptrs */, const float* X,
+                    int activation, int likelihood);
+LGNN_API int lgnn_invalidate(lgnn_ctx* h);
+/* bytes currently held by the context (graph + caches + workspace).  host value. */
+LGNN_API int64_t lgnn_device_bytes(const lgnn_ctx* h);
+/* cap for the backward workspace (chunks over classes are sized to fit); default 8 GiB */
+LGNN_API int lgnn_set_workspace_limit(lgnn_ctx* h, int64_t bytes);
+
+/* ---- forward: model(x_indices) -> [M, C]  (gnn/models/base_gnn.py:136-161, eval mode) ----- */
+LGNN_API int lgnn_forward(lgnn_ctx* h, const int64_t* idx, int64_t M, float* out /* [M, C] */, void* stream);
+/* all-node logits [N, C] (what forward() indexes into) */
+LGNN_API int lgnn_forward_all(lgnn_ctx* h, float* out /* [N, C] */, void* stream);
+
+/* ---- KFAC factors of one mini-batch --------------------------------------------------------
+ * Replaces CurvlinopsInterface.kron (laplace/curvature/curvlinops.py:77-108) =
+ * KFACLinearOperator._compute_kfac (curvlinops/kfac.py:540-581, 607-661, 777-875) +
+ * _rescale_kron_factors (curvlinops.py:46-53) + the loss (curvlinops.py:106).
+ *   A_out[l]  [in_l, in_l]  += in_l^T in_l / n_train      (all N rows the Linear sees)
+ *   B_out[l]  [out_l,out_l] += sum_c g_{l,c}^T g_{l,c}     (one backward per class column c)
+ *   *loss_out               += factor * loss(model(idx), y)
+ * idx int64 [M]; y int64 [M] (classification) -- regression passes fp32 targets [M, C] as y.
+ * The batch is the unit: B has cross-sample terms inside a batch, so callers
+ * must keep the reference loader's batch boundaries.                                          */
+LGNN_API int lgnn_kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train,
+                         uint32_t flags, float* const* A_out /* host array of L device ptrs */,
+                         float* const* B_out /* host array of L device ptrs */, float* loss_out,
+                         void* stream);
+
+/* ---- diagonal GGN of one mini-batch ----------------------------------------------------------
+ * Replaces GGNInterface.diag (laplace/curvature/curvature.py:412-432 with jacobians :89-130 and
+ * _get_functional_hessian :365-372):  diag_out[P] += einsum('bcp,bck,bkp->p', J, Lambda, J),
+ * parameter order = named_parameters() (W0 row-major, b0, W1, b1, ...).  2-layer GCN and
+ * L-layer models are both handled without materialising J.                                     */
+LGNN_API int lgnn_diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags,
+                         float* diag_out /* [P] */, float* loss_out, void* stream);
+
+/* ---- last-layer full GGN of one mini-batch ------------------------------------------------------
+ * Replaces GGNInterface.full with last_layer_jacobians (laplace/curvature/curvature.py:132-167,
+ * 374-410): J_n = [I_C (x) phi_n^T | s_n I_C], H_out[P_ll, P_ll] += sum_n J_n^T Lambda_n J_n,
+ * P_ll = C*(D+1), weight index c*D+d then C bias entries.                                         */
+LGNN_API int lgnn_lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M,
+                                   float* H_out, float* loss_out, void* stream);
+
+/* ---- timing hook (bench.py roofline) -----------------------------------------------------------
+ * While enabled, every launch of the dominant kernel of the KFAC path (the fused SpMM^T -> Gram
+ * kernel of the lowest layer) is bracketed by HIP events recorded on `stream` itself
+ * (torch.cuda.Event only sees torch's current stream).  lgnn_kernel_timing_read synchronises on
+ * the recorded events and returns the number of launches, their summed duration in ms and the
+ * summed number of class planes they processed; enabling resets the counters.                    */
+LGNN_API int lgnn_enable_kernel_timing(lgnn_ctx* h, int enable);
+LGNN_API int lgnn_kernel_timing_read(lgnn_ctx* h, int64_t* launches, double* total_ms, int64_t* planes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAPLACE_GNN_HIP_H */

@@ -1,0 +1,305 @@
+// Context management, model binding and the cached full-graph forward pass.
+//
+// The reference recomputes the dense-adjacency forward (incl. normalize_adj) three times per
+// mini-batch (curvlinops/kfac.py:576, laplace/curvature/curvlinops.py:106, laplace/baselaplace.py:832)
+// although it does not depend on the batch: model(x_indices) computes all N node outputs and indexes
+// them (gnn/models/base_gnn.py:136-161).  Here it runs once per weight version and is cached,
+// together with the raw input Grams in_l^T in_l of the KFAC A factors (kfac.py:819-875), which are
+// batch independent for the same reason.
+#include "lgnn_internal.h"
+
+namespace lgnn {
+
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+
+int DevBuf::reserve(size_t want) {
+  if (want <= bytes && p) return 0;
+  if (p) {
+    hipError_t e = hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    if (e != hipSuccess) { set_error(std::string("hipFree: ") + hipGetErrorString(e)); return 1; }
+  }
+  size_t sz = std::max<size_t>(want, 256);
+  hipError_t e = hipMalloc(&p, sz);
+  if (e != hipSuccess) {
+    p = nullptr;
+    set_error("hipMalloc(" + std::to_string(sz) + " B): " + hipGetErrorString(e));
+    return 1;
+  }
+  bytes = sz;
+  return 0;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  bytes = 0;
+}
+
+static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
+  ForwardCache& fc = h->fc;
+  const int64_t N = h->N;
+  const int L = h->L;
+  int64_t maxw = 0;
+  for (int l = 0; l < L; ++l) maxw = std::max(maxw, h->dims[l + 1]);
+  LGNN_CALL(fc.out.reserve(size_t(N) * h->dims[L] * 4));
+
+  if (h->kind == LGNN_KIND_GCN) {
+    LGNN_CALL(fc.tmp.reserve(size_t(N) * maxw * 4));
+    fc.lin_in_p[0] = h->X;
+    fc.lin_in_ld[0] = h->dims[0];
+    for (int l = 0; l < L; ++l) {
+      const int64_t din = h->dims[l], dout = h->dims[l + 1];
+      GemmEpilogue ep;
+      ep.bias = h->b[l];
+      // Z_l = h_l W_l^T + b_l   (nn.Linear inside GCNConv, gnn/models/layers.py:45-46)
+      LGNN_CALL(launch_gemm(fc.lin_in_p[l], fc.lin_in_ld[l], h->Wt[l].as<float>(), dout, fc.tmp.as<float>(), dout, N,
+                            din, dout, ep, s));
+      if (l < L - 1) {
+        LGNN_CALL(fc.act_out[l].reserve(size_t(N) * dout * 4));
+        // h_{l+1} = act(A_hat Z_l)  (norm = Identity, dropout = identity in eval; base_gnn.py:141-156)
+        LGNN_CALL(launch_spmm(h->P, N, fc.tmp.as<float>(), dout, fc.act_out[l].as<float>(), dout, dout,
+                              h->act == LGNN_ACT_RELU ? 1 : 2, s));
+        fc.hact_p[l] = fc.act_out[l].as<float>();
+        fc.hact_ld[l] = dout;
+        fc.lin_in_p[l + 1] = fc.hact_p[l];
+        fc.lin_in_ld[l + 1] = dout;
+      } else {
+        LGNN_CALL(launch_spmm(h->P, N, fc.tmp.as<float>(), dout, fc.out.as<float>(), dout, dout, 0, s));
+      }
+    }
+  } else {
+    // GraphSAGE: cat_l = [h_l | A_bar h_l]  (gnn/models/layers.py:26-29)
+    for (int l = 0; l < L; ++l) {
+      const int64_t d = h->dims[l];
+      LGNN_CALL(fc.lin_in[l].reserve(size_t(N) * 2 * d * 4));
+      fc.lin_in_p[l] = fc.lin_in[l].as<float>();
+      fc.lin_in_ld[l] = 2 * d;
+    }
+    LGNN_HIP_CHECK(hipMemcpy2DAsync(fc.lin_in[0].p, size_t(2 * h->dims[0]) * 4, h->X, size_t(h->dims[0]) * 4,
+                                    size_t(h->dims[0]) * 4, size_t(N), hipMemcpyDeviceToDevice, s));
+    for (int l = 0; l < L; ++l) {
+      const int64_t d = h->dims[l], dout = h->dims[l + 1];
+      float* cat = fc.lin_in[l].as<float>();
+      SpmmArgs a{};
+      a.rowptr = h->P.rowptr; a.col = h->P.col; a.val = h->P.val; a.nrows = N;
+      a.in = cat; a.in_ld = 2 * d; a.out = cat + d; a.out_ld = 2 * d; a.width = d; a.out_act = -1;
+      LGNN_CALL(launch_spmm_ex(a, 1, s));
+      GemmEpilogue ep;
+      ep.bias = h->b[l];
+      if (l < L - 1) {
+        ep.out_act = h->act;
+        float* nxt = fc.lin_in[l + 1].as<float>();
+        LGNN_CALL(launch_gemm(cat, 2 * d, h->Wt[l].as<float>(), dout, nxt, 2 * dout, N, 2 * d, dout, ep, s));
+        fc.hact_p[l] = nxt;
+        fc.hact_ld[l] = 2 * dout;
+      } else {
+        LGNN_CALL(launch_gemm(cat, 2 * d, h->Wt[l].as<float>(), dout, fc.out.as<float>(), dout, N, 2 * d, dout, ep, s));
+      }
+    }
+  }
+  return 0;
+}
+
+int forward_ensure(lgnn_ctx* h, hipStream_t s) {
+  LGNN_REQUIRE(h->L > 0 && h->X, "no model bound (call lgnn_bind_model first)");
+  if (h->fc.valid) return 0;
+  for (int l = 0; l < h->L; ++l) {
+    LGNN_CALL(h->Wt[l].reserve(size_t(h->in_dim[l]) * h->dims[l + 1] * 4));
+    LGNN_CALL(launch_transpose(h->W[l], h->dims[l + 1], h->in_dim[l], h->Wt[l].as<float>(), s));
+  }
+  LGNN_CALL(gcn_or_sage_forward(h, s));
+  h->fc.valid = true;
+  h->fc.aux_valid = false;
+  for (int l = 0; l < kMaxLayers; ++l) h->fc.gram_valid[l] = false;
+  return 0;
+}
+
+int forward_ensure_grams(lgnn_ctx* h, hipStream_t s) {
+  LGNN_CALL(forward_ensure(h, s));
+  for (int l = 0; l < h->L; ++l) {
+    if (h->fc.gram_valid[l]) continue;
+    const int64_t D = h->in_dim[l];
+    LGNN_CALL(h->fc.gram_raw[l].reserve(size_t(D) * D * 4));
+    LGNN_HIP_CHECK(hipMemsetAsync(h->fc.gram_raw[l].p, 0, size_t(D) * D * 4, s));
+    LGNN_CALL(launch_gram(h->fc.lin_in_p[l], h->fc.lin_in_ld[l], h->N, D, h->fc.gram_raw[l].as<float>(), s));
+    h->fc.gram_valid[l] = true;
+  }
+  return 0;
+}
+
+// rowsum(P) and P @ lin_in[l] for GCN (closed-form diagonal GGN and last-layer features)
+int forward_ensure_aux(lgnn_ctx* h, hipStream_t s) {
+  LGNN_CALL(forward_ensure(h, s));
+  if (h->fc.aux_valid) return 0;
+  LGNN_CALL(h->fc.rowsum.reserve(size_t(h->N) * 4));
+  LGNN_CALL(launch_csr_rowsum(h->P, h->N, h->fc.rowsum.as<float>(), s));
+  if (h->kind == LGNN_KIND_GCN) {
+    for (int l = 0; l < h->L; ++l) {
+      const int64_t d = h->dims[l];
+      LGNN_CALL(h->fc.prop_in[l].reserve(size_t(h->N) * d * 4));
+      LGNN_CALL(launch_spmm(h->P, h->N, h->fc.lin_in_p[l], h->fc.lin_in_ld[l], h->fc.prop_in[l].as<float>(), d, d, 0, s));
+    }
+  }
+  h->fc.aux_valid = true;
+  return 0;
+}
+
+}  // namespace lgnn
+
+using namespace lgnn;
+
+extern "C" int lgnn_abi_version(void) { return LGNN_ABI_VERSION; }
+extern "C" const char* lgnn_last_error(void) { return lgnn::g_error.c_str(); }
+
+extern "C" int lgnn_create(lgnn_ctx** out, int64_t num_nodes, const int64_t* edge_index, int64_t num_edges, int kind,
+                           int symmetric, void* stream) {
+  if (!out) { set_error("null output handle"); return 2; }
+  *out = nullptr;
+  LGNN_REQUIRE(kind == LGNN_KIND_GCN || kind == LGNN_KIND_SAGE, "unknown graph kind");
+  LGNN_REQUIRE(num_edges == 0 || edge_index != nullptr, "edge_index is null");
+  lgnn_ctx* h = new (std::nothrow) lgnn_ctx();
+  if (!h) { set_error("out of host memory"); return 1; }
+  h->N = num_nodes;
+  h->kind = kind;
+  h->sym = symmetric != 0;
+  int rc = graph_build(h, edge_index, num_edges, static_cast<hipStream_t>(stream));
+  if (rc == 0) {
+    rc = h->ws.pos.reserve(size_t(num_nodes) * 4);
+    if (rc == 0) rc = launch_fill_i32(h->ws.pos.as<int32_t>(), num_nodes, INT32_MAX, static_cast<hipStream_t>(stream));
+  }
+  if (rc != 0) { lgnn_destroy(h); return rc; }
+  *out = h;
+  return 0;
+}
+
+extern "C" void lgnn_destroy(lgnn_ctx* h) {
+  if (!h) return;
+  (void)hipDeviceSynchronize();
+  DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
+                    &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.planes_a,
+                    &h->ws.planes_b, &h->ws.misc, &h->ws.top, &h->ws.flags};
+  for (DevBuf* b : bufs) b->release();
+  for (int l = 0; l < kMaxLayers; ++l) {
+    h->Wt[l].release(); h->fc.lin_in[l].release(); h->fc.act_out[l].release(); h->fc.gram_raw[l].release();
+    h->fc.prop_in[l].release(); h->ws.gram_scratch[l].release();
+  }
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  delete h;
+}
+
+extern "C" int64_t lgnn_nnz(const lgnn_ctx* h) { return h ? h->nnz : -1; }
+extern "C" int64_t lgnn_num_nodes(const lgnn_ctx* h) { return h ? h->N : -1; }
+extern "C" int lgnn_is_symmetric(const lgnn_ctx* h) { return h && h->sym ? 1 : 0; }
+
+extern "C" int lgnn_bind_model(lgnn_ctx* h, int num_layers, const int64_t* dims, const float* const* weights,
+                               const float* const* biases, const float* X, int activation, int likelihood) {
+  if (!h) { set_error("null context"); return 2; }
+  LGNN_REQUIRE(num_layers >= 1 && num_layers <= kMaxLayers, "num_layers out of range");
+  LGNN_REQUIRE(dims && weights && biases && X, "null model pointer");
+  LGNN_REQUIRE(activation == LGNN_ACT_RELU || activation == LGNN_ACT_TANH, "unsupported activation");
+  LGNN_REQUIRE(likelihood == LGNN_LIK_CLASSIFICATION || likelihood == LGNN_LIK_REGRESSION, "unsupported likelihood");
+  h->L = num_layers;
+  h->n_params = 0;
+  for (int l = 0; l <= num_layers; ++l) {
+    LGNN_REQUIRE(dims[l] > 0, "layer width must be positive");
+    h->dims[l] = dims[l];
+  }
+  for (int l = 0; l < num_layers; ++l) {
+    LGNN_REQUIRE(weights[l] && biases[l], "null weight / bias pointer (bias=False is not supported)");
+    h->W[l] = weights[l];
+    h->b[l] = biases[l];
+    h->in_dim[l] = h->kind == LGNN_KIND_SAGE ? 2 * dims[l] : dims[l];
+    h->n_params += h->in_dim[l] * dims[l + 1] + dims[l + 1];
+  }
+  h->X = X;
+  h->act = activation;
+  h->lik = likelihood;
+  return lgnn_invalidate(h);
+}
+
+extern "C" int lgnn_invalidate(lgnn_ctx* h) {
+  if (!h) { set_error("null context"); return 2; }
+  h->fc.valid = false;
+  h->fc.aux_valid = false;
+  for (int l = 0; l < kMaxLayers; ++l) h->fc.gram_valid[l] = false;
+  return 0;
+}
+
+extern "C" int lgnn_set_workspace_limit(lgnn_ctx* h, int64_t bytes) {
+  if (!h) { set_error("null context"); return 2; }
+  LGNN_REQUIRE(bytes >= (int64_t(1) << 20), "workspace limit too small");
+  h->ws_limit = bytes;
+  return 0;
+}
+
+extern "C" int64_t lgnn_device_bytes(const lgnn_ctx* h) {
+  if (!h) return -1;
+  size_t t = 0;
+  const DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
+                          &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->ws.pos, &h->ws.seeds, &h->ws.probs,
+                          &h->ws.planes_a, &h->ws.planes_b, &h->ws.misc, &h->ws.top, &h->ws.flags};
+  for (const DevBuf* b : bufs) t += b->bytes;
+  for (int l = 0; l < kMaxLayers; ++l)
+    t += h->Wt[l].bytes + h->fc.lin_in[l].bytes + h->fc.act_out[l].bytes + h->fc.gram_raw[l].bytes +
+         h->fc.prop_in[l].bytes + h->ws.gram_scratch[l].bytes;
+  return int64_t(t);
+}
+
+extern "C" int lgnn_forward_all(lgnn_ctx* h, float* out, void* stream) {
+  if (!h || !out) { set_error("null argument"); return 2; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  LGNN_CALL(forward_ensure(h, s));
+  LGNN_HIP_CHECK(hipMemcpyAsync(out, h->fc.out.p, size_t(h->N) * h->dims[h->L] * 4, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+extern "C" int lgnn_forward(lgnn_ctx* h, const int64_t* idx, int64_t M, float* out, void* stream) {
+  if (!h || (M > 0 && (!idx || !out))) { set_error("null argument"); return 2; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  LGNN_CALL(forward_ensure(h, s));
+  return launch_gather_rows(h->fc.out.as<float>(), h->dims[h->L], idx, M, h->dims[h->L], out, s);
+}
+
+extern "C" int lgnn_enable_kernel_timing(lgnn_ctx* h, int enable) {
+  if (!h) { set_error("null context"); return 2; }
+  h->timing = enable != 0;
+  h->ev_used = 0;
+  h->ev_planes = 0;
+  return 0;
+}
+
+extern "C" int lgnn_kernel_timing_read(lgnn_ctx* h, int64_t* launches, double* total_ms, int64_t* planes) {
+  if (!h || !launches || !total_ms || !planes) { set_error("null argument"); return 2; }
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    LGNN_HIP_CHECK(hipEventSynchronize(h->ev[i + 1]));
+    float ms = 0.f;
+    LGNN_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+    tot += ms;
+  }
+  *launches = int64_t(h->ev_used / 2);
+  *total_ms = tot;
+  *planes = h->ev_planes;
+  return 0;
+}
+
+extern "C" int lgnn_kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train,
+                                    uint32_t flags, float* const* A_out, float* const* B_out, float* loss_out,
+                                    void* stream) {
+  if (!h) { set_error("null context"); return 2; }
+  return kfac_accumulate(h, idx, y, M, n_train, flags, A_out, B_out, loss_out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lgnn_diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags,
+                                    float* diag_out, float* loss_out, void* stream) {
+  if (!h) { set_error("null context"); return 2; }
+  return diag_accumulate(h, idx, y, M, flags, diag_out, loss_out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lgnn_lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out,
+                                              float* loss_out, void* stream) {
+  if (!h) { set_error("null context"); return 2; }
+  return lastlayer_full_accumulate(h, idx, y, M, H_out, loss_out, static_cast<hipStream_t>(stream));
+}

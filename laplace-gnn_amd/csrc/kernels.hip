@@ -1,0 +1,644 @@
+// Hand-written gfx950 kernels of the curvature path:
+//   * CSR SpMM with dense right-hand sides (sub-wave groups per row, 16-byte gathers)
+//   * fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32) with bias / activation-derivative epilogues
+//   * fp32 MFMA Gram contraction X^T X (upper sub-tiles, split over rows, float atomics into a
+//     per-call scratch) and the symmetric accumulate into the caller's factor
+//   * the fused SpMM^T -> LDS row-block tile -> MFMA Gram kernel (gathered rows never reach HBM)
+// wave = 64 lanes; MFMA 32x32x2 f32: lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
+// C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)   (cdna_hip_programming.md section 3).
+#include "lgnn_internal.h"
+
+namespace lgnn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+  return act == LGNN_ACT_RELU ? fmaxf(x, 0.f) : tanhf(x);
+}
+// derivative of the activation expressed through its OUTPUT h (relu: h > 0 <=> pre > 0)
+__device__ __forceinline__ float act_deriv_from_out(float h, int act) {
+  return act == LGNN_ACT_RELU ? (h > 0.f ? 1.f : 0.f) : (1.f - h * h);
+}
+
+// =====================================================================================
+// SpMM: out[plane][r][0:width) = epi( self[r] + sum_j val[j] * in[plane][col[j]][0:width) )
+// LPR lanes cooperate on one row (VEC floats each per pass), 64/LPR rows per wave.
+// =====================================================================================
+
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, sl = lane % LPR;
+  const int64_t row = (int64_t(blockIdx.x) * 4 + wave) * RPW + sub;
+  if (row >= a.nrows) return;
+  const int64_t plane = blockIdx.y;
+  const float* __restrict__ in = a.in + plane * a.in_plane_stride;
+  float* __restrict__ out = a.out + plane * a.out_plane_stride;
+  const int32_t s = a.rowptr[row], e = a.rowptr[row + 1];
+  for (int64_t c0 = int64_t(sl) * VEC; c0 < a.width; c0 += int64_t(LPR) * VEC) {
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    int32_t p = s;
+    for (; p + 4 <= e; p += 4) {
+      int32_t j0 = a.col[p], j1 = a.col[p + 1], j2 = a.col[p + 2], j3 = a.col[p + 3];
+      float v0 = a.val[p], v1 = a.val[p + 1], v2 = a.val[p + 2], v3 = a.val[p + 3];
+      if constexpr (VEC == 4) {
+        float4 x0 = *reinterpret_cast<const float4*>(in + int64_t(j0) * a.in_ld + c0);
+        float4 x1 = *reinterpret_cast<const float4*>(in + int64_t(j1) * a.in_ld + c0);
+        float4 x2 = *reinterpret_cast<const float4*>(in + int64_t(j2) * a.in_ld + c0);
+        float4 x3 = *reinterpret_cast<const float4*>(in + int64_t(j3) * a.in_ld + c0);
+        acc[0] += v0 * x0.x; acc[1] += v0 * x0.y; acc[2] += v0 * x0.z; acc[3] += v0 * x0.w;
+        acc[0] += v1 * x1.x; acc[1] += v1 * x1.y; acc[2] += v1 * x1.z; acc[3] += v1 * x1.w;
+        acc[0] += v2 * x2.x; acc[1] += v2 * x2.y; acc[2] += v2 * x2.z; acc[3] += v2 * x2.w;
+        acc[0] += v3 * x3.x; acc[1] += v3 * x3.y; acc[2] += v3 * x3.z; acc[3] += v3 * x3.w;
+      } else {
+        float x0 = in[int64_t(j0) * a.in_ld + c0], x1 = in[int64_t(j1) * a.in_ld + c0];
+        float x2 = in[int64_t(j2) * a.in_ld + c0], x3 = in[int64_t(j3) * a.in_ld + c0];
+        acc[0] += v0 * x0; acc[0] += v1 * x1; acc[0] += v2 * x2; acc[0] += v3 * x3;
+      }
+    }
+    for (; p < e; ++p) {
+      int32_t j = a.col[p];
+      float v = a.val[p];
+      if constexpr (VEC == 4) {
+        float4 x = *reinterpret_cast<const float4*>(in + int64_t(j) * a.in_ld + c0);
+        acc[0] += v * x.x; acc[1] += v * x.y; acc[2] += v * x.z; acc[3] += v * x.w;
+      } else {
+        acc[0] += v * in[int64_t(j) * a.in_ld + c0];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float r = acc[v];
+      if (a.self) r += a.self[plane * a.self_plane_stride + row * a.self_ld + c0 + v];
+      if (a.hact) r *= act_deriv_from_out(a.hact[row * a.hact_ld + c0 + v], a.act);
+      if (a.out_act >= 0) r = act_apply(r, a.out_act);
+      acc[v] = r;
+    }
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(out + row * a.out_ld + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+      out[row * a.out_ld + c0] = acc[0];
+    }
+  }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int VEC>
+static int spmm_dispatch(const SpmmArgs& a, int64_t nplanes, hipStream_t s) {
+  const int64_t lanes_needed = cdiv(a.width, VEC);
+  int lpr = 1;
+  while (lpr < 64 && lpr < lanes_needed) lpr <<= 1;
+  const int rpw = 64 / lpr;
+  const dim3 grid{unsigned(cdiv(a.nrows, int64_t(4) * rpw)), unsigned(nplanes), 1u};
+  dim3 block(256);
+  switch (lpr) {
+    case 1: hipLaunchKernelGGL((spmm_kernel<1, VEC>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((spmm_kernel<2, VEC>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((spmm_kernel<4, VEC>), grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((spmm_kernel<8, VEC>), grid, block, 0, s, a); break;
+    case 16: hipLaunchKernelGGL((spmm_kernel<16, VEC>), grid, block, 0, s, a); break;
+    case 32: hipLaunchKernelGGL((spmm_kernel<32, VEC>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((spmm_kernel<64, VEC>), grid, block, 0, s, a); break;
+  }
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_spmm_ex(const SpmmArgs& a, int64_t nplanes, hipStream_t s) {
+  if (a.nrows <= 0 || a.width <= 0 || nplanes <= 0) return 0;
+  LGNN_REQUIRE(nplanes < 65536, "too many planes for one launch");
+  const bool vec = (a.width % 4 == 0) && (a.in_ld % 4 == 0) && (a.out_ld % 4 == 0) &&
+                   (a.in_plane_stride % 4 == 0) && (a.out_plane_stride % 4 == 0) && aligned16(a.in) &&
+                   aligned16(a.out);
+  return vec ? spmm_dispatch<4>(a, nplanes, s) : spmm_dispatch<1>(a, nplanes, s);
+}
+
+int launch_spmm(const Csr& m, int64_t nrows, const float* in, int64_t in_ld, float* out, int64_t out_ld,
+                int64_t width, int epilogue, hipStream_t s) {
+  SpmmArgs a{};
+  a.rowptr = m.rowptr; a.col = m.col; a.val = m.val; a.nrows = nrows;
+  a.in = in; a.in_ld = in_ld; a.out = out; a.out_ld = out_ld; a.width = width;
+  a.out_act = epilogue == 0 ? -1 : (epilogue == 1 ? LGNN_ACT_RELU : LGNN_ACT_TANH);
+  return launch_spmm_ex(a, 1, s);
+}
+
+__global__ void csr_rowsum_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ val, int64_t n,
+                                  float* __restrict__ out) {
+  int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  float acc = 0.f;
+  for (int32_t p = rowptr[r]; p < rowptr[r + 1]; ++p) acc += val[p];
+  out[r] = acc;
+}
+int launch_csr_rowsum(const Csr& m, int64_t nrows, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(csr_rowsum_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, s, m.rowptr, m.val, nrows, out);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================
+// GEMM  C[R, Nout] = A[R, K] @ B[K, Nout]  (fp32 MFMA 32x32x2), 128x128 block tile, BK = 32
+// =====================================================================================
+constexpr int GBM = 128, GBN = 128, GBK = 32;
+
+struct GemmArgs {
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  int64_t R, K, Nout;
+  const float* bias;
+  const float* hact; int64_t hact_ld; int64_t hact_row_mod; int act;
+  int out_act;
+  int vecA, vecB;
+};
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ float As[GBM][GBK + 1];  // odd stride: column reads of the A operand are conflict free
+  __shared__ float Bs[GBK][GBN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int64_t row0 = int64_t(blockIdx.x) * GBM, col0 = int64_t(blockIdx.y) * GBN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  for (int64_t k0 = 0; k0 < g.K; k0 += GBK) {
+    const int kvalid = int(min(int64_t(GBK), g.K - k0));
+    // A tile: 128 rows x 32 k ; thread -> (row = tid/8 + 32*it, k4 = (tid%8)*4)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = (tid >> 3) + 32 * it, k4 = (tid & 7) * 4;
+      const int64_t grow = row0 + r;
+      float x[4] = {0.f, 0.f, 0.f, 0.f};
+      if (grow < g.R) {
+        const float* src = g.A + grow * g.lda + k0 + k4;
+        if (g.vecA && k4 + 4 <= kvalid) {
+          float4 t = *reinterpret_cast<const float4*>(src);
+          x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (k4 + q < kvalid) x[q] = src[q];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) As[r][k4 + q] = x[q];
+    }
+    // B tile: 32 k x 128 cols ; thread -> (k = tid/32 + 8*it, c4 = (tid%32)*4)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int k = (tid >> 5) + 8 * it, c4 = (tid & 31) * 4;
+      float x[4] = {0.f, 0.f, 0.f, 0.f};
+      if (k < kvalid) {
+        const float* src = g.B + (k0 + k) * g.ldb + col0 + c4;
+        if (g.vecB && col0 + c4 + 4 <= g.Nout) {
+          float4 t = *reinterpret_cast<const float4*>(src);
+          x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (col0 + c4 + q < g.Nout) x[q] = src[q];
+        }
+      }
+      *reinterpret_cast<float4*>(&Bs[k][c4]) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+    __syncthreads();
+    const int ksteps = (kvalid + 1) >> 1;
+    for (int kk = 0; kk < ksteps; ++kk) {
+      const int k = kk * 2 + lhi;
+      float av[2], bv[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) av[m] = As[wr * 64 + m * 32 + l31][k];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bv[n] = Bs[k][wc * 64 + n * 32 + l31];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // epilogue
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int64_t col = col0 + wc * 64 + n * 32 + l31;
+      if (col >= g.Nout) continue;
+      const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row >= g.R) continue;
+        float v = acc[m][n][r] + bias;
+        if (g.hact) {
+          const int64_t hr = g.hact_row_mod > 0 ? row % g.hact_row_mod : row;
+          v *= act_deriv_from_out(g.hact[hr * g.hact_ld + col], g.act);
+        }
+        if (g.out_act >= 0) v = act_apply(v, g.out_act);
+        g.C[row * g.ldc + col] = v;
+      }
+    }
+  }
+}
+
+int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t R,
+                int64_t K, int64_t Nout, const GemmEpilogue& ep, hipStream_t s) {
+  if (R <= 0 || Nout <= 0) return 0;
+  LGNN_REQUIRE(K > 0, "gemm with empty K");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.R = R; g.K = K; g.Nout = Nout;
+  g.bias = ep.bias; g.hact = ep.hact; g.hact_ld = ep.hact_ld; g.hact_row_mod = ep.hact_row_mod; g.act = ep.act;
+  g.out_act = ep.out_act;
+  g.vecA = (lda % 4 == 0) && aligned16(A);
+  g.vecB = (ldb % 4 == 0) && aligned16(B);
+  const dim3 grid{unsigned(cdiv(R, GBM)), unsigned(cdiv(Nout, GBN)), 1u};
+  hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, g);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================
+// Gram contraction  scratch[D, D] += X^T X  (upper sub-tiles only)
+// A workgroup owns a DT x DT output tile pair (ti <= tj) and a contiguous range of rows; its 4
+// waves split the 32x32 sub-tiles (upper triangle on diagonal tiles).  Row blocks of KT = 32 are
+// staged through LDS; every sub-tile MFMA reads its two operands straight from the LDS tile
+// (lane l: X[k0 + (l>>5)][sub*32 + (l&31)], conflict free for a row stride that is a multiple of 32).
+// =====================================================================================
+constexpr int KT = 32;
+
+template <int DT> struct GramCfg {
+  static constexpr int NSUB = DT / 32;
+  static constexpr int NP_DIAG = NSUB * (NSUB + 1) / 2;
+  static constexpr int NP_OFF = NSUB * NSUB;
+  static constexpr bool HAS_OFF = DT < 256;  // DT = 256 is only used when the whole factor is one tile
+  static constexpr int NSLOT = ((HAS_OFF ? NP_OFF : NP_DIAG) + 3) / 4;
+};
+
+// decode pair index p of the upper triangle (row-major) of an NSUB x NSUB grid
+__device__ __forceinline__ void decode_upper(int p, int nsub, int& si, int& sj) {
+  int i = 0;
+  while (p >= nsub - i) { p -= nsub - i; ++i; }
+  si = i; sj = i + p;
+}
+
+template <int NSLOT>
+__device__ __forceinline__ void gram_mfma_block(const float* __restrict__ ta, const float* __restrict__ tb,
+                                                int ldt, const int (&si)[NSLOT], const int (&sj)[NSLOT],
+                                                int nmine, int lane, f32x16 (&acc)[NSLOT]) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll 4
+  for (int kk = 0; kk < KT / 2; ++kk) {
+    const int k = kk * 2 + lhi;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      if (s < nmine) {
+        const float a = ta[k * ldt + si[s] * 32 + l31];
+        const float b = tb[k * ldt + sj[s] * 32 + l31];
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[s], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int NSLOT>
+__device__ __forceinline__ void gram_flush(float* __restrict__ scratch, int64_t D, int64_t i0, int64_t j0,
+                                           const int (&si)[NSLOT], const int (&sj)[NSLOT], int nmine, int lane,
+                                           const f32x16 (&acc)[NSLOT]) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    if (s < nmine) {
+      const int64_t j = j0 + sj[s] * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t i = i0 + si[s] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (i < D && j < D) atomicAdd(&scratch[i * D + j], acc[s][r]);
+      }
+    }
+  }
+}
+
+template <int DT, int VEC>
+__global__ __launch_bounds__(256) void gram_mem_kernel(const float* __restrict__ X, int64_t ld, int64_t R, int64_t D,
+                                                       float* __restrict__ scratch, int64_t rows_per_wg, int ntile) {
+  using Cfg = GramCfg<DT>;
+  constexpr int NSLOT = Cfg::NSLOT;
+  constexpr int PANELS = Cfg::HAS_OFF ? 2 : 1;
+  __shared__ float tile[PANELS][KT][DT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // tile pair (ti <= tj) from blockIdx.x
+  int ti, tj;
+  decode_upper(int(blockIdx.x), ntile, ti, tj);
+  const bool diag = ti == tj;
+  const int np = diag ? Cfg::NP_DIAG : Cfg::NP_OFF;
+  int si[NSLOT], sj[NSLOT];
+  int nmine = 0;
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int p = wave + 4 * s;
+    si[s] = sj[s] = 0;
+    if (p < np) {
+      if (diag) decode_upper(p, Cfg::NSUB, si[s], sj[s]);
+      else { si[s] = p / Cfg::NSUB; sj[s] = p % Cfg::NSUB; }
+      nmine = s + 1;
+    }
+  }
+  f32x16 acc[NSLOT];
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+  const int64_t r_begin = int64_t(blockIdx.y) * rows_per_wg;
+  const int64_t r_end = min(R, r_begin + rows_per_wg);
+  const int64_t cA = int64_t(ti) * DT, cB = int64_t(tj) * DT;
+  constexpr int PER_THREAD = KT * DT / 4 / 256;  // float4 slots per thread per panel
+  float4 stage[PANELS][PER_THREAD];
+
+  auto load_block = [&](int64_t rb) {
+#pragma unroll
+    for (int pn = 0; pn < PANELS; ++pn) {
+      const int64_t c0 = pn == 0 ? cA : cB;
+      if (pn == 1 && diag) continue;
+#pragma unroll
+      for (int it = 0; it < PER_THREAD; ++it) {
+        const int flat = it * 256 + tid;
+        const int r = flat / (DT / 4), c4 = (flat % (DT / 4)) * 4;
+        const int64_t grow = rb + r, gcol = c0 + c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grow < r_end) {
+          const float* src = X + grow * ld + gcol;
+          if (VEC == 4 && gcol + 4 <= D) {
+            v = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (gcol + 0 < D) v.x = src[0];
+            if (gcol + 1 < D) v.y = src[1];
+            if (gcol + 2 < D) v.z = src[2];
+            if (gcol + 3 < D) v.w = src[3];
+          }
+        }
+        stage[pn][it] = v;
+      }
+    }
+  };
+  auto store_block = [&]() {
+#pragma unroll
+    for (int pn = 0; pn < PANELS; ++pn) {
+      if (pn == 1 && diag) continue;
+#pragma unroll
+      for (int it = 0; it < PER_THREAD; ++it) {
+        const int flat = it * 256 + tid;
+        const int r = flat / (DT / 4), c4 = (flat % (DT / 4)) * 4;
+        *reinterpret_cast<float4*>(&tile[pn][r][c4]) = stage[pn][it];
+      }
+    }
+  };
+
+  if (r_begin < r_end) {
+    load_block(r_begin);
+    for (int64_t rb = r_begin; rb < r_end; rb += KT) {
+      store_block();
+      __syncthreads();
+      if (rb + KT < r_end) load_block(rb + KT);  // in flight while the MFMAs run
+      const float* ta = &tile[0][0][0];
+      const float* tb = (PANELS == 2 && !diag) ? &tile[PANELS - 1][0][0] : ta;
+      gram_mfma_block<NSLOT>(ta, tb, DT, si, sj, nmine, lane, acc);
+      __syncthreads();
+    }
+    gram_flush<NSLOT>(scratch, D, cA, cB, si, sj, nmine, lane, acc);
+  }
+}
+
+int launch_gram(const float* X, int64_t ld, int64_t R, int64_t D, float* scratch, hipStream_t s) {
+  if (R <= 0 || D <= 0) return 0;
+  const bool vec = (ld % 4 == 0) && aligned16(X);
+  int dt = D <= 64 ? 64 : (D <= 128 ? 128 : (D <= 256 ? 256 : 128));
+  const int ntile = int(cdiv(D, dt));
+  const int npairs = ntile * (ntile + 1) / 2;
+  // split the rows so that about 4 workgroups per CU exist (256 CUs), at least one 32-row block each
+  int64_t want_wg = std::max<int64_t>(1, (1024 + npairs - 1) / npairs);
+  int64_t rows_per_wg = std::max<int64_t>(KT, cdiv(cdiv(R, want_wg), KT) * KT);
+  const int64_t ksplit = cdiv(R, rows_per_wg);
+  LGNN_REQUIRE(ksplit < 65536, "gram split too large");
+  const dim3 grid{unsigned(npairs), unsigned(ksplit), 1u};
+#define LGNN_GRAM_LAUNCH(DTV)                                                                                   \
+  if (vec) hipLaunchKernelGGL((gram_mem_kernel<DTV, 4>), grid, dim3(256), 0, s, X, ld, R, D, scratch, rows_per_wg, ntile); \
+  else hipLaunchKernelGGL((gram_mem_kernel<DTV, 1>), grid, dim3(256), 0, s, X, ld, R, D, scratch, rows_per_wg, ntile);
+  if (dt == 64) { LGNN_GRAM_LAUNCH(64) }
+  else if (dt == 128) { LGNN_GRAM_LAUNCH(128) }
+  else { LGNN_GRAM_LAUNCH(256) }
+#undef LGNN_GRAM_LAUNCH
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void sym_accumulate_kernel(const float* __restrict__ scratch, int64_t D, float scale,
+                                      float* __restrict__ out) {
+  const int64_t n = D * D;
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < n; q += stride) {
+    const int64_t i = q / D, j = q - i * D;
+    const int64_t a = i < j ? i : j, b = i < j ? j : i;
+    out[q] += scale * scratch[a * D + b];
+  }
+}
+int launch_sym_accumulate(const float* scratch, int64_t D, float scale, float* out, hipStream_t s) {
+  if (D <= 0) return 0;
+  const int64_t n = D * D;
+  hipLaunchKernelGGL(sym_accumulate_kernel, dim3(unsigned(std::min<int64_t>(cdiv(n, 256), 2048))), dim3(256), 0, s,
+                     scratch, D, scale, out);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================
+// Fused SpMM^T -> Gram.  Row task (plane p, node n): y = epi(self + sum_j val[j] * in[p][col[j]][:]);
+// the 32-row block of y is built in LDS by the 4 waves (LPR lanes per row, 16-byte gathers), then
+// contracted into the workgroup's register-resident upper-triangular Gram accumulators.  y is
+// written to HBM only when a lower layer needs it.  Workgroups walk blocks plane-major so that the
+// plane being gathered stays resident in the Infinity Cache.
+// =====================================================================================
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void spmm_gram_kernel(FusedArgs a) {
+  using Cfg = GramCfg<DT>;
+  constexpr int NSLOT = (Cfg::NP_DIAG + 3) / 4;
+  constexpr int LPR = DT / 4 >= 64 ? 64 : DT / 4;  // lanes per row (float4 each)
+  constexpr int RPW = 64 / LPR;
+  constexpr int PASSES = DT / (LPR * 4);  // 1 for DT <= 256
+  static_assert(PASSES == 1, "DT <= 256");
+  __shared__ float tile[KT][DT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sub = lane / LPR, sl = lane % LPR;
+  const int c0 = sl * 4;
+
+  int si[NSLOT], sj[NSLOT];
+  int nmine = 0;
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int p = wave + 4 * s;
+    si[s] = sj[s] = 0;
+    if (p < Cfg::NP_DIAG) { decode_upper(p, Cfg::NSUB, si[s], sj[s]); nmine = s + 1; }
+  }
+  f32x16 acc[NSLOT];
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+  const int64_t blocks_per_plane = (a.nrows + KT - 1) / KT;
+  const int64_t nblocks = blocks_per_plane * a.nplanes;
+  const bool col_ok = c0 < a.width;  // width % 4 == 0 is required by the launcher
+
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int64_t plane = blk / blocks_per_plane;
+    const int64_t rb = (blk - plane * blocks_per_plane) * KT;
+    const float* __restrict__ in = a.in + plane * a.in_plane_stride;
+    // each wave produces rows  wave*RPW + sub + 4*RPW*it
+#pragma unroll 1
+    for (int it = 0; it < KT / (4 * RPW); ++it) {
+      const int r = it * 4 * RPW + wave * RPW + sub;
+      const int64_t row = rb + r;
+      float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < a.nrows && col_ok) {
+        const int32_t s = a.rowptr[row], e = a.rowptr[row + 1];
+        int32_t p = s;
+        for (; p + 4 <= e; p += 4) {
+          const int32_t j0 = a.col[p], j1 = a.col[p + 1], j2 = a.col[p + 2], j3 = a.col[p + 3];
+          const float v0 = a.val[p], v1 = a.val[p + 1], v2 = a.val[p + 2], v3 = a.val[p + 3];
+          const float4 x0 = *reinterpret_cast<const float4*>(in + int64_t(j0) * a.in_ld + c0);
+          const float4 x1 = *reinterpret_cast<const float4*>(in + int64_t(j1) * a.in_ld + c0);
+          const float4 x2 = *reinterpret_cast<const float4*>(in + int64_t(j2) * a.in_ld + c0);
+          const float4 x3 = *reinterpret_cast<const float4*>(in + int64_t(j3) * a.in_ld + c0);
+          y.x += v0 * x0.x; y.y += v0 * x0.y; y.z += v0 * x0.z; y.w += v0 * x0.w;
+          y.x += v1 * x1.x; y.y += v1 * x1.y; y.z += v1 * x1.z; y.w += v1 * x1.w;
+          y.x += v2 * x2.x; y.y += v2 * x2.y; y.z += v2 * x2.z; y.w += v2 * x2.w;
+          y.x += v3 * x3.x; y.y += v3 * x3.y; y.z += v3 * x3.z; y.w += v3 * x3.w;
+        }
+        for (; p < e; ++p) {
+          const int32_t j = a.col[p];
+          const float v = a.val[p];
+          const float4 x = *reinterpret_cast<const float4*>(in + int64_t(j) * a.in_ld + c0);
+          y.x += v * x.x; y.y += v * x.y; y.z += v * x.z; y.w += v * x.w;
+        }
+        if (a.self) {
+          const float4 t = *reinterpret_cast<const float4*>(a.self + plane * a.self_plane_stride + row * a.self_ld + c0);
+          y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+        }
+        if (a.hact) {
+          const float4 hh = *reinterpret_cast<const float4*>(a.hact + row * a.hact_ld + c0);
+          y.x *= act_deriv_from_out(hh.x, a.act); y.y *= act_deriv_from_out(hh.y, a.act);
+          y.z *= act_deriv_from_out(hh.z, a.act); y.w *= act_deriv_from_out(hh.w, a.act);
+        }
+        if (a.store)
+          *reinterpret_cast<float4*>(a.store + plane * a.store_plane_stride + row * a.store_ld + c0) = y;
+      }
+      *reinterpret_cast<float4*>(&tile[r][c0]) = y;
+    }
+    __syncthreads();
+    gram_mfma_block<NSLOT>(&tile[0][0], &tile[0][0], DT, si, sj, nmine, lane, acc);
+    __syncthreads();
+  }
+  gram_flush<NSLOT>(a.scratch, a.width, 0, 0, si, sj, nmine, lane, acc);
+}
+
+int launch_spmm_gram_ex(const FusedArgs& a, hipStream_t s) {
+  if (a.nrows <= 0 || a.nplanes <= 0 || a.width <= 0) return 0;
+  LGNN_REQUIRE(a.width <= 256 && a.width % 4 == 0, "fused SpMM+Gram needs width <= 256 and width % 4 == 0");
+  LGNN_REQUIRE(a.in_ld % 4 == 0 && a.in_plane_stride % 4 == 0 && aligned16(a.in), "fused SpMM+Gram alignment");
+  const int64_t nblocks = cdiv(a.nrows, KT) * a.nplanes;
+  const unsigned grid = unsigned(std::min<int64_t>(nblocks, 512));  // 2 workgroups per CU, persistent
+  if (a.width <= 64) hipLaunchKernelGGL((spmm_gram_kernel<64>), dim3(grid), dim3(256), 0, s, a);
+  else if (a.width <= 128) hipLaunchKernelGGL((spmm_gram_kernel<128>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((spmm_gram_kernel<256>), dim3(grid), dim3(256), 0, s, a);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+bool fused_supported(int64_t width, int64_t in_ld, int64_t in_plane_stride, const void* in) {
+  return width <= 256 && width % 4 == 0 && in_ld % 4 == 0 && in_plane_stride % 4 == 0 && aligned16(in);
+}
+
+int launch_spmm_gram(const Csr& m, int64_t nrows, int64_t nplanes, const float* in, float* store_or_null,
+                     int64_t width, float* scratch, hipStream_t s) {
+  FusedArgs a{};
+  a.rowptr = m.rowptr; a.col = m.col; a.val = m.val; a.nrows = nrows; a.nplanes = nplanes;
+  a.in = in; a.in_ld = width; a.in_plane_stride = nrows * width;
+  a.store = store_or_null; a.store_ld = width; a.store_plane_stride = nrows * width;
+  a.width = width; a.scratch = scratch;
+  return launch_spmm_gram_ex(a, s);
+}
+
+// =====================================================================================
+// small utilities
+// =====================================================================================
+__global__ void transpose_kernel(const float* __restrict__ in, int64_t rows, int64_t cols, float* __restrict__ out) {
+  __shared__ float t[32][33];
+  const int64_t bx = int64_t(blockIdx.x) * 32, by = int64_t(blockIdx.y) * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int64_t r = by + i, c = bx + threadIdx.x;
+    if (r < rows && c < cols) t[i][threadIdx.x] = in[r * cols + c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int64_t r = bx + i, c = by + threadIdx.x;  // out is [cols, rows]
+    if (r < cols && c < rows) out[r * rows + c] = t[threadIdx.x][i];
+  }
+}
+int launch_transpose(const float* in, int64_t rows, int64_t cols, float* out, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return 0;
+  hipLaunchKernelGGL(transpose_kernel, dim3(unsigned(cdiv(cols, 32)), unsigned(cdiv(rows, 32))), dim3(32, 8), 0, s, in,
+                     rows, cols, out);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+int launch_fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(unsigned(std::min<int64_t>(cdiv(n, 256), 2048))), dim3(256), 0, s, p, n, v);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ in, int64_t ld, const int64_t* __restrict__ idx,
+                                   int64_t M, int64_t width, int64_t nrows_in, float* __restrict__ out,
+                                   int* __restrict__ bad) {
+  const int64_t total = M * width;
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < total; q += stride) {
+    const int64_t m = q / width, c = q - m * width;
+    const int64_t n = idx[m];
+    if (n < 0 || n >= nrows_in) { if (bad) *bad = 1; out[q] = 0.f; continue; }
+    out[q] = in[n * ld + c];
+  }
+}
+int launch_gather_rows(const float* in, int64_t ld, const int64_t* idx, int64_t M, int64_t width, float* out,
+                       hipStream_t s) {
+  if (M <= 0 || width <= 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M * width, 256), 2048))), dim3(256), 0,
+                     s, in, ld, idx, M, width, int64_t(1) << 62, out, (int*)nullptr);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace lgnn

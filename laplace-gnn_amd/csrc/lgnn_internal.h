@@ -1,0 +1,211 @@
+// Internal declarations shared by the HIP translation units of liblaplace_gnn_hip.so.
+// gfx950 (MI355X / CDNA4) only: wave64, fp32-input MFMA, 160 KiB LDS per CU.
+#pragma once
+#include <cstring>  // rocprim's texture iterator needs host memset declared first
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/laplace_gnn_hip.h"
+
+namespace lgnn {
+
+void set_error(const std::string& msg);
+
+#define LGNN_HIP_CHECK(expr)                                                              \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      lgnn::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+      return 1;                                                                           \
+    }                                                                                     \
+  } while (0)
+
+#define LGNN_REQUIRE(cond, msg)                                                           \
+  do {                                                                                    \
+    if (!(cond)) {                                                                        \
+      lgnn::set_error(std::string(msg) + " (" #cond ")");                                 \
+      return 2;                                                                           \
+    }                                                                                     \
+  } while (0)
+
+#define LGNN_CALL(expr)                                                                   \
+  do {                                                                                    \
+    int _rc = (expr);                                                                     \
+    if (_rc != 0) return _rc;                                                             \
+  } while (0)
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// grow-only device buffer (no allocation in steady state)
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t want);
+  void release();
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// CSR with int32 indices (N, nnz < 2^31), fp32 values aligned with `col`
+struct Csr {
+  int32_t* rowptr = nullptr;  // [n+1]
+  int32_t* col = nullptr;     // [nnz]
+  float* val = nullptr;       // [nnz]
+};
+
+constexpr int kMaxLayers = 8;
+
+struct ForwardCache {
+  bool valid = false;
+  bool aux_valid = false;            // rowsum / propagated inputs for diag + last layer
+  bool gram_valid[kMaxLayers] = {};  // raw input Grams (upper triangle) per layer
+  DevBuf lin_in[kMaxLayers];         // GraphSAGE: cat_l = [h_l | P h_l]  [N, 2 d_l]
+  DevBuf act_out[kMaxLayers];        // GCN: h_{l+1} = act(P Z_l), l < L-1 : [N, out_l]
+  const float* lin_in_p[kMaxLayers] = {};  // what nn.Linear l sees: [N, in_l] with row stride lin_in_ld
+  int64_t lin_in_ld[kMaxLayers] = {};
+  const float* hact_p[kMaxLayers] = {};    // activation output h_{l+1} (input of layer l+1), row stride hact_ld
+  int64_t hact_ld[kMaxLayers] = {};
+  DevBuf out;                        // logits for all nodes [N, C]
+  DevBuf tmp;                        // [N, max width] scratch of the forward
+  DevBuf gram_raw[kMaxLayers];       // [in_l, in_l] raw in^T in (upper sub-tiles valid)
+  DevBuf prop_in[kMaxLayers];        // P @ lin_in[l]  [N, in_l]   (diag / last layer; GCN)
+  DevBuf rowsum;                     // rowsum(P) [N]
+};
+
+struct Workspace {
+  DevBuf pos;       // int32 [N]   batch position of a node, INT_MAX if not in batch
+  DevBuf seeds;     // fp32 [M, C, C] (c-major rows inside a sample: [m][c][k])
+  DevBuf probs;     // fp32 [M, C] softmax
+  DevBuf planes_a;  // backward planes, ping
+  DevBuf planes_b;  // backward planes, pong
+  DevBuf gram_scratch[kMaxLayers];  // [out_l, out_l] per-call partial B (upper sub-tiles)
+  DevBuf misc;
+  DevBuf top;    // top-layer gradient planes [C][N][C]
+  DevBuf flags;  // 64 B of asynchronous error flags
+};
+
+}  // namespace lgnn
+
+struct lgnn_ctx {
+  int64_t N = 0;
+  int64_t nnz = 0;
+  int kind = 0;
+  bool sym = false;
+  // stored 0/1 adjacency A (rows) and its transpose; AT aliases A when symmetric
+  lgnn::Csr A, AT;
+  lgnn::DevBuf A_rowptr, A_col, AT_rowptr, AT_col, val_fwd, val_bwd, deg_scale;
+  // propagation matrix P (forward) and P^T (backward) views into the buffers above
+  lgnn::Csr P, PT;
+  // model
+  int L = 0;
+  int64_t dims[lgnn::kMaxLayers + 1] = {};
+  int64_t in_dim[lgnn::kMaxLayers] = {};  // columns of weight l (2*dims[l] for GraphSAGE)
+  const float* W[lgnn::kMaxLayers] = {};
+  const float* b[lgnn::kMaxLayers] = {};
+  const float* X = nullptr;
+  int act = 0, lik = 0;
+  int64_t n_params = 0;
+  lgnn::DevBuf Wt[lgnn::kMaxLayers];  // W_l^T [in_l, out_l] (forward GEMM operand)
+  lgnn::ForwardCache fc;
+  lgnn::Workspace ws;
+  int64_t ws_limit = int64_t(8) << 30;
+  // timing of the dominant kernel
+  bool timing = false;
+  std::vector<hipEvent_t> ev;   // pairs (start, stop), grown on demand
+  size_t ev_used = 0;           // events recorded since the last reset
+  int64_t ev_planes = 0;
+};
+
+namespace lgnn {
+
+struct SpmmArgs {
+  const int32_t* rowptr;
+  const int32_t* col;
+  const float* val;
+  int64_t nrows;
+  const float* in;
+  int64_t in_ld;
+  int64_t in_plane_stride;
+  float* out;
+  int64_t out_ld;
+  int64_t out_plane_stride;
+  int64_t width;
+  const float* self;  // optional [plane][r][self_ld]
+  int64_t self_ld;
+  int64_t self_plane_stride;
+  const float* hact;  // optional: multiply by act'(hact[r]) (shared by all planes)
+  int64_t hact_ld;
+  int act;
+  int out_act;  // -1 none, else apply activation to the result
+};
+
+struct FusedArgs {
+  const int32_t* rowptr; const int32_t* col; const float* val;
+  int64_t nrows;     // rows per plane (N)
+  int64_t nplanes;
+  const float* in; int64_t in_ld; int64_t in_plane_stride;
+  float* store; int64_t store_ld; int64_t store_plane_stride;  // optional
+  const float* self; int64_t self_ld; int64_t self_plane_stride;  // optional
+  const float* hact; int64_t hact_ld; int act;                    // optional
+  int64_t width;     // D <= DT
+  float* scratch;    // [D, D]
+};
+
+// ---- graph.hip -----------------------------------------------------------------------
+int graph_build(lgnn_ctx* h, const int64_t* edge_index, int64_t E, hipStream_t s);
+
+// ---- kernels (launchers) -------------------------------------------------------------
+// out[r, 0:width) = sum_j val[j] * in[col[j], 0:width)   for r in [0, nrows)
+// epilogue: 0 none, 1 relu, 2 tanh
+int launch_spmm(const Csr& m, int64_t nrows, const float* in, int64_t in_ld, float* out, int64_t out_ld,
+                int64_t width, int epilogue, hipStream_t s);
+// rowsum of the CSR values
+int launch_csr_rowsum(const Csr& m, int64_t nrows, float* out, hipStream_t s);
+
+// C[R, Nout] = A[R, K] @ B[K, Nout] (+ bias[Nout]) (* dact(Hact[r / rows_per_node]))
+struct GemmEpilogue {
+  const float* bias = nullptr;
+  const float* hact = nullptr;  // activation output of the layer below, [N, Nout] (ld = hact_ld)
+  int64_t hact_ld = 0;
+  int act = 0;                  // LGNN_ACT_*
+  int64_t hact_row_mod = 0;     // hact row = r % hact_row_mod (planes are [c][n][w]); 0 -> r
+  int out_act = -1;             // apply activation to the result itself (-1 none)
+};
+int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t R,
+                int64_t K, int64_t Nout, const GemmEpilogue& ep, hipStream_t s);
+
+// scratch[D, D] (upper sub-tiles) += X[0:R, col0:col0+D)^T X[...]; X row-major with ld
+int launch_gram(const float* X, int64_t ld, int64_t R, int64_t D, float* scratch, hipStream_t s);
+// out[i,j] += scale * scratch[min(i,j), max(i,j)]
+int launch_sym_accumulate(const float* scratch, int64_t D, float scale, float* out, hipStream_t s);
+// fused: rows r=(plane, n): y = sum_j val*in_plane[col[j]]; scratch += y^T y; optional store of y
+int launch_spmm_ex(const SpmmArgs& a, int64_t nplanes, hipStream_t s);
+int launch_spmm_gram_ex(const FusedArgs& a, hipStream_t s);
+bool fused_supported(int64_t width, int64_t in_ld, int64_t in_plane_stride, const void* in);
+int launch_spmm_gram(const Csr& m, int64_t nrows, int64_t nplanes, const float* in, float* store_or_null,
+                     int64_t width, float* scratch, hipStream_t s);
+
+int launch_transpose(const float* in, int64_t rows, int64_t cols, float* out, hipStream_t s);
+int launch_fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s);
+int launch_gather_rows(const float* in, int64_t ld, const int64_t* idx, int64_t M, int64_t width, float* out,
+                       hipStream_t s);
+
+// ---- kfac.hip ---------------------------------------------------------------------------
+int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train, uint32_t flags,
+                    float* const* A_out, float* const* B_out, float* loss_out, hipStream_t s);
+int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bool want_seeds, bool fork_exact,
+                   float* loss_out, hipStream_t s);
+int batch_epilogue(lgnn_ctx* h, const int64_t* idx, int64_t M, hipStream_t s);
+int batch_check_flag(lgnn_ctx* h, hipStream_t s);
+// ---- forward.hip ------------------------------------------------------------------------
+int forward_ensure(lgnn_ctx* h, hipStream_t s);
+int forward_ensure_grams(lgnn_ctx* h, hipStream_t s);
+int forward_ensure_aux(lgnn_ctx* h, hipStream_t s);
+// ---- diag.hip ---------------------------------------------------------------------------
+int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags, float* diag_out,
+                    float* loss_out, hipStream_t s);
+int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out,
+                              float* loss_out, hipStream_t s);
+
+}  // namespace lgnn

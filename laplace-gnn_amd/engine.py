@@ -1,0 +1,228 @@
+"""Python handle on one ``lgnn_ctx`` (graph + bound model + caches) of the HIP library.
+
+PyTorch-ROCm is used for device memory and streams only: every tensor is handed over as a raw
+device pointer, the current torch stream as a ``hipStream_t``.  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import torch
+
+from . import _lib
+
+KINDS = {"gcn": _lib.KIND_GCN, "sage": _lib.KIND_SAGE}
+ACTS = {"relu": _lib.ACT_RELU, "tanh": _lib.ACT_TANH}
+LIKS = {"classification": _lib.LIK_CLASSIFICATION, "regression": _lib.LIK_REGRESSION}
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dev_ptr(t: torch.Tensor, dtype, what: str) -> C.c_void_p:
+    if not t.is_cuda:
+        raise _lib.HipLibraryError(f"{what} must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{what} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{what} must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+class GraphEngine:
+    """Graph ingest + model binding + per-batch curvature accumulation on one GPU."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, kind: str = "gcn", symmetric: bool = False):
+        self.lib = _lib.load()
+        if kind not in KINDS:
+            raise ValueError(f"kind must be one of {list(KINDS)}")
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError("edge_index must have shape [2, E]")
+        ei = edge_index.contiguous()
+        self.device = ei.device
+        self.kind = kind
+        self.num_nodes = int(num_nodes)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.lgnn_create(
+                C.byref(self._h), self.num_nodes, _dev_ptr(ei, torch.int64, "edge_index"), ei.shape[1],
+                KINDS[kind], int(bool(symmetric)), _stream(self.device))
+        _lib.check(rc, "lgnn_create")
+        self._bound = None  # keeps the bound tensors alive (borrowed pointers)
+        self.dims = None
+
+    # -- lifetime -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.lgnn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- graph ----------------------------------------------------------------------------------
+    @property
+    def nnz(self) -> int:
+        return int(self.lib.lgnn_nnz(self._h))
+
+    @property
+    def is_symmetric(self) -> bool:
+        return bool(self.lib.lgnn_is_symmetric(self._h))
+
+    def export_adj(self):
+        nnz = self.nnz
+        rows = torch.empty(nnz, dtype=torch.int64, device=self.device)
+        cols = torch.empty(nnz, dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.lgnn_export_adj(self._h, rows.data_ptr(), cols.data_ptr(), _stream(self.device)),
+                   "lgnn_export_adj")
+        return rows, cols
+
+    def adj_to_edge_index(self) -> torch.Tensor:
+        n = C.c_int64(0)
+        _lib.check(self.lib.lgnn_adj_to_edge_index(self._h, None, C.byref(n), _stream(self.device)),
+                   "lgnn_adj_to_edge_index")
+        out = torch.empty(2, n.value, dtype=torch.int64, device=self.device)
+        if n.value:
+            _lib.check(self.lib.lgnn_adj_to_edge_index(self._h, out.data_ptr(), C.byref(n), _stream(self.device)),
+                       "lgnn_adj_to_edge_index")
+        return out
+
+    def export_propagation(self):
+        nnz = self.nnz
+        rows = torch.empty(nnz, dtype=torch.int64, device=self.device)
+        cols = torch.empty(nnz, dtype=torch.int64, device=self.device)
+        vals = torch.empty(nnz, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.lgnn_export_propagation(self._h, rows.data_ptr(), cols.data_ptr(), vals.data_ptr(),
+                                                    _stream(self.device)), "lgnn_export_propagation")
+        return rows, cols, vals
+
+    # -- model ----------------------------------------------------------------------------------
+    def bind(self, X: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
+             act: str = "relu", likelihood: str = "classification"):
+        L = len(weights)
+        if L != len(biases) or L == 0:
+            raise ValueError("need one bias per weight")
+        if act not in ACTS:
+            raise NotImplementedError(f"activation {act!r} is not supported (relu, tanh)")
+        mult = 2 if self.kind == "sage" else 1
+        dims = [X.shape[1]]
+        for w, b in zip(weights, biases):
+            if w.shape[1] != mult * dims[-1] or b.shape[0] != w.shape[0]:
+                raise ValueError(f"weight shape {tuple(w.shape)} does not chain from width {dims[-1]}")
+            dims.append(w.shape[0])
+        if X.shape[0] != self.num_nodes:
+            raise ValueError("X must have one row per node")
+        Xp = _dev_ptr(X, torch.float32, "X")
+        wp = [_dev_ptr(w, torch.float32, "weight").value for w in weights]
+        bp = [_dev_ptr(b, torch.float32, "bias").value for b in biases]
+        dims_c = (C.c_int64 * (L + 1))(*dims)
+        rc = self.lib.lgnn_bind_model(self._h, L, dims_c, _lib.ptr_array(wp), _lib.ptr_array(bp), Xp, ACTS[act],
+                                      LIKS[likelihood])
+        _lib.check(rc, "lgnn_bind_model")
+        self._bound = (X, list(weights), list(biases))
+        self.dims = dims
+        self.in_dims = [mult * d for d in dims[:-1]]
+        self._versions = self._param_versions()
+
+    def _param_versions(self):
+        _, ws, bs = self._bound
+        return [(t.data_ptr(), t._version) for t in (*ws, *bs)]
+
+    def invalidate(self):
+        _lib.check(self.lib.lgnn_invalidate(self._h), "lgnn_invalidate")
+
+    def _sync_versions(self):
+        """In-place updates of the bound parameters (optimizer steps) invalidate the cached forward."""
+        if self._bound is None:
+            raise _lib.HipLibraryError("no model bound")
+        v = self._param_versions()
+        if v != self._versions:
+            self.invalidate()
+            self._versions = v
+
+    @property
+    def num_layers(self):
+        return len(self.dims) - 1
+
+    @property
+    def n_params(self):
+        return sum(i * o + o for i, o in zip(self.in_dims, self.dims[1:]))
+
+    def device_bytes(self) -> int:
+        return int(self.lib.lgnn_device_bytes(self._h))
+
+    def set_workspace_limit(self, nbytes: int):
+        _lib.check(self.lib.lgnn_set_workspace_limit(self._h, int(nbytes)), "lgnn_set_workspace_limit")
+
+    # -- forward --------------------------------------------------------------------------------
+    def forward(self, idx: torch.Tensor) -> torch.Tensor:
+        self._sync_versions()
+        idx = idx.contiguous()
+        out = torch.empty(idx.shape[0], self.dims[-1], dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.lgnn_forward(self._h, _dev_ptr(idx, torch.int64, "idx"), idx.shape[0], out.data_ptr(),
+                                         _stream(self.device)), "lgnn_forward")
+        return out
+
+    def forward_all(self) -> torch.Tensor:
+        self._sync_versions()
+        out = torch.empty(self.num_nodes, self.dims[-1], dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.lgnn_forward_all(self._h, out.data_ptr(), _stream(self.device)), "lgnn_forward_all")
+        return out
+
+    # -- curvature ------------------------------------------------------------------------------
+    def new_kfac_buffers(self):
+        """Zeroed caller-owned accumulators, as ONE flat fp32 buffer [A_0|B_0|...|A_{L-1}|B_{L-1}|loss]
+        (one all-reduce suffices) plus per-factor views."""
+        sizes = []
+        for i, o in zip(self.in_dims, self.dims[1:]):
+            sizes += [i * i, o * o]
+        flat = torch.zeros(sum(sizes) + 1, dtype=torch.float32, device=self.device)
+        views, off = [], 0
+        for l, (i, o) in enumerate(zip(self.in_dims, self.dims[1:])):
+            A = flat[off:off + i * i].view(i, i); off += i * i
+            B = flat[off:off + o * o].view(o, o); off += o * o
+            views.append((A, B))
+        loss = flat[off:off + 1]
+        return flat, views, loss
+
+    def kfac_accumulate(self, idx, y, n_train: int, views, loss, fork_exact: bool = True, fuse: bool = True):
+        self._sync_versions()
+        idx, y = idx.contiguous(), y.contiguous()
+        flags = (_lib.FLAG_FORK_EXACT_SEED if fork_exact else 0) | (0 if fuse else _lib.FLAG_NO_FUSE)
+        A = _lib.ptr_array([a.data_ptr() for a, _ in views])
+        B = _lib.ptr_array([b.data_ptr() for _, b in views])
+        rc = self.lib.lgnn_kfac_accumulate(
+            self._h, _dev_ptr(idx, torch.int64, "idx"), _dev_ptr(y, torch.int64, "y"), idx.shape[0], int(n_train),
+            flags, A, B, loss.data_ptr(), _stream(self.device))
+        _lib.check(rc, "lgnn_kfac_accumulate")
+
+    def diag_accumulate(self, idx, y, diag: torch.Tensor, loss: torch.Tensor):
+        self._sync_versions()
+        idx, y = idx.contiguous(), y.contiguous()
+        rc = self.lib.lgnn_diag_accumulate(
+            self._h, _dev_ptr(idx, torch.int64, "idx"), _dev_ptr(y, torch.int64, "y"), idx.shape[0], 0,
+            _dev_ptr(diag, torch.float32, "diag"), loss.data_ptr(), _stream(self.device))
+        _lib.check(rc, "lgnn_diag_accumulate")
+
+    def lastlayer_full_accumulate(self, idx, y, H: torch.Tensor, loss: torch.Tensor):
+        self._sync_versions()
+        idx, y = idx.contiguous(), y.contiguous()
+        rc = self.lib.lgnn_lastlayer_full_accumulate(
+            self._h, _dev_ptr(idx, torch.int64, "idx"), _dev_ptr(y, torch.int64, "y"), idx.shape[0],
+            _dev_ptr(H, torch.float32, "H"), loss.data_ptr(), _stream(self.device))
+        _lib.check(rc, "lgnn_lastlayer_full_accumulate")
+
+    # -- timing hook ----------------------------------------------------------------------------
+    def enable_kernel_timing(self, on: bool = True):
+        _lib.check(self.lib.lgnn_enable_kernel_timing(self._h, int(on)), "lgnn_enable_kernel_timing")
+
+    def kernel_timing(self):
+        n, ms, planes = C.c_int64(0), C.c_double(0.0), C.c_int64(0)
+        _lib.check(self.lib.lgnn_kernel_timing_read(self._h, C.byref(n), C.byref(ms), C.byref(planes)),
+                   "lgnn_kernel_timing_read")
+        return n.value, ms.value, planes.value
