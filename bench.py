@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""la.fit() throughput of the KFAC curvature path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[2], SURVEY.md 8(d) "C3"): 2-layer GCN on a synthetic
+ogbn-arxiv-shaped graph -- N = 169 343 nodes, 1 166 243 undirected random edges (symmetrised,
+self loops added), F = 128, H = 256, C = 40, N_train = 90 941 in 10 mini-batches of 10 000
+(reference loader: batch_size=10000, shuffle=False), hessian_structure="kron".
+A *step* is one complete ``la.fit(loader)``: forward + A-factor Grams (recomputed every step: the
+engine's cache is invalidated first), the 10 per-batch KFAC accumulations, the factor all-reduce
+(N > 1) and the eigendecomposition ``fit`` ends with.  value = steps * N_train / wall.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, the graph / features / weights replicated, whole batches dealt
+round-robin (batch t -> rank t mod N, never split: B factors have cross-sample terms inside a
+batch), one RCCL all-reduce of the flat factor buffer.  Total work is fixed => "strong" scaling;
+with 10 batches the speed-up is bounded by ceil(10/N) (5x at N = 8).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: N, undirected edges, F, H, C, N_train, batch
+    "arxiv": dict(N=169_343, E=1_166_243, F=128, H=256, C=40, n_train=90_941, batch=10_000),
+    "cora": dict(N=2_708, E=5_278, F=1_433, H=64, C=7, n_train=1_299, batch=10_000),
+}
+PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def make_workload(name: str, device, seed: int = 0):
+    """Seeded synthetic inputs of the named shape; generated on the CPU generator so
+    every rank (and the CPU baseline) sees identical data."""
+    w = WORKLOADS[name]
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, w["N"], (2, w["E"]), generator=g, dtype=torch.int64)
+    X = torch.randn(w["N"], w["F"], generator=g)
+    y_all = torch.randint(0, w["C"], (w["N"],), generator=g, dtype=torch.int64)
+    train_idx = torch.randperm(w["N"], generator=g)[: w["n_train"]]
+    train_y = y_all[train_idx]
+    return w, ei, X, train_idx, train_y
+
+
+def cpu_baseline(name: str, ei, X, Ws, bs, train_idx, train_y, w):
+    """Oracle (CPU restatement, numpy + scipy) timed on the host cores on a bounded sample:
+    the first mini-batch of the same workload, forward and A factors included (the reference
+    recomputes them per batch)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gnn_laplace_oracle as O
+
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    rp, col = O.edge_index_to_adj_csr(ei.numpy(), w["N"], "gcn", True)
+    om = O.GnnModel("gcn", rp, col, X.numpy(), Ws, bs)
+    M = min(w["batch"], w["n_train"])
+    t0 = time.perf_counter()
+    O.kfac_batch(om, train_idx[:M].numpy(), train_y[:M].numpy(), w["n_train"])
+    dt = time.perf_counter() - t0
+    return {
+        "value": M / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
+        "sample": f"first mini-batch ({M} of {w['n_train']} samples) of the same {name}-shaped kron fit, "
+                  f"oracle/gnn_laplace_oracle.kfac_batch, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="arxiv", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import laplace_gnn_amd as lg
+
+    w, ei, X, train_idx, train_y = make_workload(args.workload, dev)
+    torch.manual_seed(0)
+    model = lg.GCN(w["F"], w["H"], w["C"], 2, X, ei, symmetric=True).to(dev)
+    loader = lg.TensorBatchLoader(train_idx.to(dev), train_y.to(dev), batch_size=w["batch"])
+    la = lg.Laplace(model, "classification", subset_of_weights="all", hessian_structure="kron")
+    eng = model.engine
+    nnz, N, H, C = eng.nnz, w["N"], w["H"], w["C"]
+
+    def step():
+        eng.invalidate()  # a fresh fit: forward + input Grams are recomputed, nothing carried over
+        la.fit(loader)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    eng.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    launches, kern_ms, planes = eng.kernel_timing()
+    eng.enable_kernel_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = args.steps * w["n_train"] / elapsed
+        # dominant kernel: fused SpMM^T -> Gram of layer 0.  ALGORITHMIC flops per class plane:
+        # SpMM 2*nnz*H + Gram 2*N*H^2 (no credit for symmetry); bytes per plane (fused, nothing written):
+        # nnz*8 + (N+1)*4 + N*H*4.  The MFMA floor is the higher one => "mfma" bound.
+        flops_plane = 2.0 * nnz * H + 2.0 * N * H * H
+        bytes_plane = nnz * 8.0 + (N + 1) * 4.0 + N * H * 4.0
+        roofline = None
+        if launches > 0 and kern_ms > 0:
+            avg_ms = kern_ms / launches
+            ach = flops_plane * planes / (kern_ms * 1e-3) / 1e12
+            roofline = {
+                "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                "kernel": "spmm_gram_kernel<256>", "launches": launches, "avg_launch_ms": avg_ms,
+                "planes_per_launch": planes / launches,
+                "algorithmic_GBps": bytes_plane * planes / (kern_ms * 1e-3) / 1e9,
+                "kernel_share_of_wall": kern_ms * 1e-3 / elapsed,
+            }
+        out = {
+            "metric": "la.fit() samples/sec (GCN, KFAC)", "value": value, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}-shaped 2-layer GCN, hessian_structure=kron (BASELINE configs[2])",
+                "num_nodes": N, "nnz": nnz, "features": w["F"], "hidden": H, "classes": C,
+                "n_train": w["n_train"], "batch_size": w["batch"],
+                "batches": len(loader), "parallelism": f"dp{world} (whole batches round-robin)",
+            },
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            Ws = [c.lin.weight.detach().cpu().numpy() for c in model.convs]
+            bs = [c.lin.bias.detach().cpu().numpy() for c in model.convs]
+            out["cpu_baseline"] = cpu_baseline(args.workload, ei, X, Ws, bs, train_idx, train_y, w)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""``laplace.curvature``-compatible backend that runs on the HIP engine.
+
+Drop-in for ``laplace.curvature.CurvlinopsGGN`` on GCN / GraphSAGE models: pass the class as
+``backend=`` to ``Laplace(...)``.  Same constructor signature, attributes and return
+conventions as laplace/curvature/curvature.py:12-83 (CurvatureInterface) and
+laplace/curvature/curvlinops.py:20-167 (CurvlinopsInterface / CurvlinopsGGN):
+
+* ``kron(x, y, N) -> (loss, Kron)`` with ``Kron.kfacs = [[B0, A0], [B0], [B1, A1], [B1], ...]``,
+  A already rescaled by M/N, everything multiplied by ``factor`` the way ``Kron.__mul__`` does
+  (curvlinops.py:55-75, 46-53, 104-108); fresh tensors on every call (callers mutate them);
+* ``diag(x, y, **kw) -> (loss, H[P])``  (curvature.py:412-432);
+* ``full(x, y, **kw) -> (loss, H[P, P])`` -- implemented for ``last_layer=True`` (curvature.py:374-410
+  with last_layer_jacobians :132-167);
+* attributes ``lossfunc``, ``factor``, ``params``, ``params_dict``, ``buffers_dict``, ``model``,
+  ``_model``, ``likelihood``, ``last_layer``, ``stochastic``.
+
+In-place fast paths (``kron_accumulate_`` ...) let the fit loop add straight into one flat buffer.
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+from torch import nn
+from torch.nn import CrossEntropyLoss, MSELoss
+
+from .matrix import Kron
+
+
+class HipCurvatureInterface:
+    def __init__(self, model: nn.Module, likelihood: str, last_layer: bool = False,
+                 subnetwork_indices: torch.LongTensor | None = None, dict_key_x: str = "input_ids",
+                 dict_key_y: str = "labels", stochastic: bool = False, fork_exact_seed: bool = True):
+        assert likelihood in ["regression", "classification"]
+        if subnetwork_indices is not None:
+            raise NotImplementedError("subnetwork Laplace is out of scope for the HIP backend")
+        if stochastic:
+            raise NotImplementedError("MC Fisher (stochastic=True) is not implemented on the HIP backend")
+        if likelihood != "classification":
+            raise NotImplementedError("the HIP backend implements the classification likelihood")
+        self.likelihood = likelihood
+        self.model = model
+        self.last_layer = last_layer
+        self.subnetwork_indices = None
+        self.dict_key_x, self.dict_key_y = dict_key_x, dict_key_y
+        self.stochastic = False
+        self.fork_exact_seed = fork_exact_seed
+        if likelihood == "regression":
+            self.lossfunc, self.factor = MSELoss(reduction="sum"), 0.5
+        else:
+            self.lossfunc, self.factor = CrossEntropyLoss(reduction="sum"), 1.0
+        # the fork's parameter filter (laplace/curvature/curvature.py:74-79)
+        self.params, self.params_dict = [], {}
+        for k, v in self.model.named_parameters():
+            if v.requires_grad and "adj" not in k and "norms" not in k:
+                self.params.append(v)
+                self.params_dict[k] = v
+        self.buffers_dict = {k: v for k, v in self.model.named_buffers()}
+        if not hasattr(model, "engine"):
+            raise TypeError("HipGGN needs a model that exposes a HIP `engine` (laplace_gnn_amd.models.GCN / "
+                            "GraphSAGE); there is no generic autograd fallback")
+
+    @property
+    def _model(self) -> nn.Module:
+        return self.model.last_layer if self.last_layer else self.model
+
+    @property
+    def engine(self):
+        return self.model.engine
+
+    # ---- kron ----------------------------------------------------------------------------------
+    def kron_accumulate_(self, views, loss_buf, x: torch.Tensor, y: torch.Tensor, N: int, fuse: bool = True):
+        """Add this batch's RAW factors (A_l/N_train, B_l) and loss into caller-owned buffers."""
+        self.engine.kfac_accumulate(x, y, N, views, loss_buf, fork_exact=self.fork_exact_seed, fuse=fuse)
+
+    def pack_kron(self, views) -> Kron:
+        """[[B0, A0], [B0], ...] in parameter order, times ``factor`` distributed like Kron.__mul__
+        (laplace/utils/matrix.py:95-113): sqrt(factor) per factor of a 2-block, factor on a 1-block."""
+        kfacs = []
+        f2 = self.factor ** 0.5
+        for A, B in views:
+            kfacs.append([B * f2 if self.factor != 1.0 else B.clone(), A * f2 if self.factor != 1.0 else A.clone()])
+            kfacs.append([B * self.factor if self.factor != 1.0 else B.clone()])
+        return Kron(kfacs)
+
+    def kron(self, x: torch.Tensor, y: torch.Tensor, N: int, **kwargs: Any):
+        if kwargs:
+            raise NotImplementedError(f"unsupported kron kwargs {sorted(kwargs)} (mc_samples / kfac_approx)")
+        _, views, loss = self.engine.new_kfac_buffers()
+        self.kron_accumulate_(views, loss, x, y, N)
+        return self.factor * loss[0].clone(), self.pack_kron(views)
+
+    # ---- diag ----------------------------------------------------------------------------------
+    def diag(self, x: torch.Tensor, y: torch.Tensor, **kwargs: Any):
+        eng = self.engine
+        H = torch.zeros(eng.n_params, dtype=torch.float32, device=eng.device)
+        loss = torch.zeros(1, dtype=torch.float32, device=eng.device)
+        eng.diag_accumulate(x, y, H, loss)
+        return self.factor * loss[0], H
+
+    # ---- full (last layer) ---------------------------------------------------------------------
+    def full(self, x: torch.Tensor, y: torch.Tensor, **kwargs: Any):
+        if not self.last_layer:
+            raise NotImplementedError("full GGN over all weights needs backpack in the reference and is out of "
+                                      "scope; use last_layer=True (SURVEY.md 8(a-6))")
+        eng = self.engine
+        p_ll = eng.in_dims[-1] * eng.dims[-1] + eng.dims[-1]
+        H = torch.zeros(p_ll, p_ll, dtype=torch.float32, device=eng.device)
+        loss = torch.zeros(1, dtype=torch.float32, device=eng.device)
+        eng.lastlayer_full_accumulate(x, y, H, loss)
+        return self.factor * loss[0], H
+
+    def jacobians(self, x, enable_backprop: bool = True):
+        raise NotImplementedError("explicit Jacobians (GLM predictive) are a 'next' row (SURVEY.md 8(f)-3)")
+
+    last_layer_jacobians = jacobians
+    functorch_jacobians = jacobians
+
+    def gradients(self, x, y):
+        raise NotImplementedError("per-sample gradients (empirical Fisher) are out of scope")
+
+
+class HipGGN(HipCurvatureInterface):
+    """GGN backend on MI355X; the counterpart of ``CurvlinopsGGN`` (curvlinops.py:143-167)."""

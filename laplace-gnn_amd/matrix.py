@@ -1,0 +1,149 @@
+"""``Kron`` / ``KronDecomposed``: the output container of the kron path.
+
+Own implementation with the same observable behaviour as laplace/utils/matrix.py for what the
+fit path touches: ``init_from_model`` (:33-72), ``__add__`` (:74-93), ``__mul__`` (:95-113,
+``pow(scalar, 1/len(F))`` per factor), ``decompose`` (:118-145, ``symeig`` clamp semantics of
+laplace/utils/utils.py:193-226), ``diag`` (:236-251), ``to_matrix`` (:253-271), ``logdet``.
+"""
+from __future__ import annotations
+
+from math import pow
+from typing import Iterable
+
+import torch
+from torch import nn
+
+
+def symeig(M: torch.Tensor):
+    """eigh with the reference's safety net: on failure add/remove identity jitter; eigenvalues
+    clamped at 0, NaNs zeroed (laplace/utils/utils.py:193-226)."""
+    try:
+        L, W = torch.linalg.eigh(M, UPLO="U")
+    except RuntimeError:
+        M = M + torch.eye(M.shape[0], device=M.device, dtype=M.dtype)
+        L, W = torch.linalg.eigh(M, UPLO="U")
+        L = L - 1.0
+    L = torch.nan_to_num(L.clamp(min=0.0))
+    W = torch.nan_to_num(W)
+    return L, W
+
+
+class Kron:
+    def __init__(self, kfacs: list):
+        self.kfacs = kfacs
+
+    @classmethod
+    def init_from_model(cls, model: nn.Module | Iterable[nn.Parameter], device) -> "Kron":
+        params = model.parameters() if isinstance(model, nn.Module) else model
+        kfacs = []
+        for p in params:
+            if p.ndim == 1:
+                kfacs.append([torch.zeros(p.size(0), p.size(0), device=device)])
+            elif p.ndim == 2:
+                o, i = p.size()
+                kfacs.append([torch.zeros(o, o, device=device), torch.zeros(i, i, device=device)])
+            else:
+                raise ValueError("Invalid parameter shape in network.")
+        return cls(kfacs)
+
+    def __add__(self, other: "Kron") -> "Kron":
+        if not isinstance(other, Kron):
+            raise ValueError("Can only add Kron to Kron.")
+        return Kron([[Hi.add(Hj) for Hi, Hj in zip(Fi, Fj)] for Fi, Fj in zip(self.kfacs, other.kfacs)])
+
+    def __mul__(self, scalar) -> "Kron":
+        if not isinstance(scalar, (int, float)) and not (torch.is_tensor(scalar) and scalar.numel() == 1):
+            raise ValueError("Input not valid python or torch scalar.")
+        scalar = float(scalar)
+        return Kron([[pow(scalar, 1 / len(F)) * Hi for Hi in F] for F in self.kfacs])
+
+    __radd__ = __add__
+    __rmul__ = __mul__
+
+    def __len__(self):
+        return len(self.kfacs)
+
+    def decompose(self, damping: bool = False) -> "KronDecomposed":
+        eigvecs, eigvals = [], []
+        for F in self.kfacs:
+            Qs, ls = [], []
+            for Hi in F:
+                lam, Q = symeig(Hi)
+                Qs.append(Q)
+                ls.append(lam)
+            eigvecs.append(Qs)
+            eigvals.append(ls)
+        return KronDecomposed(eigvecs, eigvals, damping=damping)
+
+    def diag(self) -> torch.Tensor:
+        out = []
+        for F in self.kfacs:
+            F0 = F[0].diag()
+            out.append(F0 if len(F) == 1 else torch.outer(F0, F[1].diag()).flatten())
+        return torch.cat(out)
+
+    def to_matrix(self) -> torch.Tensor:
+        blocks = [F[0] if len(F) == 1 else torch.kron(F[0], F[1]) for F in self.kfacs]
+        return torch.block_diag(*blocks)
+
+    def logdet(self) -> torch.Tensor:
+        ld = 0
+        for F in self.kfacs:
+            if len(F) == 1:
+                ld = ld + F[0].logdet()
+            else:
+                ld = ld + len(F[1]) * F[0].logdet() + len(F[0]) * F[1].logdet()
+        return ld
+
+
+class KronDecomposed:
+    """Eigendecomposed factors plus prior precision ``deltas`` (laplace/utils/matrix.py:277-394)."""
+
+    def __init__(self, eigenvectors, eigenvalues, deltas: torch.Tensor | None = None, damping: bool = False):
+        self.eigenvectors, self.eigenvalues = eigenvectors, eigenvalues
+        dev = eigenvectors[0][0].device
+        self.deltas = torch.zeros(len(self), device=dev) if deltas is None else deltas
+        self.damping = damping
+
+    def __len__(self):
+        return len(self.eigenvalues)
+
+    def __add__(self, deltas: torch.Tensor) -> "KronDecomposed":
+        deltas = torch.as_tensor(deltas, device=self.deltas.device, dtype=self.deltas.dtype).reshape(-1)
+        if deltas.numel() == 1:
+            deltas = deltas.expand(len(self))
+        if deltas.numel() != len(self):
+            raise ValueError("Invalid shape of delta added.")
+        return KronDecomposed(self.eigenvectors, self.eigenvalues, self.deltas + deltas, self.damping)
+
+    def __mul__(self, scalar) -> "KronDecomposed":
+        scalar = float(scalar)
+        ev = [[pow(scalar, 1 / len(ls)) * l for l in ls] for ls in self.eigenvalues]
+        return KronDecomposed(self.eigenvectors, ev, self.deltas, self.damping)
+
+    def logdet(self) -> torch.Tensor:
+        """sum_blocks sum log(l1 (x) l2 + delta)  (matrix.py:371-394)."""
+        ld = 0
+        for ls, delta in zip(self.eigenvalues, self.deltas):
+            if len(ls) == 1:
+                ld = ld + torch.log(ls[0] + delta).sum()
+            else:
+                l1, l2 = ls
+                if self.damping:
+                    ds = torch.sqrt(delta)
+                    ld = ld + torch.log(torch.outer(l1 + ds, l2 + ds)).sum()
+                else:
+                    ld = ld + torch.log(torch.outer(l1, l2) + delta).sum()
+        return ld
+
+    def to_matrix(self, exponent: float = 1) -> torch.Tensor:
+        blocks = []
+        for Qs, ls, delta in zip(self.eigenvectors, self.eigenvalues, self.deltas):
+            if len(ls) == 1:
+                Q, l = Qs[0], ls[0]
+                blocks.append(Q @ torch.diag(torch.pow(l + delta, exponent)) @ Q.T)
+            else:
+                Q = torch.kron(Qs[0], Qs[1])
+                l = torch.pow(torch.outer(ls[0], ls[1]) + delta, exponent).flatten()
+                blocks.append(Q @ torch.diag(l) @ Q.T)
+        return torch.block_diag(*blocks)
