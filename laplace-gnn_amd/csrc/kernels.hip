@@ -7,18 +7,11 @@
 // wave = 64 lanes; MFMA 32x32x2 f32: lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
 // C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)   (cdna_hip_programming.md section 3).
 #include "lgnn_internal.h"
+#include "device_utils.h"
 
 namespace lgnn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-__device__ __forceinline__ float act_apply(float x, int act) {
-  return act == LGNN_ACT_RELU ? fmaxf(x, 0.f) : tanhf(x);
-}
-// derivative of the activation expressed through its OUTPUT h (relu: h > 0 <=> pre > 0)
-__device__ __forceinline__ float act_deriv_from_out(float h, int act) {
-  return act == LGNN_ACT_RELU ? (h > 0.f ? 1.f : 0.f) : (1.f - h * h);
-}
 
 // =====================================================================================
 // SpMM: out[plane][r][0:width) = epi( self[r] + sum_j val[j] * in[plane][col[j]][0:width) )

@@ -1,0 +1,153 @@
+"""Drop-in front-end on the GPU: Laplace(...).fit(loader) with the HipGGN backend reproduces the
+reference's fitted attributes (golden vectors from the reference's KronLaplace / DiagLaplace)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from gpu_utils import rel
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "c1_" not in p)
+IDS = [os.path.basename(p)[:-4] for p in CASES]
+
+
+def model_from_golden(g, device="cuda"):
+    import laplace_gnn_amd as lg
+
+    kind = str(g["kind"])
+    L = int(g["num_layers"])
+    X = torch.from_numpy(g["X"])
+    ei = torch.from_numpy(g["edge_index"])
+    F, C = X.shape[1], g[f"W{L - 1}"].shape[0]
+    Hd = g["W0"].shape[0]
+    cls = lg.GCN if kind == "gcn" else lg.GraphSAGE
+    model = cls(F, Hd, C, L, X, ei, symmetric=bool(g["symmetric"]))
+    with torch.no_grad():
+        for l, conv in enumerate(model.convs):
+            conv.lin.weight.copy_(torch.from_numpy(g[f"W{l}"]))
+            conv.lin.bias.copy_(torch.from_numpy(g[f"b{l}"]))
+    model.eval()
+    return model.to(device) if device else model
+
+
+@pytest.mark.parametrize("path", CASES, ids=IDS)
+def test_kron_laplace_fit(path):
+    import laplace_gnn_amd as lg
+
+    g = np.load(path)
+    model = model_from_golden(g)
+    assert [k for k, _ in model.named_parameters()] == [
+        f"convs.{l}.lin.{w}" for l in range(int(g["num_layers"])) for w in ("weight", "bias")]
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(),
+                                  batch_size=int(g["batch_size"]))
+    la = lg.Laplace(model, "classification", subset_of_weights="all", hessian_structure="kron")
+    assert isinstance(la, lg.KronLaplace) and la._backend_cls is lg.HipGGN
+    la.fit(loader)
+    assert len(la.H_facs.kfacs) == int(g["kron_n_blocks"])
+    for i, Fs in enumerate(la.H_facs.kfacs):
+        for j, Hm in enumerate(Fs):
+            assert rel(Hm.cpu().numpy(), g[f"kron_{i}_{j}"]) < RTOL, (i, j)
+    assert abs(float(la.loss) - float(g["kron_loss"])) <= RTOL * abs(float(g["kron_loss"]))
+    assert la.n_data == int(g["n_data"]) and la.n_outputs == int(g["n_outputs"]) and la.n_params == int(g["n_params"])
+    assert model.output_size == la.n_outputs
+    # the eigendecomposition fit() ends with (eigenvalues are basis independent)
+    for i, ls in enumerate(la.H.eigenvalues):
+        for j, lam in enumerate(ls):
+            ref = g[f"kron_eig_{i}_{j}"]
+            assert np.abs(lam.cpu().numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30), (i, j)
+    # torch.utils.data.DataLoader (the reference's loader) gives the same batches
+    from torch.utils.data import DataLoader, TensorDataset
+    dl = DataLoader(TensorDataset(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"])),
+                    batch_size=int(g["batch_size"]), shuffle=False)
+    la2 = lg.KronLaplace(model, "classification", backend=lg.HipGGN)
+    la2.fit(dl)
+    for Fa, Fb in zip(la.H_facs.kfacs, la2.H_facs.kfacs):
+        for a, b in zip(Fa, Fb):
+            assert rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("path", CASES, ids=IDS)
+def test_diag_laplace_fit(path):
+    import laplace_gnn_amd as lg
+
+    g = np.load(path)
+    model = model_from_golden(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(),
+                                  batch_size=int(g["batch_size"]))
+    la = lg.Laplace(model, "classification", subset_of_weights="all", hessian_structure="diag")
+    la.fit(loader)
+    assert rel(la.H.cpu().numpy(), g["diag_H"]) < RTOL
+    assert abs(float(la.loss) - float(g["diag_loss"])) <= RTOL * abs(float(g["diag_loss"]))
+    assert la.mean.shape[0] == int(g["n_params"])
+
+
+def test_backend_kron_returns_fresh_tensors_and_reference_layout():
+    """CurvatureInterface contract (laplace/curvature/curvlinops.py:55-108): fresh tensors per call,
+    [[B,A],[B]] per Linear, A rescaled by M/N, callers may mutate the result."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, "gcn_small_1batch_s0.npz"))
+    model = model_from_golden(g)
+    be = lg.HipGGN(model, "classification")
+    assert be.factor == 1.0 and isinstance(be.lossfunc, torch.nn.CrossEntropyLoss)
+    assert list(be.params_dict) == ["convs.0.lin.weight", "convs.0.lin.bias", "convs.1.lin.weight",
+                                    "convs.1.lin.bias"]
+    x = torch.from_numpy(g["train_idx"]).cuda()
+    y = torch.from_numpy(g["train_y"]).cuda()
+    loss1, k1 = be.kron(x, y, N=len(x))
+    k1.kfacs[0][0].mul_(0.0)  # callers mutate what they get
+    loss2, k2 = be.kron(x, y, N=len(x))
+    assert rel(k2.kfacs[0][0].cpu().numpy(), g["kron_0_0"]) < RTOL
+    assert abs(float(loss1) - float(loss2)) < 1e-6 * abs(float(loss2))
+    assert [len(F) for F in k2.kfacs] == [2, 1, 2, 1]
+    assert k2.kfacs[0][0].shape == (8, 8) and k2.kfacs[0][1].shape == (12, 12)
+    # A scales with M/N, B does not (tests/test_curv_backends_curvlinops.py:308-333 pattern)
+    _, k3 = be.kron(x, y, N=7 * len(x))
+    assert rel(7 * k3.kfacs[0][1].cpu().numpy(), k2.kfacs[0][1].cpu().numpy()) < 1e-5
+    assert rel(k3.kfacs[0][0].cpu().numpy(), k2.kfacs[0][0].cpu().numpy()) < 1e-5
+    with pytest.raises(NotImplementedError):
+        be.full(x, y)
+
+
+def test_fit_override_false_accumulates_like_reference():
+    """fit twice with override=False: Kron discounting of laplace/baselaplace.py:1589-1607 (B: old + new;
+    A: old * n_old/(n_old+n_new) + new * n_new/(n_old+n_new)); loss and n_data add up."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, "gcn_small_3batch_s0.npz"))
+    model = model_from_golden(g)
+    idx, y = torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda()
+    loader = lg.TensorBatchLoader(idx, y, batch_size=int(g["batch_size"]))
+    la = lg.KronLaplace(model, "classification")
+    la.fit(loader)
+    la.fit(loader, override=False)
+    assert la.n_data == 2 * len(idx)
+    assert abs(float(la.loss) - 2 * float(g["kron_loss"])) < 1e-4 * 2 * float(g["kron_loss"])
+    for i, Fs in enumerate(la.H_facs.kfacs):
+        ref = [g[f"kron_{i}_{j}"] for j in range(len(Fs))]
+        assert rel(Fs[0].cpu().numpy(), 2 * ref[0]) < RTOL
+        if len(Fs) == 2:
+            assert rel(Fs[1].cpu().numpy(), ref[1]) < RTOL
+
+
+def test_weight_update_invalidates_cache():
+    g = np.load(os.path.join(GOLDEN, "gcn_small_1batch_s0.npz"))
+    model = model_from_golden(g)
+    idx = torch.from_numpy(g["train_idx"]).cuda()
+    out1 = model(idx).clone()
+    with torch.no_grad():
+        model.convs[1].lin.weight.mul_(2.0)  # in-place update bumps the version counter
+    out2 = model(idx)
+    assert not torch.equal(out1, out2)
+
+
+def test_missing_gpu_model_fails_loudly():
+    g = np.load(os.path.join(GOLDEN, "gcn_small_1batch_s0.npz"))
+    model = model_from_golden(g, device=None)  # stays on the CPU
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.arange(3))

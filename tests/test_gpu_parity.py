@@ -60,3 +60,51 @@ def test_kfac_fit_matches_reference(path, fuse):
         assert torch.equal(B, B.T) and torch.equal(A, A.T)  # exactly symmetric by construction
     assert abs(loss - float(g["kron_loss"])) <= RTOL * abs(float(g["kron_loss"]))
     eng.close()
+
+
+def _diag_fit(eng, idx, y, batch_size):
+    H = torch.zeros(eng.n_params, device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    for s in range(0, len(idx), batch_size):
+        eng.diag_accumulate(idx[s:s + batch_size], y[s:s + batch_size], H, loss)
+    torch.cuda.synchronize()
+    return H.cpu().numpy(), float(loss.item())
+
+
+@pytest.mark.parametrize("path", CASES, ids=IDS)
+def test_diag_fit_matches_reference(path):
+    g = np.load(path)
+    eng = engine_from_golden(g)
+    idx = torch.from_numpy(g["train_idx"]).cuda()
+    y = torch.from_numpy(g["train_y"]).cuda()
+    H, loss = _diag_fit(eng, idx, y, int(g["batch_size"]))
+    assert H.shape[0] == int(g["n_params"])
+    assert rel(H, g["diag_H"]) < RTOL
+    # per parameter block as well (a small block must not hide behind a large one)
+    L = int(g["num_layers"])
+    off = 0
+    for l in range(L):
+        for n in (g[f"W{l}"].size, g[f"b{l}"].size):
+            assert rel(H[off:off + n], g["diag_H"][off:off + n]) < RTOL, (l, n)
+            off += n
+    assert abs(loss - float(g["diag_loss"])) <= RTOL * abs(float(g["diag_loss"]))
+    eng.close()
+
+
+@pytest.mark.parametrize("path", [p for p in CASES if "full_H" in np.load(p)],
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_lastlayer_full_matches_reference_block(path):
+    """The last layer's block of the reference's full GGN (GGNInterface.full golden)."""
+    g = np.load(path)
+    eng = engine_from_golden(g)
+    idx = torch.from_numpy(g["train_idx"]).cuda()
+    y = torch.from_numpy(g["train_y"]).cuda()
+    L = int(g["num_layers"])
+    p_ll = g[f"W{L - 1}"].size + g[f"b{L - 1}"].size
+    H = torch.zeros(p_ll, p_ll, device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    eng.lastlayer_full_accumulate(idx, y, H, loss)
+    torch.cuda.synchronize()
+    assert rel(H.cpu().numpy(), g["full_H"][-p_ll:, -p_ll:]) < RTOL
+    assert abs(float(loss.item()) - float(g["full_loss"])) <= RTOL * abs(float(g["full_loss"]))
+    eng.close()
