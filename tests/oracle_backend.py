@@ -1,0 +1,56 @@
+"""TEST-ONLY backend: the CPU oracle behind the ``CurvatureInterface`` signatures, so that the host
+logic of ``laplace_gnn_amd.laplace`` (fit loop, Kron accumulation, override semantics, batch
+sharding + all-reduce) can be exercised without a GPU.  Never shipped, never the product path."""
+import numpy as np
+import torch
+from torch.nn import CrossEntropyLoss
+
+import gnn_laplace_oracle as O
+from laplace_gnn_amd.matrix import Kron
+
+
+class CpuForwardGCN(torch.nn.Module):
+    """Wraps a laplace_gnn_amd model so that forward() also runs through the oracle on the CPU."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.inner = model
+        self.convs = model.convs
+
+    def oracle_model(self):
+        m = self.inner
+        rp, col = O.edge_index_to_adj_csr(m.edge_index.numpy(), m.num_nodes, m.kind, m.symmetric)
+        Ws = [c.lin.weight.detach().numpy() for c in m.convs]
+        bs = [c.lin.bias.detach().numpy() for c in m.convs]
+        return O.GnnModel(m.kind, rp, col, m.X.numpy(), Ws, bs)
+
+    def forward(self, x_indices):
+        out, _, _ = O.forward_all(self.oracle_model())
+        return torch.from_numpy(out[x_indices.numpy()])
+
+
+class OracleBackend:
+    def __init__(self, model, likelihood, last_layer=False, subnetwork_indices=None, dict_key_x="input_ids",
+                 dict_key_y="labels", stochastic=False):
+        assert likelihood == "classification"
+        self.model, self.likelihood, self.last_layer = model, likelihood, last_layer
+        self.lossfunc, self.factor = CrossEntropyLoss(reduction="sum"), 1.0
+        self.params = [p for k, p in model.named_parameters() if p.requires_grad and "adj" not in k]
+        self.params_dict = dict(model.named_parameters())
+        self.buffers_dict = dict(model.named_buffers())
+        self.calls = []
+
+    def kron(self, x, y, N, **kw):
+        self.calls.append(("kron", tuple(x.tolist())))
+        loss, kfacs = O.kfac_batch(self.model.oracle_model(), x.numpy(), y.numpy(), N)
+        return torch.tensor(float(loss)), Kron([[torch.from_numpy(np.ascontiguousarray(h)) for h in F] for F in kfacs])
+
+    def diag(self, x, y, **kw):
+        self.calls.append(("diag", tuple(x.tolist())))
+        loss, H = O.diag_batch(self.model.oracle_model(), x.numpy(), y.numpy())
+        return torch.tensor(float(loss)), torch.from_numpy(H)
+
+    def full(self, x, y, **kw):
+        self.calls.append(("full", tuple(x.tolist())))
+        loss, H = O.lastlayer_full_batch(self.model.oracle_model(), x.numpy(), y.numpy())
+        return torch.tensor(float(loss)), torch.from_numpy(H)

@@ -1,0 +1,245 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol the header declares, the
+ctypes table matches the header, and the host logic (Kron container, loaders, Laplace front with an
+injected oracle backend) behaves like the reference's caller."""
+import glob
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from oracle_backend import CpuForwardGCN, OracleBackend
+
+import laplace_gnn_amd as lg
+
+RTOL = 1e-4
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+# ---- C ABI --------------------------------------------------------------------------------------
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "laplace_gnn_hip.h")).read()
+    return sorted(set(re.findall(r"LGNN_API[^;(]*?\b(lgnn_[a-z_]+)\s*\(", text)))
+
+
+def test_library_builds_loads_and_exports_every_header_symbol():
+    if not os.path.exists(lg._lib.LIB_PATH):
+        subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, check=True)
+    lib = lg._lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/laplace_gnn_hip.h but not exported"
+    assert sorted(lg._lib.SIGNATURES) == syms, "ctypes table and header disagree"
+    assert lib.lgnn_abi_version() == 1
+    assert isinstance(lib.lgnn_last_error(), bytes)
+    out = subprocess.run(["nm", "-D", "--defined-only", lg._lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(re.findall(r" T (lgnn_[a-z_]+)", out))
+    assert exported == syms, "the .so exports exactly the header's entry points (hidden visibility otherwise)"
+
+
+def test_header_cites_reference_for_every_compute_entry_point():
+    text = open(os.path.join(ROOT, "include", "laplace_gnn_hip.h")).read()
+    for needle in ("curvlinops.py:77-108", "curvature.py:412-432", "curvature.py:132-167", "base_gnn.py:136-161",
+                   "gnn/utils.py:325-330", "gnn/utils.py:333-336", "utils.py:106-112"):
+        assert needle in text, needle
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(lg._lib, "_lib", None)
+    monkeypatch.setattr(lg._lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(lg._lib.HipLibraryError, match="no CPU fallback"):
+        lg._lib.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "laplace-gnn_amd")
+    for path in glob.glob(os.path.join(pkg, "**", "*"), recursive=True):
+        if path.endswith((".py", ".hip", ".h", ".cpp")):
+            src = open(path).read()
+            assert "gnn_laplace_oracle" not in src and "oracle/" not in src, path
+
+
+# ---- Kron container (laplace tests/test_matrix.py patterns) ------------------------------------------
+def _rand_kron(seed=0):
+    g = torch.Generator().manual_seed(seed)
+
+    def psd(n):
+        a = torch.randn(n, n + 3, generator=g)
+        return a @ a.T
+
+    return lg.Kron([[psd(4), psd(6)], [psd(4)], [psd(3), psd(4)], [psd(3)]])
+
+
+def test_kron_add_mul_diag_to_matrix():
+    k1, k2 = _rand_kron(0), _rand_kron(1)
+    s = k1 + k2
+    for Fs, Fa, Fb in zip(s.kfacs, k1.kfacs, k2.kfacs):
+        for h, a, b in zip(Fs, Fa, Fb):
+            assert torch.allclose(h, a + b)
+    m = k1 * 0.25
+    assert torch.allclose(m.kfacs[0][0], 0.5 * k1.kfacs[0][0])  # sqrt(0.25) per factor of a 2-block
+    assert torch.allclose(m.kfacs[1][0], 0.25 * k1.kfacs[1][0])
+    assert torch.allclose(m.to_matrix(), 0.25 * k1.to_matrix(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(k1.diag(), k1.to_matrix().diag(), rtol=1e-5)
+    assert torch.allclose(k1.logdet(), torch.logdet(k1.to_matrix()), rtol=1e-4)
+    with pytest.raises(ValueError):
+        k1 + 3
+    with pytest.raises(ValueError):
+        k1 * "x"
+
+
+def test_kron_decompose_matches_dense():
+    k = _rand_kron(2)
+    kd = k.decompose()
+    assert torch.allclose(kd.to_matrix(), k.to_matrix(), rtol=1e-3, atol=1e-3)
+    delta = torch.tensor(0.7)
+    dense = k.to_matrix() + 0.7 * torch.eye(k.to_matrix().shape[0])
+    assert torch.allclose((kd + delta).logdet(), torch.logdet(dense), rtol=1e-4)
+    assert torch.allclose((kd * 2.0 + delta).logdet(), torch.logdet(2 * k.to_matrix() + 0.7 * torch.eye(dense.shape[0])),
+                          rtol=1e-4)
+    # symeig clamps at zero like laplace/utils/utils.py:221-224
+    L, W = lg.symeig(torch.tensor([[1.0, 0.0], [0.0, -1e-3]]))
+    assert float(L.min()) == 0.0
+
+
+def test_kron_init_from_model_layout():
+    lin = torch.nn.Linear(5, 3)
+    k = lg.Kron.init_from_model([lin.weight, lin.bias], "cpu")
+    assert [tuple(h.shape) for F in k.kfacs for h in F] == [(3, 3), (5, 5), (3, 3)]
+
+
+# ---- loaders ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,bs", [(33, 12), (10, 10), (7, 100), (25, 1)])
+def test_tensor_batch_loader_has_dataloader_boundaries(n, bs):
+    from torch.utils.data import DataLoader, TensorDataset
+
+    idx, y = torch.arange(n) * 3, torch.arange(n) % 4
+    ours = list(lg.TensorBatchLoader(idx, y, bs))
+    ref = list(DataLoader(TensorDataset(idx, y), batch_size=bs, shuffle=False))
+    assert len(ours) == len(ref) == len(lg.TensorBatchLoader(idx, y, bs))
+    for (a, b), (c, d) in zip(ours, ref):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    assert len(lg.TensorBatchLoader(idx, y, bs).dataset) == n
+
+
+def test_batches_of_rank_partition():
+    for world in (1, 2, 3, 8, 16):
+        owned = [lg.batches_of_rank(10, r, world) for r in range(world)]
+        assert sorted(t for o in owned for t in o) == list(range(10))
+    assert [len(lg.batches_of_rank(10, r, 8)) for r in range(8)] == [2, 2, 1, 1, 1, 1, 1, 1]
+
+
+# ---- front-end with an injected oracle backend ------------------------------------------------------------
+def _cpu_model(g):
+    kind, L = str(g["kind"]), int(g["num_layers"])
+    X, ei = torch.from_numpy(g["X"]), torch.from_numpy(g["edge_index"])
+    cls = lg.GCN if kind == "gcn" else lg.GraphSAGE
+    m = cls(X.shape[1], g["W0"].shape[0], g[f"W{L - 1}"].shape[0], L, X, ei, symmetric=bool(g["symmetric"]))
+    with torch.no_grad():
+        for l, conv in enumerate(m.convs):
+            conv.lin.weight.copy_(torch.from_numpy(g[f"W{l}"]))
+            conv.lin.bias.copy_(torch.from_numpy(g[f"b{l}"]))
+    return CpuForwardGCN(m.eval())
+
+
+@pytest.mark.parametrize("name", ["gcn_small_3batch_s1", "sage_small_3batch_s1", "gcn_small_isolated_s0"])
+def test_fit_loop_with_oracle_backend_matches_reference(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = _cpu_model(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"]),
+                                  int(g["batch_size"]))
+    la = lg.Laplace(model, "classification", subset_of_weights="all", hessian_structure="kron", backend=OracleBackend)
+    la.fit(loader)
+    assert [c[0] for c in la.backend.calls] == ["kron"] * len(loader)
+    for i, Fs in enumerate(la.H_facs.kfacs):
+        for j, Hm in enumerate(Fs):
+            assert rel(Hm.numpy(), g[f"kron_{i}_{j}"]) < RTOL
+    assert abs(float(la.loss) - float(g["kron_loss"])) < RTOL * float(g["kron_loss"])
+    assert (la.n_data, la.n_outputs, la.n_params) == (int(g["n_data"]), int(g["n_outputs"]), int(g["n_params"]))
+    assert isinstance(la.H, lg.KronDecomposed)
+    ld = lg.Laplace(model, "classification", "all", "diag", backend=OracleBackend)
+    ld.fit(loader)
+    assert rel(ld.H.numpy(), g["diag_H"]) < RTOL
+    # marginal likelihood identity (laplace tests/test_baselaplace.py:308-384 pattern), diag case
+    pp = 0.7
+    ld.prior_precision = pp
+    expect = -float(ld.loss) - 0.5 * (float(torch.log(ld.H + pp).sum()) - ld.n_params * np.log(pp)
+                                      + pp * float(ld.mean @ ld.mean))
+    assert abs(float(ld.log_marginal_likelihood()) - expect) < 1e-3 * abs(expect)
+    la.prior_precision = pp
+    dense = la.H_facs.to_matrix() + pp * torch.eye(la.n_params)
+    expect = -float(la.loss) - 0.5 * (float(torch.logdet(dense.double())) - la.n_params * np.log(pp)
+                                      + pp * float(la.mean @ la.mean))
+    assert abs(float(la.log_marginal_likelihood()) - expect) < 1e-3 * abs(expect)
+
+
+def test_override_false_triples_and_override_true_is_idempotent():
+    """tests/test_baselaplace.py:387-426 pattern: fit, fit(override=False), fit(override=False)."""
+    g = np.load(os.path.join(GOLDEN, "gcn_small_1batch_s0.npz"))
+    model = _cpu_model(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"]), 10000)
+    ld = lg.DiagLaplace(model, "classification", backend=OracleBackend)
+    ld.fit(loader)
+    H1 = ld.H.clone()
+    ld.fit(loader)
+    assert torch.allclose(ld.H, H1)
+    ld.fit(loader, override=False)
+    ld.fit(loader, override=False)
+    assert torch.allclose(ld.H, 3 * H1, rtol=1e-5) and ld.n_data == 3 * len(loader.dataset)
+
+
+def test_factory_keys_and_errors():
+    g = np.load(os.path.join(GOLDEN, "gcn_small_1batch_s0.npz"))
+    model = _cpu_model(g)
+    assert isinstance(lg.Laplace(model, "classification", "all", "kron", backend=OracleBackend), lg.KronLaplace)
+    assert isinstance(lg.Laplace(model, "classification", "all", "diag", backend=OracleBackend), lg.DiagLaplace)
+    ll = lg.Laplace(model, "classification", "last_layer", "full", backend=OracleBackend)
+    assert isinstance(ll, lg.FullLLLaplace) and ll.n_params == 3 * 8 + 3
+    with pytest.raises(NotImplementedError):
+        lg.Laplace(model, "classification", "all", "lowrank")
+    with pytest.raises(ValueError):
+        lg.Laplace(model, "classification", "subnetwork", "kron")
+    with pytest.raises(ValueError):
+        lg.Laplace(model, "poisson", "all", "kron")
+    with pytest.raises(ValueError):
+        lg.KronLaplace(model, "classification", sigma_noise=2.0)
+    with pytest.raises(TypeError, match="engine"):
+        lg.HipGGN(torch.nn.Linear(2, 2), "classification")
+
+
+def test_lastlayer_full_front_with_oracle_backend():
+    g = np.load(os.path.join(GOLDEN, "sage_small_1batch_s0.npz"))
+    model = _cpu_model(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"]), 10000)
+    ll = lg.Laplace(model, "classification", "last_layer", "full", backend=OracleBackend)
+    ll.fit(loader)
+    p = ll.n_params
+    assert rel(ll.H.numpy(), g["full_H"][-p:, -p:]) < RTOL
+    assert ll.mean.shape[0] == p
+
+
+def test_model_constructor_validation():
+    X = torch.randn(6, 4)
+    adj = torch.zeros(6, 6)
+    adj[0, 1] = adj[2, 3] = 1
+    m = lg.GCN(4, 5, 3, 2, X, adj)
+    assert m.edge_index.tolist() == [[0, 2], [1, 3]]
+    assert [tuple(p.shape) for p in m.parameters()] == [(5, 4), (5,), (3, 5), (3,)]
+    s = lg.GraphSAGE(4, 5, 3, 2, X, adj, None)
+    assert [tuple(p.shape) for p in s.parameters()] == [(5, 8), (5,), (3, 10), (3,)]
+    with pytest.raises(AssertionError):
+        lg.GCN(4, 5, 3, 2, X, adj * 2)
+    for kw in (dict(norm="layer"), dict(res=True), dict(act="gelu"), dict(update_adj=True)):
+        with pytest.raises(NotImplementedError):
+            lg.GCN(4, 5, 3, 2, X, adj, **kw)
+    with pytest.raises(NotImplementedError):
+        lg.GraphSAGE(4, 5, 3, 2, X, adj, 5)
