@@ -1,0 +1,188 @@
+"""GPU parity beyond the golden sizes: (a) seeded mid-size graphs against the CPU oracle, incl. edge
+cases the domain has (skewed degrees, empty edge list, single-sample batch, ragged last batch,
+3-layer models); (b) BASELINE-size (arxiv-shaped) runs checked through size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+import gnn_laplace_oracle as O
+from gpu_utils import kfac_fit_engine, oracle_from_arrays, rel
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def _make(kind, N, F, H, C, E, L=2, seed=0, skew=False, symmetric=True):
+    g = torch.Generator().manual_seed(seed)
+    if skew:  # a few hubs with thousands of neighbours + a long tail (power-law-like)
+        w = torch.rand(N, generator=g) ** 6
+        src = torch.multinomial(w + 1e-6, E, replacement=True, generator=g)
+        dst = torch.randint(0, N, (E,), generator=g)
+        ei = torch.stack([src, dst])
+    else:
+        ei = torch.randint(0, N, (2, E), generator=g)
+    X = torch.randn(N, F, generator=g)
+    mult = 2 if kind == "sage" else 1
+    dims = [F] + [H] * (L - 1) + [C]
+    Ws = [torch.randn(dims[l + 1], mult * dims[l], generator=g) / (mult * dims[l]) ** 0.5 for l in range(L)]
+    bs = [torch.randn(dims[l + 1], generator=g) * 0.1 for l in range(L)]
+    return ei, X, Ws, bs
+
+
+def _engine(kind, N, ei, X, Ws, bs, symmetric=True):
+    import laplace_gnn_amd as lg
+
+    eng = lg.GraphEngine(ei.cuda(), N, kind=kind, symmetric=symmetric)
+    eng.bind(X.cuda(), [w.cuda() for w in Ws], [b.cuda() for b in bs])
+    return eng
+
+
+@pytest.mark.parametrize("kind,skew,L", [("gcn", False, 2), ("gcn", True, 2), ("sage", True, 2), ("gcn", False, 3),
+                                         ("sage", False, 3), ("gcn", False, 1)])
+def test_kfac_midsize_vs_oracle(kind, skew, L):
+    N, F, H, C, E = 4000, 96, 64, 10, 16000
+    ei, X, Ws, bs = _make(kind, N, F, H, C, E, L=L, seed=3, skew=skew)
+    g = torch.Generator().manual_seed(7)
+    idx = torch.randperm(N, generator=g)[:900]
+    y = torch.randint(0, C, (900,), generator=g)
+    eng = _engine(kind, N, ei, X, Ws, bs)
+    views, loss = kfac_fit_engine(eng, idx.cuda(), y.cuda(), 400)  # 400 / 400 / 100 (ragged)
+    om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], True)
+    oloss, oH = O.fit_kron(om, idx.numpy(), y.numpy(), 400)
+    for l, (A, B) in enumerate(views):
+        assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL, f"B_{l}"
+        assert rel(A.cpu().numpy(), oH[2 * l][1]) < RTOL, f"A_{l}"
+    assert abs(loss - float(oloss)) < RTOL * abs(float(oloss))
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
+def test_diag_and_lastlayer_midsize_vs_oracle(kind):
+    N, F, H, C, E = 1500, 50, 32, 6, 5000
+    ei, X, Ws, bs = _make(kind, N, F, H, C, E, seed=5, skew=True)
+    g = torch.Generator().manual_seed(9)
+    idx = torch.randperm(N, generator=g)[:300]
+    y = torch.randint(0, C, (300,), generator=g)
+    eng = _engine(kind, N, ei, X, Ws, bs)
+    Hd = torch.zeros(eng.n_params, device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    for s in (0, 130):
+        eng.diag_accumulate(idx[s:s + 130 if s == 0 else None].cuda(), y[s:s + 130 if s == 0 else None].cuda(), Hd, loss)
+    om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], True)
+    _, oH = O.fit_diag(om, idx.numpy(), y.numpy(), 300)
+    assert rel(Hd.cpu().numpy(), oH) < RTOL
+    p_ll = Ws[-1].numel() + bs[-1].numel()
+    Hl = torch.zeros(p_ll, p_ll, device="cuda")
+    l2 = torch.zeros(1, device="cuda")
+    eng.lastlayer_full_accumulate(idx.cuda(), y.cuda(), Hl, l2)
+    _, oHl = O.lastlayer_full_batch(om, idx.numpy(), y.numpy())
+    assert rel(Hl.cpu().numpy(), oHl) < RTOL
+    # diag(last-layer full) == last-layer part of diag (cross-structure consistency)
+    assert rel(torch.diagonal(Hl).cpu().numpy(), oH[-p_ll:]) < RTOL
+    eng.close()
+
+
+def test_edge_cases_empty_graph_single_sample():
+    """No edges at all (GCN: A = I after self loops; GraphSAGE: all rows isolated) and a 1-sample batch."""
+    N, F, H, C = 50, 8, 16, 4
+    for kind in ("gcn", "sage"):
+        _, X, Ws, bs = _make(kind, N, F, H, C, 10, seed=1)
+        ei = torch.zeros(2, 0, dtype=torch.int64)
+        eng = _engine(kind, N, ei, X, Ws, bs, symmetric=False)
+        assert eng.nnz == (N if kind == "gcn" else 0)
+        idx, y = torch.tensor([7]), torch.tensor([2])
+        views, loss = kfac_fit_engine(eng, idx.cuda(), y.cuda(), 10)
+        om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], False)
+        _, oH = O.fit_kron(om, idx.numpy(), y.numpy(), 10)
+        for l, (A, B) in enumerate(views):
+            assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL and rel(A.cpu().numpy(), oH[2 * l][1]) < RTOL
+        eng.close()
+
+
+def test_bad_inputs_raise():
+    import laplace_gnn_amd as lg
+
+    N = 20
+    ei = torch.tensor([[0, 1], [1, 25]])  # 25 >= N
+    with pytest.raises(lg._lib.HipLibraryError, match="out of"):
+        lg.GraphEngine(ei.cuda(), N)
+    with pytest.raises(lg._lib.HipLibraryError, match="GPU"):
+        lg.GraphEngine(torch.tensor([[0], [1]]), N)  # CPU tensor
+    eng = lg.GraphEngine(torch.tensor([[0], [1]]).cuda(), N)
+    with pytest.raises(ValueError):
+        eng.bind(torch.randn(N, 4).cuda(), [torch.randn(3, 5).cuda()], [torch.randn(3).cuda()])
+    with pytest.raises(NotImplementedError):
+        eng.bind(torch.randn(N, 4).cuda(), [torch.randn(3, 4).cuda()], [torch.randn(3).cuda()], act="gelu")
+    eng.close()
+
+
+# ---- BASELINE size: arxiv-shaped -----------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def arxiv():
+    import bench
+    import laplace_gnn_amd as lg
+
+    w, ei, X, train_idx, train_y = bench.make_workload("arxiv", "cuda")
+    torch.manual_seed(0)
+    model = lg.GCN(w["F"], w["H"], w["C"], 2, X, ei, symmetric=True).to("cuda").eval()
+    return w, model, train_idx.cuda(), train_y.cuda(), X
+
+
+def test_arxiv_shape_properties(arxiv):
+    """Full-size run checked through properties that need no CPU reference:
+    * fused and unfused kernel paths agree (two independent implementations of B_0);
+    * A factors equal batches * X^T X / N_train (torch fp32 reference of the Gram kernel);
+    * factors symmetric, positive semi-definite; loss equals torch's CE on the engine's logits;
+    * one batch processed twice doubles B (linearity of the accumulate)."""
+    w, model, idx, y, X = arxiv
+    eng = model.engine
+    M = w["batch"]
+    b0, b1 = slice(0, M), slice(M, 2 * M)
+    _, v_f, loss_f = eng.new_kfac_buffers()
+    eng.kfac_accumulate(idx[b0], y[b0], w["n_train"], v_f, loss_f, fuse=True)
+    _, v_u, loss_u = eng.new_kfac_buffers()
+    eng.kfac_accumulate(idx[b0], y[b0], w["n_train"], v_u, loss_u, fuse=False)
+    torch.cuda.synchronize()
+    for (Af, Bf), (Au, Bu) in zip(v_f, v_u):
+        assert rel(Bf.cpu().numpy(), Bu.cpu().numpy()) < 1e-5
+        assert torch.equal(Af, Au)
+        assert torch.equal(Bf, Bf.T)
+        ev = torch.linalg.eigvalsh(Bf.double())
+        assert float(ev.min()) > -1e-5 * float(ev.max())
+    Xd = X.cuda().double()
+    assert rel(v_f[0][0].cpu().numpy(), (Xd.T @ Xd / w["n_train"]).cpu().numpy()) < 1e-5
+    logits = model(idx[b0])
+    ce = torch.nn.functional.cross_entropy(logits.double(), y[b0], reduction="sum")
+    assert abs(float(loss_f) - float(ce)) < 1e-5 * float(ce)
+    # accumulate twice == 2x ; a different batch gives a different B but the same A increment
+    eng.kfac_accumulate(idx[b0], y[b0], w["n_train"], v_f, loss_f, fuse=True)
+    torch.cuda.synchronize()
+    assert rel(v_f[0][1].cpu().numpy(), 2 * v_u[0][1].cpu().numpy()) < 1e-5
+    _, v_2, l_2 = eng.new_kfac_buffers()
+    eng.kfac_accumulate(idx[b1], y[b1], w["n_train"], v_2, l_2, fuse=True)
+    torch.cuda.synchronize()
+    assert torch.equal(v_2[0][0], v_u[0][0]) and rel(v_2[0][1].cpu().numpy(), v_u[0][1].cpu().numpy()) > 1e-3
+
+
+def test_arxiv_shape_sampled_oracle_check(arxiv):
+    """B_1 (40 x 40) of one full-size batch against the oracle's sparse backward restricted to the top
+    layer (cheap on the CPU: no 256-wide planes)."""
+    w, model, idx, y, X = arxiv
+    eng = model.engine
+    M = 2000
+    _, v, loss = eng.new_kfac_buffers()
+    eng.kfac_accumulate(idx[:M], y[:M], w["n_train"], v, loss)
+    torch.cuda.synchronize()
+    logits = eng.forward_all().cpu().numpy()
+    rows, cols, vals = [t.cpu().numpy() for t in eng.export_propagation()]
+    import scipy.sparse as sp
+    P = sp.csr_matrix((vals, (rows, cols)), shape=(w["N"], w["N"]))
+    V = O.kfac_seeds(logits[idx[:M].cpu().numpy()])
+    B1 = np.zeros((w["C"], w["C"]), np.float64)
+    PT = P.T.tocsr()
+    sel = sp.csr_matrix((np.ones(M, np.float32), (idx[:M].cpu().numpy(), np.arange(M))), shape=(w["N"], M))
+    PTs = (PT @ sel).tocsr()
+    for c in range(w["C"]):
+        g1 = PTs @ V[:, :, c]
+        B1 += g1.T.astype(np.float64) @ g1
+    assert rel(v[1][1].cpu().numpy(), B1) < RTOL
