@@ -41,6 +41,7 @@ class GraphEngine:
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError("edge_index must have shape [2, E]")
         ei = edge_index.contiguous()
+        _dev_ptr(ei, torch.int64, "edge_index")  # raises for CPU tensors: there is no CPU path
         self.device = ei.device
         self.kind = kind
         self.num_nodes = int(num_nodes)
