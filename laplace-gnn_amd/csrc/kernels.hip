@@ -148,6 +148,7 @@ struct GemmArgs {
   const float* hact; int64_t hact_ld; int64_t hact_row_mod; int act;
   int out_act;
   int vecA, vecB;
+  const uint8_t* row_active;  // optional, indexed like hact rows: inactive rows are not written
 };
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
@@ -223,7 +224,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
     __syncthreads();
   }
-  // epilogue
+  // epilogue.  hact / row_active rows are r % hact_row_mod; rows of a tile are consecutive, so one
+  // modulo per workgroup and a conditional subtract per row replace 64 integer divisions per lane
+  const bool wrap = g.hact_row_mod > 0;
+  const int64_t hbase = wrap ? row0 % g.hact_row_mod : row0;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -233,18 +237,160 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       const float bias = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int lr = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int64_t row = row0 + lr;
         if (row >= g.R) continue;
+        int64_t hr = hbase + lr;
+        if (wrap) { while (hr >= g.hact_row_mod) hr -= g.hact_row_mod; }
+        if (g.row_active && !g.row_active[hr]) continue;
         float v = acc[m][n][r] + bias;
-        if (g.hact) {
-          const int64_t hr = g.hact_row_mod > 0 ? row % g.hact_row_mod : row;
-          v *= act_deriv_from_out(g.hact[hr * g.hact_ld + col], g.act);
-        }
+        if (g.hact) v *= act_deriv_from_out(g.hact[hr * g.hact_ld + col], g.act);
         if (g.out_act >= 0) v = act_apply(v, g.out_act);
         g.C[row * g.ldc + col] = v;
       }
     }
   }
+}
+
+// Small-K variant (K <= 64, Nout <= 256): the backward GEMM  up = act'(h) * (g W)  has K = #classes.
+// B (the whole weight) sits in LDS once per workgroup, workgroups are persistent over 128-row tiles,
+// each wave owns 32 rows x all Nout columns (NT MFMA tiles), the next A tile is prefetched into
+// registers while the MFMAs of the current one run.  No K loop barriers, no per-element division.
+template <int NT, int VECA>
+__global__ __launch_bounds__(256, 2) void gemm_smallk_kernel(GemmArgs g) {
+  extern __shared__ float smem[];
+  const int K = int(g.K), K2 = (K + 1) & ~1, KP = K2 | 1;
+  constexpr int NP = NT * 32;
+  float* __restrict__ Bs = smem;
+  float* __restrict__ As = smem + K2 * NP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  for (int f = tid; f < K2 * NP; f += 256) {
+    const int k = f / NP, c = f - k * NP;
+    Bs[f] = (k < K && c < g.Nout) ? g.B[int64_t(k) * g.ldb + c] : 0.f;
+  }
+  const int64_t ntiles = (g.R + GBM - 1) / GBM;
+  constexpr int MAXV = VECA == 4 ? 8 : 32;  // staged float4 / floats per thread (K <= 64)
+  float4 st4[VECA == 4 ? MAXV : 1];
+  float st1[VECA == 1 ? MAXV : 1];
+  // Thread t stages elements t*VECA + e*256*VECA (e = 0..MAXV-1) of the tile in row-major order; their
+  // (row, k) coordinates advance by a fixed (q, rem) per step, so one division per thread per kernel.
+  const int step = 256 * VECA;
+  const int q = step / K, rem = step - q * K;
+  const int r_first = (tid * VECA) / K, k_first = (tid * VECA) - r_first * K;
+
+  auto load_tile = [&](int64_t tile) {
+    const int64_t row0 = tile * GBM;
+    int r = r_first, k = k_first;
+#pragma unroll
+    for (int e = 0; e < MAXV; ++e) {
+      const bool ok = r < GBM && row0 + r < g.R;
+      if constexpr (VECA == 4) {
+        st4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) st4[e] = *reinterpret_cast<const float4*>(g.A + (row0 + r) * g.lda + k);
+      } else {
+        st1[e] = ok ? g.A[(row0 + r) * g.lda + k] : 0.f;
+      }
+      r += q; k += rem;
+      if (k >= K) { k -= K; r += 1; }
+    }
+  };
+  auto store_tile = [&]() {
+    int r = r_first, k = k_first;
+#pragma unroll
+    for (int e = 0; e < MAXV; ++e) {
+      if (r < GBM) {
+        float* d = As + r * KP + k;
+        if constexpr (VECA == 4) { d[0] = st4[e].x; d[1] = st4[e].y; d[2] = st4[e].z; d[3] = st4[e].w; }
+        else d[0] = st1[e];
+      }
+      r += q; k += rem;
+      if (k >= K) { k -= K; r += 1; }
+    }
+  };
+  if (K2 != K) {  // odd K: the padding column of As must be zero
+    for (int r = tid; r < GBM; r += 256) As[r * KP + K] = 0.f;
+  }
+
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    store_tile();
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    constexpr int NTW = NT > 4 ? 4 : NT;  // column tiles per pass: 64 accumulator registers
+    const int64_t row0 = tile * GBM;
+    const bool wrap = g.hact_row_mod > 0;
+    const int64_t hbase = wrap ? row0 % g.hact_row_mod : row0;
+    // Row bookkeeping of the epilogue first, so the activity-flag loads fly during the MFMAs:
+    // hro[r] = row of hact / row_active for accumulator register r, wr[r] = this lane writes that row.
+    int32_t hro[16];
+    bool wr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      int64_t hr = hbase + lr;
+      if (wrap) { while (hr >= g.hact_row_mod) hr -= g.hact_row_mod; }
+      hro[r] = int32_t(hr);
+      const bool valid = row0 + lr < g.R;
+      wr[r] = valid && (g.row_active == nullptr || g.row_active[valid ? hr : 0] != 0);
+    }
+    const float* __restrict__ arow = As + (wave * 32 + l31) * KP + lhi;
+#pragma unroll 1
+    for (int pass = 0; pass < NT / NTW; ++pass) {
+      f32x16 acc[NTW];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+      const float* __restrict__ brow = Bs + lhi * NP + pass * NTW * 32 + l31;
+      for (int kk = 0; kk < K2 / 2; ++kk) {
+        const float av = arow[2 * kk];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[2 * kk * NP + n * 32], acc[n], 0, 0, 0);
+      }
+      const int colb = pass * NTW * 32 + l31;
+      // epilogue in two sweeps per 4 rows: all independent loads first, then math + predicated stores
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float hv[4][NTW];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r = rg * 4 + rr;
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) {
+            const int col = colb + n * 32;
+            hv[rr][n] = (g.hact && wr[r] && col < g.Nout) ? g.hact[int64_t(hro[r]) * g.hact_ld + col] : 1.f;
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r = rg * 4 + rr;
+          const int64_t row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) {
+            const int col = colb + n * 32;
+            float v = acc[n][r] + (g.bias ? g.bias[col < g.Nout ? col : 0] : 0.f);
+            if (g.hact) v *= act_deriv_from_out(hv[rr][n], g.act);
+            if (g.out_act >= 0) v = act_apply(v, g.out_act);
+            if (wr[r] && col < g.Nout) g.C[row * g.ldc + col] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int NT>
+static int smallk_launch(const GemmArgs& g, size_t smem, hipStream_t s) {
+  const int64_t ntiles = cdiv(g.R, GBM);
+  const unsigned grid = unsigned(std::min<int64_t>(ntiles, 512));
+  if (g.vecA && g.K % 4 == 0) hipLaunchKernelGGL((gemm_smallk_kernel<NT, 4>), dim3(grid), dim3(256), smem, s, g);
+  else hipLaunchKernelGGL((gemm_smallk_kernel<NT, 1>), dim3(grid), dim3(256), smem, s, g);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t R,
@@ -255,8 +401,22 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float*
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.R = R; g.K = K; g.Nout = Nout;
   g.bias = ep.bias; g.hact = ep.hact; g.hact_ld = ep.hact_ld; g.hact_row_mod = ep.hact_row_mod; g.act = ep.act;
   g.out_act = ep.out_act;
+  g.row_active = ep.row_active;
   g.vecA = (lda % 4 == 0) && aligned16(A);
   g.vecB = (ldb % 4 == 0) && aligned16(B);
+  if (K <= 64 && Nout <= 256 && R >= GBM) {
+    const int nt = Nout <= 32 ? 1 : (Nout <= 64 ? 2 : (Nout <= 128 ? 4 : 8));
+    const int K2 = int((K + 1) & ~int64_t(1)), KP = K2 | 1;
+    const size_t smem = (size_t(K2) * nt * 32 + size_t(GBM) * KP) * 4;
+    if (smem <= 64 * 1024) {
+      switch (nt) {
+        case 1: return smallk_launch<1>(g, smem, s);
+        case 2: return smallk_launch<2>(g, smem, s);
+        case 4: return smallk_launch<4>(g, smem, s);
+        default: return smallk_launch<8>(g, smem, s);
+      }
+    }
+  }
   const dim3 grid{unsigned(cdiv(R, GBM)), unsigned(cdiv(Nout, GBN)), 1u};
   hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, g);
   LGNN_HIP_CHECK(hipGetLastError());
@@ -295,14 +455,14 @@ __device__ __forceinline__ void gram_mfma_block(const float* __restrict__ ta, co
 #pragma unroll 4
   for (int kk = 0; kk < KT / 2; ++kk) {
     const int k = kk * 2 + lhi;
+    float av[NSLOT], bv[NSLOT];
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-      if (s < nmine) {
-        const float a = ta[k * ldt + si[s] * 32 + l31];
-        const float b = tb[k * ldt + sj[s] * 32 + l31];
-        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[s], 0, 0, 0);
-      }
+    for (int s = 0; s < NSLOT; ++s) {  // padding slots (s >= nmine) redo sub-tile (0,0); dropped at flush
+      av[s] = ta[k * ldt + si[s] * 32 + l31];
+      bv[s] = tb[k * ldt + sj[s] * 32 + l31];
     }
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[s], 0, 0, 0);
   }
 }
 
@@ -510,25 +670,35 @@ __global__ __launch_bounds__(256, 2) void spmm_gram_kernel(FusedArgs a) {
       const int64_t row = rb + r;
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < a.nrows && col_ok) {
-        const int32_t s = a.rowptr[row], e = a.rowptr[row + 1];
-        int32_t p = s;
-        for (; p + 4 <= e; p += 4) {
-          const int32_t j0 = a.col[p], j1 = a.col[p + 1], j2 = a.col[p + 2], j3 = a.col[p + 3];
-          const float v0 = a.val[p], v1 = a.val[p + 1], v2 = a.val[p + 2], v3 = a.val[p + 3];
-          const float4 x0 = *reinterpret_cast<const float4*>(in + int64_t(j0) * a.in_ld + c0);
-          const float4 x1 = *reinterpret_cast<const float4*>(in + int64_t(j1) * a.in_ld + c0);
-          const float4 x2 = *reinterpret_cast<const float4*>(in + int64_t(j2) * a.in_ld + c0);
-          const float4 x3 = *reinterpret_cast<const float4*>(in + int64_t(j3) * a.in_ld + c0);
-          y.x += v0 * x0.x; y.y += v0 * x0.y; y.z += v0 * x0.z; y.w += v0 * x0.w;
-          y.x += v1 * x1.x; y.y += v1 * x1.y; y.z += v1 * x1.z; y.w += v1 * x1.w;
-          y.x += v2 * x2.x; y.y += v2 * x2.y; y.z += v2 * x2.z; y.w += v2 * x2.w;
-          y.x += v3 * x3.x; y.y += v3 * x3.y; y.z += v3 * x3.z; y.w += v3 * x3.w;
+        int32_t s = a.rowptr[row], e = a.rowptr[row + 1];
+        if constexpr (RPW == 1) {  // one row per wave: bounds, (col, val) and row bases become scalar
+          s = __builtin_amdgcn_readfirstlane(s);
+          e = __builtin_amdgcn_readfirstlane(e);
         }
-        for (; p < e; ++p) {
-          const int32_t j = a.col[p];
-          const float v = a.val[p];
-          const float4 x = *reinterpret_cast<const float4*>(in + int64_t(j) * a.in_ld + c0);
-          y.x += v * x.x; y.y += v * x.y; y.z += v * x.z; y.w += v * x.w;
+        // UNR neighbour rows in flight per lane; entries with value 0 (masked-out inactive source rows,
+        // zero-degree scalings) issue no load at all
+        constexpr int UNR = 8;
+        for (int32_t p = s; p < e; p += UNR) {
+          float4 x[UNR];
+          float v[UNR];
+          int32_t j[UNR];
+          // (1) all (value, column) pairs of the chunk first: independent loads, one wait
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const bool ok = p + u < e;
+            v[u] = ok ? a.val[p + u] : 0.f;
+            j[u] = ok ? a.col[p + u] : 0;
+          }
+          // (2) then the row gathers back to back (skipped where the value is zero)
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v[u] != 0.f) x[u] = *reinterpret_cast<const float4*>(in + int64_t(j[u]) * a.in_ld + c0);
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            y.x += v[u] * x[u].x; y.y += v[u] * x[u].y; y.z += v[u] * x[u].z; y.w += v[u] * x[u].w;
+          }
         }
         if (a.self) {
           const float4 t = *reinterpret_cast<const float4*>(a.self + plane * a.self_plane_stride + row * a.self_ld + c0);
@@ -559,7 +729,7 @@ int launch_spmm_gram_ex(const FusedArgs& a, hipStream_t s) {
   const unsigned grid = unsigned(std::min<int64_t>(nblocks, 512));  // 2 workgroups per CU, persistent
   if (a.width <= 64) hipLaunchKernelGGL((spmm_gram_kernel<64>), dim3(grid), dim3(256), 0, s, a);
   else if (a.width <= 128) hipLaunchKernelGGL((spmm_gram_kernel<128>), dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((spmm_gram_kernel<256>), dim3(grid), dim3(256), 0, s, a);
+  else return launch_spmm_gram256(a, s);
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }

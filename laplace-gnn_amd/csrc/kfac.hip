@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void seed_kernel(const float* __restrict__ logi
 __global__ void seed_spmm_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                  const float* __restrict__ val, int64_t N, int64_t C,
                                  const int32_t* __restrict__ pos, const float* __restrict__ seeds,
-                                 float* __restrict__ g) {
+                                 float* __restrict__ g, uint8_t* __restrict__ active) {
   extern __shared__ float sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n = int64_t(blockIdx.x) * (blockDim.x >> 6) + wave;
@@ -144,6 +144,19 @@ __global__ void seed_spmm_kernel(const int32_t* __restrict__ rowptr, const int32
   for (int64_t q = lane; q < CC; q += 64) {
     const int64_t c = q / C, k = q - c * C;
     g[(c * N + n) * C + k] = any ? buf[q] : 0.f;
+  }
+  if (lane == 0) active[n] = any ? 1 : 0;
+}
+
+// values of P^T with the columns of all-zero source rows removed: the fused SpMM issues no load for them
+__global__ void mask_values_kernel(const int32_t* __restrict__ col, const float* __restrict__ val, int64_t nnz,
+                                   const uint8_t* __restrict__ active, const int32_t* __restrict__ pos,
+                                   float* __restrict__ out) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < nnz; p += stride) {
+    const int32_t j = col[p];
+    const bool on = active ? active[j] != 0 : pos[j] != INT32_MAX;
+    out[p] = on ? val[p] : 0.f;
   }
 }
 
@@ -247,11 +260,13 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
     LGNN_CALL(h->ws.top.reserve(size_t(N) * CC * 4));
     gtop = h->ws.top.as<float>();
   }
+  LGNN_CALL(h->ws.active.reserve(size_t(N)));
   if (h->kind == LGNN_KIND_GCN) {
     int waves = int(std::max<int64_t>(1, std::min<int64_t>(4, (48 * 1024) / (CC * 4))));
     LGNN_REQUIRE(CC * 4 <= 150 * 1024, "too many classes for the seed SpMM kernel");
     hipLaunchKernelGGL(seed_spmm_kernel, dim3(unsigned(cdiv(N, waves))), dim3(64 * waves), size_t(waves) * CC * 4, s,
-                       h->PT.rowptr, h->PT.col, h->PT.val, N, C, h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), gtop);
+                       h->PT.rowptr, h->PT.col, h->PT.val, N, C, h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), gtop,
+                       h->ws.active.as<uint8_t>());
     LGNN_HIP_CHECK(hipGetLastError());
     LGNN_CALL(launch_gram(gtop, C, C * N, C, h->ws.gram_scratch[L - 1].as<float>(), s));
   } else {
@@ -267,6 +282,21 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
 
   // ---- lower layers, chunked over classes ----------------------------------------------------------
   if (L > 1) {
+    // Source rows of the first backward plane set are non-zero only where the top-layer gradient is:
+    // GCN: nodes with a batch node among their P^T neighbours (flags from the seed SpMM);
+    // GraphSAGE: the batch nodes themselves.  Zeroed values make the fused SpMM skip those gathers.
+    const float* val_top = h->PT.val;
+    const uint8_t* row_active = nullptr;
+    if (!no_fuse && h->nnz > 0) {
+      LGNN_CALL(h->ws.val_act.reserve(size_t(h->nnz) * 4));
+      const bool gcn = h->kind == LGNN_KIND_GCN;
+      hipLaunchKernelGGL(mask_values_kernel, dim3(unsigned(std::min<int64_t>(cdiv(h->nnz, 256), 4096))), dim3(256), 0, s,
+                         h->PT.col, h->PT.val, h->nnz, gcn ? h->ws.active.as<uint8_t>() : (const uint8_t*)nullptr,
+                         h->ws.pos.as<int32_t>(), h->ws.val_act.as<float>());
+      LGNN_HIP_CHECK(hipGetLastError());
+      val_top = h->ws.val_act.as<float>();
+      if (gcn) row_active = h->ws.active.as<uint8_t>();
+    }
     int64_t maxw = 0;
     for (int l = 0; l < L - 1; ++l) maxw = std::max(maxw, h->in_dim[l + 1]);  // GEMM output width of layer l+1
     const int64_t per_class = N * maxw * 4 * 2;  // ping + pong
@@ -288,13 +318,17 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           // up = act'(h_l) * (g W_l)     (gnn/models/layers.py:45-46 backward through lin and the activation)
           GemmEpilogue ep;
           ep.hact = h->fc.hact_p[l - 1]; ep.hact_ld = h->fc.hact_ld[l - 1]; ep.act = h->act; ep.hact_row_mod = N;
+          const bool top_level = l == L - 1;
+          const bool fuse_here = !no_fuse && fused_supported(d, d, N * d, ping);
+          if (top_level && fuse_here) ep.row_active = row_active;  // inactive rows are never read below
           LGNN_CALL(launch_gemm(g, dout, h->W[l], d, ping, d, cc * N, dout, d, ep, s));
           FusedArgs a{};
-          a.rowptr = h->PT.rowptr; a.col = h->PT.col; a.val = h->PT.val; a.nrows = N; a.nplanes = cc;
+          a.rowptr = h->PT.rowptr; a.col = h->PT.col; a.val = (top_level && fuse_here) ? val_top : h->PT.val;
+          a.nrows = N; a.nplanes = cc;
           a.in = ping; a.in_ld = d; a.in_plane_stride = N * d;
           a.store = store ? pong : nullptr; a.store_ld = d; a.store_plane_stride = N * d;
           a.width = d; a.scratch = scratch;
-          if (!no_fuse && fused_supported(d, a.in_ld, a.in_plane_stride, a.in)) {
+          if (fuse_here) {
             if (h->timing && dominant) LGNN_CALL(record_event(h, s));
             LGNN_CALL(launch_spmm_gram_ex(a, s));
             if (h->timing && dominant) { LGNN_CALL(record_event(h, s)); h->ev_planes += cc; }
@@ -311,7 +345,8 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           GemmEpilogue ep;
           LGNN_CALL(launch_gemm(g, dout, h->W[l], 2 * d, ping, 2 * d, cc * N, dout, 2 * d, ep, s));
           FusedArgs a{};
-          a.rowptr = h->PT.rowptr; a.col = h->PT.col; a.val = h->PT.val; a.nrows = N; a.nplanes = cc;
+          a.rowptr = h->PT.rowptr; a.col = h->PT.col; a.val = (l == L - 1) ? val_top : h->PT.val;
+          a.nrows = N; a.nplanes = cc;
           a.in = ping + d; a.in_ld = 2 * d; a.in_plane_stride = N * 2 * d;
           a.self = ping; a.self_ld = 2 * d; a.self_plane_stride = N * 2 * d;
           a.hact = h->fc.hact_p[l - 1]; a.hact_ld = h->fc.hact_ld[l - 1]; a.act = h->act;

@@ -82,6 +82,8 @@ struct Workspace {
   DevBuf gram_scratch[kMaxLayers];  // [out_l, out_l] per-call partial B (upper sub-tiles)
   DevBuf misc;
   DevBuf top;    // top-layer gradient planes [C][N][C]
+  DevBuf active;   // uint8 [N]: node has a non-zero top-layer gradient row
+  DevBuf val_act;  // fp32 [nnz]: P^T values with inactive source columns zeroed
   DevBuf flags;  // 64 B of asynchronous error flags
 };
 
@@ -171,6 +173,7 @@ struct GemmEpilogue {
   int act = 0;                  // LGNN_ACT_*
   int64_t hact_row_mod = 0;     // hact row = r % hact_row_mod (planes are [c][n][w]); 0 -> r
   int out_act = -1;             // apply activation to the result itself (-1 none)
+  const uint8_t* row_active = nullptr;  // optional [hact rows]: rows flagged 0 are neither computed on nor written
 };
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t R,
                 int64_t K, int64_t Nout, const GemmEpilogue& ep, hipStream_t s);
@@ -182,6 +185,7 @@ int launch_sym_accumulate(const float* scratch, int64_t D, float scale, float* o
 // fused: rows r=(plane, n): y = sum_j val*in_plane[col[j]]; scratch += y^T y; optional store of y
 int launch_spmm_ex(const SpmmArgs& a, int64_t nplanes, hipStream_t s);
 int launch_spmm_gram_ex(const FusedArgs& a, hipStream_t s);
+int launch_spmm_gram256(const FusedArgs& a, hipStream_t s);  // fused256.hip
 bool fused_supported(int64_t width, int64_t in_ld, int64_t in_plane_stride, const void* in);
 int launch_spmm_gram(const Csr& m, int64_t nrows, int64_t nplanes, const float* in, float* store_or_null,
                      int64_t width, float* scratch, hipStream_t s);
