@@ -1,0 +1,219 @@
+// Backward plane GEMM of the KFAC path (GCN):  U[p][n][:] = act'(h[n][:]) * (G[p][n][:] @ W)
+// for the ACTIVE nodes n only (nodes whose top-layer gradient row is non-zero for this batch).
+//
+//   K  = width of G (number of classes at the top level, <= 64)  -> no K loop, W lives in LDS
+//   Nout <= 256                                                  -> a wave owns 32 rows x all columns
+// Persistent 256-thread workgroups walk (plane, 128-row tile) pairs of the compacted row list; the next
+// A tile is prefetched into registers while the MFMAs (v_mfma_f32_32x32x2_f32) of the current one run.
+// The activation derivative comes from a per-node bit mask for ReLU (32 B per node instead of a 1 KiB
+// float row) and from the float activations otherwise.  Inactive rows are never written: the fused
+// SpMM that consumes U skips them (their P^T values are zeroed, kfac.hip).
+#include "device_utils.h"
+#include "gram256.h"  // f32x16
+#include "lgnn_internal.h"
+
+namespace lgnn {
+
+namespace {
+
+constexpr int BGM = 128;  // rows per tile
+
+template <int NT, int VECA>
+__global__ __launch_bounds__(256, 2) void backgemm_kernel(BackGemmArgs g) {
+  extern __shared__ float smem[];
+  const int K = int(g.K), K2 = (K + 1) & ~1, KP = K2 | 1;
+  constexpr int NP = NT * 32;
+  constexpr int NTW = NT > 4 ? 4 : NT;  // column tiles per pass (64 accumulator registers)
+  float* __restrict__ Bs = smem;
+  float* __restrict__ As = smem + K2 * NP;
+  int32_t* __restrict__ nodes = reinterpret_cast<int32_t*>(As + BGM * KP);  // node id of every tile row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  for (int f = tid; f < K2 * NP; f += 256) {
+    const int k = f / NP, c = f - k * NP;
+    Bs[f] = (k < K && c < g.Nout) ? g.W[int64_t(k) * g.ldw + c] : 0.f;
+  }
+  if (K2 != K)
+    for (int r = tid; r < BGM; r += 256) As[r * KP + K] = 0.f;
+
+  const int64_t na = g.rows ? int64_t(*g.na_dev) : g.N;
+  const int64_t tiles_per_plane = (na + BGM - 1) / BGM;
+  const int64_t ntiles = tiles_per_plane * g.planes;
+
+  constexpr int MAXV = VECA == 4 ? 8 : 32;
+  float4 st4[VECA == 4 ? MAXV : 1];
+  float st1[VECA == 1 ? MAXV : 1];
+  const int step = 256 * VECA;
+  const int q = step / K, rem = step - q * K;
+  const int r_first = (tid * VECA) / K, k_first = (tid * VECA) - r_first * K;
+
+  auto tile_coords = [&](int64_t tile, int64_t& plane, int64_t& t0) {
+    plane = tile / tiles_per_plane;
+    t0 = (tile - plane * tiles_per_plane) * BGM;
+  };
+  auto node_of = [&](int64_t t) -> int64_t { return g.rows ? int64_t(g.rows[t]) : t; };
+  auto load_tile = [&](int64_t tile) {
+    int64_t plane, t0;
+    tile_coords(tile, plane, t0);
+    const float* __restrict__ base = g.G + plane * g.N * g.K;
+    int r = r_first, k = k_first;
+#pragma unroll
+    for (int e = 0; e < MAXV; ++e) {
+      const bool ok = r < BGM && t0 + r < na;
+      if constexpr (VECA == 4) {
+        st4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) st4[e] = *reinterpret_cast<const float4*>(base + node_of(t0 + r) * g.K + k);
+      } else {
+        st1[e] = ok ? base[node_of(t0 + r) * g.K + k] : 0.f;
+      }
+      r += q; k += rem;
+      if (k >= K) { k -= K; r += 1; }
+    }
+  };
+  auto store_tile = [&](int64_t tile) {
+    int64_t plane, t0;
+    tile_coords(tile, plane, t0);
+    int r = r_first, k = k_first;
+#pragma unroll
+    for (int e = 0; e < MAXV; ++e) {
+      if (r < BGM) {
+        float* d = As + r * KP + k;
+        if constexpr (VECA == 4) { d[0] = st4[e].x; d[1] = st4[e].y; d[2] = st4[e].z; d[3] = st4[e].w; }
+        else d[0] = st1[e];
+      }
+      r += q; k += rem;
+      if (k >= K) { k -= K; r += 1; }
+    }
+    if (tid < BGM) nodes[tid] = t0 + tid < na ? int32_t(node_of(t0 + tid)) : -1;
+  };
+
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    store_tile(tile);
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    int64_t plane, t0;
+    tile_coords(tile, plane, t0);
+    float* __restrict__ Up = g.U + plane * g.N * g.Nout;
+    int32_t nd[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nd[r] = nodes[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+    const float* __restrict__ arow = As + (wave * 32 + l31) * KP + lhi;
+#pragma unroll 1
+    for (int pass = 0; pass < NT / NTW; ++pass) {
+      f32x16 acc[NTW];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+      const float* __restrict__ brow = Bs + lhi * NP + pass * NTW * 32 + l31;
+      for (int kk = 0; kk < K2 / 2; ++kk) {
+        const float av = arow[2 * kk];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[2 * kk * NP + n * 32], acc[n], 0, 0, 0);
+      }
+      const int colb = pass * NTW * 32 + l31;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        // all mask loads of 4 rows first, then math and stores
+        uint32_t mw[4][NTW];
+        float hv[4][NTW];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r = rg * 4 + rr;
+          const bool live = nd[r] >= 0;
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) {
+            mw[rr][n] = 0xffffffffu;
+            hv[rr][n] = 1.f;
+            const int col = colb + n * 32;
+            if (g.mask_bits) {
+              if (live) mw[rr][n] = g.mask_bits[int64_t(nd[r]) * g.mask_words + pass * NTW + n];
+            } else if (g.hact) {
+              if (live && col < g.Nout) hv[rr][n] = g.hact[int64_t(nd[r]) * g.hact_ld + col];
+            }
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r = rg * 4 + rr;
+          if (nd[r] < 0) continue;
+          float* __restrict__ urow = Up + int64_t(nd[r]) * g.Nout;
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) {
+            const int col = colb + n * 32;
+            float v = acc[n][r];
+            if (g.mask_bits) v = ((mw[rr][n] >> l31) & 1u) ? v : 0.f;
+            else if (g.hact) v *= act_deriv_from_out(hv[rr][n], g.act);
+            if (col < g.Nout) urow[col] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int NT>
+int backgemm_launch(const BackGemmArgs& g, size_t smem, bool vec, hipStream_t s) {
+  const int64_t worst = cdiv(g.N, BGM) * g.planes;
+  const unsigned grid = unsigned(std::min<int64_t>(worst, 512));
+  if (vec) hipLaunchKernelGGL((backgemm_kernel<NT, 4>), dim3(grid), dim3(256), smem, s, g);
+  else hipLaunchKernelGGL((backgemm_kernel<NT, 1>), dim3(grid), dim3(256), smem, s, g);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// bit j of word w of node n = (h[n][32 w + j] > 0)
+__global__ void relu_mask_bits_kernel(const float* __restrict__ h, int64_t ld, int64_t N, int64_t H, int64_t words,
+                                      uint32_t* __restrict__ bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;  // one wave per (node, 64-col chunk)
+  const int64_t chunks = (H + 63) / 64;
+  if (wid >= N * chunks) return;
+  const int64_t n = wid / chunks, ch = wid - n * chunks;
+  const int64_t col = ch * 64 + lane;
+  const bool on = col < H && h[n * ld + col] > 0.f;
+  const unsigned long long m = __ballot(on);
+  if (lane == 0) {
+    bits[n * words + 2 * ch] = uint32_t(m);
+    if (2 * ch + 1 < words) bits[n * words + 2 * ch + 1] = uint32_t(m >> 32);
+  }
+}
+
+}  // namespace
+
+bool backgemm_supported(int64_t K, int64_t Nout) {
+  if (K < 1 || K > 64 || Nout < 1 || Nout > 256) return false;
+  const int nt = Nout <= 32 ? 1 : (Nout <= 64 ? 2 : (Nout <= 128 ? 4 : 8));
+  const int K2 = int((K + 1) & ~int64_t(1)), KP = K2 | 1;
+  return (size_t(K2) * nt * 32 + size_t(BGM) * KP + BGM) * 4 <= 64 * 1024;
+}
+
+int launch_backgemm(const BackGemmArgs& g, hipStream_t s) {
+  if (g.planes <= 0 || g.N <= 0) return 0;
+  LGNN_REQUIRE(backgemm_supported(g.K, g.Nout), "backgemm shape not supported");
+  const int nt = g.Nout <= 32 ? 1 : (g.Nout <= 64 ? 2 : (g.Nout <= 128 ? 4 : 8));
+  const int K2 = int((g.K + 1) & ~int64_t(1)), KP = K2 | 1;
+  const size_t smem = (size_t(K2) * nt * 32 + size_t(BGM) * KP + BGM) * 4;
+  const bool vec = g.K % 4 == 0 && (reinterpret_cast<uintptr_t>(g.G) & 15) == 0;
+  switch (nt) {
+    case 1: return backgemm_launch<1>(g, smem, vec, s);
+    case 2: return backgemm_launch<2>(g, smem, vec, s);
+    case 4: return backgemm_launch<4>(g, smem, vec, s);
+    default: return backgemm_launch<8>(g, smem, vec, s);
+  }
+}
+
+int launch_relu_mask_bits(const float* h, int64_t ld, int64_t N, int64_t H, uint32_t* bits, hipStream_t s) {
+  const int64_t words = cdiv(H, 32), chunks = cdiv(H, 64);
+  const int64_t waves = N * chunks;
+  hipLaunchKernelGGL(relu_mask_bits_kernel, dim3(unsigned(cdiv(waves * 64, 256))), dim3(256), 0, s, h, ld, N, H, words,
+                     bits);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace lgnn

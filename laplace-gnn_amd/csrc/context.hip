@@ -63,6 +63,10 @@ static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
                               h->act == LGNN_ACT_RELU ? 1 : 2, s));
         fc.hact_p[l] = fc.act_out[l].as<float>();
         fc.hact_ld[l] = dout;
+        if (h->act == LGNN_ACT_RELU) {
+          LGNN_CALL(fc.mask_bits[l].reserve(size_t(N) * cdiv(dout, 32) * 4));
+          LGNN_CALL(launch_relu_mask_bits(fc.hact_p[l], dout, N, dout, fc.mask_bits[l].as<uint32_t>(), s));
+        }
         fc.lin_in_p[l + 1] = fc.hact_p[l];
         fc.lin_in_ld[l + 1] = dout;
       } else {
@@ -179,11 +183,11 @@ extern "C" void lgnn_destroy(lgnn_ctx* h) {
   (void)hipDeviceSynchronize();
   DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
                     &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.planes_a,
-                    &h->ws.planes_b, &h->ws.misc, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act};
+                    &h->ws.planes_b, &h->ws.misc, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (DevBuf* b : bufs) b->release();
   for (int l = 0; l < kMaxLayers; ++l) {
     h->Wt[l].release(); h->fc.lin_in[l].release(); h->fc.act_out[l].release(); h->fc.gram_raw[l].release();
-    h->fc.prop_in[l].release(); h->ws.gram_scratch[l].release();
+    h->fc.prop_in[l].release(); h->ws.gram_scratch[l].release(); h->fc.mask_bits[l].release();
   }
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   delete h;
@@ -239,11 +243,11 @@ extern "C" int64_t lgnn_device_bytes(const lgnn_ctx* h) {
   size_t t = 0;
   const DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
                           &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->ws.pos, &h->ws.seeds, &h->ws.probs,
-                          &h->ws.planes_a, &h->ws.planes_b, &h->ws.misc, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act};
+                          &h->ws.planes_a, &h->ws.planes_b, &h->ws.misc, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (const DevBuf* b : bufs) t += b->bytes;
   for (int l = 0; l < kMaxLayers; ++l)
     t += h->Wt[l].bytes + h->fc.lin_in[l].bytes + h->fc.act_out[l].bytes + h->fc.gram_raw[l].bytes +
-         h->fc.prop_in[l].bytes + h->ws.gram_scratch[l].bytes;
+         h->fc.prop_in[l].bytes + h->ws.gram_scratch[l].bytes + h->fc.mask_bits[l].bytes;
   return int64_t(t);
 }
 

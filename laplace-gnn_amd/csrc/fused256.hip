@@ -29,19 +29,22 @@ constexpr int UNR = 12;    // neighbour rows in flight per lane and per pipeline
 constexpr int DEPTH = 3;   // rows whose gathers are in flight per wave
 constexpr int RPWB = KT256 / 4;  // rows per gather wave and block
 
-// First <= 64 entries of one CSR row, one entry per lane, plus the lanes whose value is non-zero.
+// First <= 64 entries of one CSR row, one per lane, then compacted so that the entries with a non-zero
+// value sit in lanes 0 .. nlive-1 (mbcnt rank + one ds_permute pair per ROW): entry u of the row is then
+// lane u, a compile-time lane for v_readlane, and zero entries never issue a load.
 struct RowEntries {
-  int32_t cj;               // column of entry `lane`
-  int32_t cvi;              // value bits of entry `lane` (0 beyond the row)
-  unsigned long long live;  // ballot(value != 0): zero entries never issue a load
-  int32_t s, e;             // row bounds (uniform)
+  int32_t cj;     // before compaction: column of entry `lane`; after: BYTE offset of live entry `lane`'s source
+                  // row inside the plane (out of range for dead lanes: the buffer unit then returns zeros)
+  int32_t cvi;    // value bits of live entry `lane` (0 for dead lanes)
+  int32_t nlive;  // number of live entries among the first 64 (uniform)
+  int32_t s, e;   // row bounds (uniform)
 };
 
 __device__ __forceinline__ RowEntries load_entries(const int32_t* __restrict__ col, const float* __restrict__ val,
                                                    int32_t s, int32_t e, int lane) {
   RowEntries r;
   r.s = s; r.e = e;
-  r.cj = 0; r.cvi = 0; r.live = 0ull;
+  r.cj = 0; r.cvi = 0; r.nlive = 0;
   if (lane < e - s) {
     r.cj = col[s + lane];
     r.cvi = __float_as_int(val[s + lane]);
@@ -49,50 +52,81 @@ __device__ __forceinline__ RowEntries load_entries(const int32_t* __restrict__ c
   return r;
 }
 
-// Issue the gathers of the first (up to) UNR live entries of `m`; consumed bits are cleared.
-__device__ __forceinline__ void issue_gathers(unsigned long long& m, int32_t cj, int32_t cvi,
-                                              const float* __restrict__ in, int64_t in_ld, int cl,
-                                              float4 (&x)[UNR], float (&v)[UNR]) {
+__device__ __forceinline__ void compact_entries(RowEntries& r, int lane, int row_bytes) {
+  const bool live = r.cvi != 0;
+  const unsigned long long m = __ballot(live);
+  const int nlive = __builtin_amdgcn_readfirstlane(int(__builtin_popcountll(m)));
+  const int below = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0));
+  const int dst = live ? below : nlive + (lane - below);  // a permutation of 0..63: live first, order kept
+  const int32_t off = live ? int32_t(uint32_t(r.cj) * uint32_t(row_bytes)) : int32_t(0xfffffff0u);
+  r.cj = __builtin_amdgcn_ds_permute(dst * 4, off);
+  r.cvi = __builtin_amdgcn_ds_permute(dst * 4, r.cvi);
+  r.nlive = nlive;
+}
+
+using srd_t = __amdgpu_buffer_rsrc_t;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+// Issue the gathers of live entries u0 .. u0+UNR-1 (u0 uniform).  One buffer load per entry: the plane is
+// the buffer, the lane's 16 bytes are the vector offset, the neighbour row is a scalar offset.
+// Per slot: one v_readlane (byte offset -> SGPR) and one buffer load; nothing is kept in scalar registers
+// between issue and use (the value is read again with v_readlane when the row is consumed), and dead
+// slots need no branch or select: their offset is out of range (zeros come back) and their value is 0.
+template <bool CONST_U0>
+__device__ __forceinline__ void issue_gathers(const RowEntries& r, int u0, srd_t srd, int voff, float4 (&x)[UNR]) {
 #pragma unroll
   for (int u = 0; u < UNR; ++u) {
-    v[u] = 0.f;
-    x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m != 0ull) {
-      const int b = __builtin_ctzll(m);
-      m &= m - 1ull;
-      const int32_t j = __builtin_amdgcn_readlane(cj, b);
-      v[u] = __int_as_float(__builtin_amdgcn_readlane(cvi, b));
-      x[u] = *reinterpret_cast<const float4*>(in + int64_t(j) * in_ld + cl);
-    }
+    const int idx = CONST_U0 ? u : min(u0 + u, 63);
+    int32_t soff = __builtin_amdgcn_readlane(r.cj, idx);
+    if (!CONST_U0 && u0 + u > 63) soff = int32_t(0xfffffff0u);
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(srd, voff, soff, 0);
+    x[u] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
   }
 }
 
-__device__ __forceinline__ void accumulate(float4& y, const float4 (&x)[UNR], const float (&v)[UNR]) {
+template <bool CONST_U0>
+__device__ __forceinline__ void accumulate(float4& y, const RowEntries& r, int u0, const float4 (&x)[UNR]) {
 #pragma unroll
   for (int u = 0; u < UNR; ++u) {
-    y.x += v[u] * x[u].x; y.y += v[u] * x[u].y; y.z += v[u] * x[u].z; y.w += v[u] * x[u].w;
+    const int idx = CONST_U0 ? u : min(u0 + u, 63);
+    float v = __int_as_float(__builtin_amdgcn_readlane(r.cvi, idx));
+    if (!CONST_U0 && u0 + u > 63) v = 0.f;
+    y.x += v * x[u].x; y.y += v * x[u].y; y.z += v * x[u].z; y.w += v * x[u].w;
   }
 }
 
-// Remainder of a row after its first UNR live entries were consumed: more rounds on the same 64
-// entries, then further 64-entry chunks (rows with more than 64 stored entries).  Not pipelined.
-__device__ __forceinline__ void gather_rest(float4& y, unsigned long long m, RowEntries r,
-                                            const int32_t* __restrict__ col, const float* __restrict__ val,
-                                            const float* __restrict__ in, int64_t in_ld, int lane, int cl) {
+// Remainder of a row after its first UNR live entries: more rounds on the same 64 entries, then further
+// 64-entry chunks (rows with more than 64 stored entries).  Not pipelined.
+__device__ __forceinline__ void gather_rest(float4& y, const RowEntries& r, const int32_t* __restrict__ col,
+                                            const float* __restrict__ val, srd_t srd, int voff, int row_bytes,
+                                            int lane) {
   float4 x[UNR];
-  float v[UNR];
-  while (m != 0ull) {
-    issue_gathers(m, r.cj, r.cvi, in, in_ld, cl, x, v);
-    accumulate(y, x, v);
+  for (int u0 = UNR; u0 < r.nlive; u0 += UNR) {
+    issue_gathers<false>(r, u0, srd, voff, x);
+    accumulate<false>(y, r, u0, x);
   }
   for (int32_t base = r.s + 64; base < r.e; base += 64) {
     RowEntries c = load_entries(col, val, base, r.e, lane);
-    unsigned long long mm = __ballot(c.cvi != 0);
-    while (mm != 0ull) {
-      issue_gathers(mm, c.cj, c.cvi, in, in_ld, cl, x, v);
-      accumulate(y, x, v);
+    compact_entries(c, lane, row_bytes);
+    for (int u0 = 0; u0 < c.nlive; u0 += UNR) {
+      issue_gathers<false>(c, u0, srd, voff, x);
+      accumulate<false>(y, c, u0, x);
     }
   }
+}
+
+template <int W>
+__device__ __forceinline__ void mfma_wave(const FusedArgs& a, const float* __restrict__ tiles, int64_t nb, int lane) {
+  f32x16 acc[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  for (int64_t i = 0; i <= nb; ++i) {
+    if (i > 0 && a.debug != 1) gram256_block<W, KT256 / 2>(tiles + ((i - 1) & 1) * KT256 * 256, lane, acc);
+    if (a.debug != 4) __syncthreads();
+  }
+  gram256_flush<W>(a.scratch, a.width, lane, acc);
 }
 
 __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
@@ -105,9 +139,12 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
 
   if (wave < 4) {
     // ------------------------------------------------ gather waves
+    if (a.debug == 5) __builtin_amdgcn_s_setprio(2);
     const int c0 = lane * 4;
     const bool col_ok = c0 < a.width;  // width % 4 == 0 (launcher)
-    const int cl = col_ok ? c0 : 0;
+    const int voff = (col_ok ? c0 : 0) * 4;            // this lane's 16 bytes inside a neighbour row
+    const int row_bytes = int(a.in_ld) * 4;
+    const int plane_bytes = int(uint32_t(a.nrows * a.in_ld * 4));  // < 2^32 (launcher); offsets are unsigned 32 bit
     const int32_t* __restrict__ rowptr = a.rowptr;
     const int32_t* __restrict__ colp = a.col;
     const float* __restrict__ valp = a.val;
@@ -146,32 +183,32 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
     load_block_entries(0, rp_next, ent);
     rp_next = load_rp(1);
     for (int64_t i = 0; i <= nb; ++i) {
-      if (i < nb) {
+      if (i < nb && a.debug != 2 && a.debug != 4) {
         int64_t plane, rb;
         block_coords(i, plane, rb);
-        const float* __restrict__ in = a.in + plane * a.in_plane_stride;
+        const float* in = a.in + plane * a.in_plane_stride;
+        // the plane as a buffer resource (wave-uniform by construction: kernel arguments and blockIdx only)
+        const srd_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, plane_bytes, 0x00020000);
         float* __restrict__ t = &tile[i & 1][0][0];
 #pragma unroll
-        for (int it = 0; it < RPWB; ++it) ent[it].live = __ballot(ent[it].cvi != 0);
+        for (int it = 0; it < RPWB; ++it) compact_entries(ent[it], lane, row_bytes);
         // gathers DEPTH rows deep: rows it+1 .. it+DEPTH-1 are in flight while row it is consumed
         float4 x[DEPTH][UNR];
-        float v[DEPTH][UNR];
 #pragma unroll
         for (int d = 0; d < DEPTH - 1; ++d)
-          issue_gathers(ent[d].live, ent[d].cj, ent[d].cvi, in, a.in_ld, cl, x[d], v[d]);
+          issue_gathers<true>(ent[d], 0, srd, voff, x[d]);
 #pragma unroll
         for (int it = 0; it < RPWB; ++it) {
           if (it + DEPTH - 1 < RPWB)
-            issue_gathers(ent[it + DEPTH - 1].live, ent[it + DEPTH - 1].cj, ent[it + DEPTH - 1].cvi, in, a.in_ld, cl,
-                          x[(it + DEPTH - 1) % DEPTH], v[(it + DEPTH - 1) % DEPTH]);
+            issue_gathers<true>(ent[it + DEPTH - 1], 0, srd, voff, x[(it + DEPTH - 1) % DEPTH]);
           if (it + DEPTH - 1 == RPWB - 1) {  // all gathers of this block are issued: fetch the next block's rows
             load_block_entries(i + 1, rp_next, ent_next);
             rp_next = load_rp(i + 2);
           }
           float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-          accumulate(y, x[it % DEPTH], v[it % DEPTH]);
-          if (ent[it].live != 0ull || ent[it].e - ent[it].s > 64)
-            gather_rest(y, ent[it].live, ent[it], colp, valp, in, a.in_ld, lane, cl);
+          accumulate<true>(y, ent[it], 0, x[it % DEPTH]);
+          if (ent[it].nlive > UNR || ent[it].e - ent[it].s > 64)
+            gather_rest(y, ent[it], colp, valp, srd, voff, row_bytes, lane);
           const int r = it * 4 + wave;
           const int64_t row = rb + r;
           if (row < a.nrows && col_ok) {
@@ -195,40 +232,27 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
 #pragma unroll
         for (int it = 0; it < RPWB; ++it) ent[it] = ent_next[it];
       }
-      __syncthreads();
+      if (a.debug != 4) __syncthreads();
     }
   } else {
     // ------------------------------------------------ MFMA waves
-    f32x16 acc[9];
-#pragma unroll
-    for (int s = 0; s < 9; ++s)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-    const int mw = wave - 4;
-    for (int64_t i = 0; i <= nb; ++i) {
-      if (i > 0) {
-        const float* __restrict__ t = &tile[(i - 1) & 1][0][0];
-        switch (mw) {
-          case 0: gram256_block<0, KT256 / 2>(t, lane, acc); break;
-          case 1: gram256_block<1, KT256 / 2>(t, lane, acc); break;
-          case 2: gram256_block<2, KT256 / 2>(t, lane, acc); break;
-          default: gram256_block<3, KT256 / 2>(t, lane, acc); break;
-        }
-      }
-      __syncthreads();
-    }
-    switch (mw) {
-      case 0: gram256_flush<0>(a.scratch, a.width, lane, acc); break;
-      case 1: gram256_flush<1>(a.scratch, a.width, lane, acc); break;
-      case 2: gram256_flush<2>(a.scratch, a.width, lane, acc); break;
-      default: gram256_flush<3>(a.scratch, a.width, lane, acc); break;
+    // each role runs its own complete block loop so the 144 accumulator registers stay put
+    if (a.debug == 6) __builtin_amdgcn_s_setprio(3);
+    switch (wave - 4) {
+      case 0: mfma_wave<0>(a, &tile[0][0][0], nb, lane); break;
+      case 1: mfma_wave<1>(a, &tile[0][0][0], nb, lane); break;
+      case 2: mfma_wave<2>(a, &tile[0][0][0], nb, lane); break;
+      default: mfma_wave<3>(a, &tile[0][0][0], nb, lane); break;
     }
   }
 }
 
 }  // namespace
 
-int launch_spmm_gram256(const FusedArgs& a, hipStream_t s) {
+int launch_spmm_gram256(const FusedArgs& a_in, hipStream_t s) {
+  FusedArgs a = a_in;
+  if (const char* dbg = getenv("LGNN_FUSED_DEBUG")) a.debug = atoi(dbg);
+  LGNN_REQUIRE(a.nrows * a.in_ld * 4 < (int64_t(1) << 32) - 4096, "plane too large for 32-bit buffer offsets");
   const int64_t nblocks = cdiv(a.nrows, KT256) * a.nplanes;
   const unsigned grid = unsigned(std::min<int64_t>(nblocks, 256));  // one persistent workgroup per CU
   hipLaunchKernelGGL(spmm_gram256_kernel, dim3(grid), dim3(512), 0, s, a);

@@ -40,18 +40,36 @@ template <int W> __device__ __forceinline__ constexpr bool tiles256_uses(int b) 
   return false;
 }
 
-// acc += tile^T tile for a [rows x 256] LDS tile (row stride 256 floats), rows = 2 * ksteps
+// acc += tile^T tile for a [rows x 256] LDS tile (row stride 256 floats), rows = 2 * ksteps.
+// The operands of k-step kk+1 are read from LDS before the 9 MFMAs of k-step kk are issued, so the
+// LDS latency hides behind 576 cycles of matrix work instead of stalling every k-step.
+template <int W>
+__device__ __forceinline__ void gram256_load(const float* __restrict__ p, float (&x)[8]) {
+#pragma unroll
+  for (int b = 0; b < 8; ++b) x[b] = tiles256_uses<W>(b) ? p[b * 32] : 0.f;
+}
+template <int W>
+__device__ __forceinline__ void gram256_mfma9(const float (&x)[8], f32x16 (&acc)[9]) {
+#pragma unroll
+  for (int s = 0; s < 9; ++s)
+    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[Tiles256<W>::si[s]], x[Tiles256<W>::sj[s]], acc[s], 0, 0, 0);
+}
 template <int W, int KSTEPS>
 __device__ __forceinline__ void gram256_block(const float* __restrict__ tile, int lane, f32x16 (&acc)[9]) {
+  static_assert(KSTEPS % 2 == 0, "k-steps are processed in pairs");
   const float* __restrict__ base = tile + (lane >> 5) * 256 + (lane & 31);
-#pragma unroll 4
-  for (int kk = 0; kk < KSTEPS; ++kk) {
-    float x[8];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) x[b] = tiles256_uses<W>(b) ? base[kk * 512 + b * 32] : 0.f;
-#pragma unroll
-    for (int s = 0; s < 9; ++s)
-      acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[Tiles256<W>::si[s]], x[Tiles256<W>::sj[s]], acc[s], 0, 0, 0);
+  float xa[8], xb[8];
+  gram256_load<W>(base, xa);
+#pragma unroll 2
+  for (int kk = 0; kk < KSTEPS; kk += 2) {
+    gram256_load<W>(base + (kk + 1) * 512, xb);
+    __builtin_amdgcn_sched_barrier(0);
+    gram256_mfma9<W>(xa, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kk + 2 < KSTEPS) gram256_load<W>(base + (kk + 2) * 512, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    gram256_mfma9<W>(xb, acc);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -177,6 +177,15 @@ int keys_to_csr(const uint64_t* keys, int64_t nnz, int64_t N, DevBuf& rowptr, De
 
 }  // namespace
 
+int compact_flags(const uint8_t* flags, int64_t n, int32_t* out, int32_t* count_dev, DevBuf& tmp, hipStream_t s) {
+  rocprim::counting_iterator<int32_t> ids(0);
+  size_t bytes = 0;
+  LGNN_HIP_CHECK(rocprim::select(nullptr, bytes, ids, flags, out, count_dev, size_t(n), s));
+  LGNN_CALL(tmp.reserve(bytes));
+  LGNN_HIP_CHECK(rocprim::select(tmp.p, bytes, ids, flags, out, count_dev, size_t(n), s));
+  return 0;
+}
+
 int graph_build(lgnn_ctx* h, const int64_t* ei, int64_t E, hipStream_t s) {
   const int64_t N = h->N;
   LGNN_REQUIRE(N > 0 && N < (int64_t(1) << 31) - 64, "num_nodes out of range");

@@ -295,7 +295,13 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
                          h->ws.pos.as<int32_t>(), h->ws.val_act.as<float>());
       LGNN_HIP_CHECK(hipGetLastError());
       val_top = h->ws.val_act.as<float>();
-      if (gcn) row_active = h->ws.active.as<uint8_t>();
+      if (gcn) {
+        row_active = h->ws.active.as<uint8_t>();
+        LGNN_CALL(h->ws.act_list.reserve(size_t(N) * 4));
+        LGNN_CALL(h->ws.act_count.reserve(64));
+        LGNN_CALL(compact_flags(row_active, N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(),
+                                h->ws.select_tmp, s));
+      }
     }
     int64_t maxw = 0;
     for (int l = 0; l < L - 1; ++l) maxw = std::max(maxw, h->in_dim[l + 1]);  // GEMM output width of layer l+1
@@ -321,7 +327,16 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           const bool top_level = l == L - 1;
           const bool fuse_here = !no_fuse && fused_supported(d, d, N * d, ping);
           if (top_level && fuse_here) ep.row_active = row_active;  // inactive rows are never read below
-          LGNN_CALL(launch_gemm(g, dout, h->W[l], d, ping, d, cc * N, dout, d, ep, s));
+          if (top_level && fuse_here && row_active && backgemm_supported(dout, d)) {
+            BackGemmArgs bg{};
+            bg.G = g; bg.W = h->W[l]; bg.ldw = d; bg.U = ping; bg.N = N; bg.K = dout; bg.Nout = d; bg.planes = cc;
+            bg.rows = h->ws.act_list.as<int32_t>(); bg.na_dev = h->ws.act_count.as<int32_t>();
+            if (h->act == LGNN_ACT_RELU) { bg.mask_bits = h->fc.mask_bits[l - 1].as<uint32_t>(); bg.mask_words = cdiv(d, 32); }
+            else { bg.hact = ep.hact; bg.hact_ld = ep.hact_ld; bg.act = h->act; }
+            LGNN_CALL(launch_backgemm(bg, s));
+          } else {
+            LGNN_CALL(launch_gemm(g, dout, h->W[l], d, ping, d, cc * N, dout, d, ep, s));
+          }
           FusedArgs a{};
           a.rowptr = h->PT.rowptr; a.col = h->PT.col; a.val = (top_level && fuse_here) ? val_top : h->PT.val;
           a.nrows = N; a.nplanes = cc;

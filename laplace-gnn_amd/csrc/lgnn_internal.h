@@ -71,6 +71,7 @@ struct ForwardCache {
   DevBuf gram_raw[kMaxLayers];       // [in_l, in_l] raw in^T in (upper sub-tiles valid)
   DevBuf prop_in[kMaxLayers];        // P @ lin_in[l]  [N, in_l]   (diag / last layer; GCN)
   DevBuf rowsum;                     // rowsum(P) [N]
+  DevBuf mask_bits[kMaxLayers];      // ReLU: bit j of word w of node n = (h_{l+1}[n][32w+j] > 0)
 };
 
 struct Workspace {
@@ -84,6 +85,9 @@ struct Workspace {
   DevBuf top;    // top-layer gradient planes [C][N][C]
   DevBuf active;   // uint8 [N]: node has a non-zero top-layer gradient row
   DevBuf val_act;  // fp32 [nnz]: P^T values with inactive source columns zeroed
+  DevBuf act_list; // int32 [N]: sorted ids of the active nodes; act_count: their number (device int32)
+  DevBuf act_count;
+  DevBuf select_tmp;
   DevBuf flags;  // 64 B of asynchronous error flags
 };
 
@@ -152,7 +156,26 @@ struct FusedArgs {
   const float* hact; int64_t hact_ld; int act;                    // optional
   int64_t width;     // D <= DT
   float* scratch;    // [D, D]
+  int debug;         // dev experiments: 1 = skip MFMAs, 2 = skip gathers
 };
+
+struct BackGemmArgs {
+  const float* G;   // planes [P][N][K]
+  const float* W;   // [K][ldw] row major, Nout columns used
+  int64_t ldw;
+  float* U;         // planes [P][N][Nout]
+  int64_t N, K, Nout;
+  int64_t planes;
+  const int32_t* rows;      // optional sorted list of active nodes (null: all N)
+  const int32_t* na_dev;    // device count of `rows`
+  const uint32_t* mask_bits; int64_t mask_words;  // ReLU mask bits of h (or null)
+  const float* hact; int64_t hact_ld; int act;    // float activations otherwise
+};
+bool backgemm_supported(int64_t K, int64_t Nout);
+int launch_backgemm(const BackGemmArgs& g, hipStream_t s);
+int launch_relu_mask_bits(const float* h, int64_t ld, int64_t N, int64_t H, uint32_t* bits, hipStream_t s);
+// out[0:count) = sorted indices i with flags[i] != 0; *count_dev = count   (graph.hip, rocPRIM select)
+int compact_flags(const uint8_t* flags, int64_t n, int32_t* out, int32_t* count_dev, DevBuf& tmp, hipStream_t s);
 
 // ---- graph.hip -----------------------------------------------------------------------
 int graph_build(lgnn_ctx* h, const int64_t* edge_index, int64_t E, hipStream_t s);

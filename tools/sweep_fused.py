@@ -28,5 +28,6 @@ def run(N, deg=6.9, F=128, H=256, C=40, M=10000):
           f"{nnz*H*4/per_plane/1e9:7.2f} TB/s (all entries)  ", flush=True)
     eng.close()
 
-for N in (20000, 40000, 80000, 169343, 340000):
+sizes = [int(a) for a in sys.argv[1:]] or [20000, 40000, 80000, 169343, 340000]
+for N in sizes:
     run(N)
