@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void backgemm_kernel(BackGemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
       const float* __restrict__ brow = Bs + lhi * NP + pass * NTW * 32 + l31;
-      for (int kk = 0; kk < K2 / 2; ++kk) {
+      for (int kk = 0; kk < (g.debug == 2 ? 1 : K2 / 2); ++kk) {
         const float av = arow[2 * kk];
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void backgemm_kernel(BackGemmArgs g) {
             float v = acc[n][r];
             if (g.mask_bits) v = ((mw[rr][n] >> l31) & 1u) ? v : 0.f;
             else if (g.hact) v *= act_deriv_from_out(hv[rr][n], g.act);
-            if (col < g.Nout) urow[col] = v;
+            if (col < g.Nout && g.debug != 1) urow[col] = v;
           }
         }
       }
@@ -192,7 +192,11 @@ bool backgemm_supported(int64_t K, int64_t Nout) {
   return (size_t(K2) * nt * 32 + size_t(BGM) * KP + BGM) * 4 <= 64 * 1024;
 }
 
-int launch_backgemm(const BackGemmArgs& g, hipStream_t s) {
+int launch_backgemm(const BackGemmArgs& g_in, hipStream_t s) {
+  BackGemmArgs g = g_in;
+#ifdef LGNN_DEV  // make DEV=1: ablation switches for tools/time_kernels.py
+  if (const char* dbg = getenv("LGNN_BACKGEMM_DEBUG")) g.debug = atoi(dbg);
+#endif
   if (g.planes <= 0 || g.N <= 0) return 0;
   LGNN_REQUIRE(backgemm_supported(g.K, g.Nout), "backgemm shape not supported");
   const int nt = g.Nout <= 32 ? 1 : (g.Nout <= 64 ? 2 : (g.Nout <= 128 ? 4 : 8));

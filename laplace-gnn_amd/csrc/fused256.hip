@@ -139,7 +139,6 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
 
   if (wave < 4) {
     // ------------------------------------------------ gather waves
-    if (a.debug == 5) __builtin_amdgcn_s_setprio(2);
     const int c0 = lane * 4;
     const bool col_ok = c0 < a.width;  // width % 4 == 0 (launcher)
     const int voff = (col_ok ? c0 : 0) * 4;            // this lane's 16 bytes inside a neighbour row
@@ -237,7 +236,6 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
   } else {
     // ------------------------------------------------ MFMA waves
     // each role runs its own complete block loop so the 144 accumulator registers stay put
-    if (a.debug == 6) __builtin_amdgcn_s_setprio(3);
     switch (wave - 4) {
       case 0: mfma_wave<0>(a, &tile[0][0][0], nb, lane); break;
       case 1: mfma_wave<1>(a, &tile[0][0][0], nb, lane); break;
@@ -251,7 +249,9 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
 
 int launch_spmm_gram256(const FusedArgs& a_in, hipStream_t s) {
   FusedArgs a = a_in;
+#ifdef LGNN_DEV  // make DEV=1: ablation switches for tools/sweep_fused.py (1 no MFMA, 2 no gather, 4 no barriers)
   if (const char* dbg = getenv("LGNN_FUSED_DEBUG")) a.debug = atoi(dbg);
+#endif
   LGNN_REQUIRE(a.nrows * a.in_ld * 4 < (int64_t(1) << 32) - 4096, "plane too large for 32-bit buffer offsets");
   const int64_t nblocks = cdiv(a.nrows, KT256) * a.nplanes;
   const unsigned grid = unsigned(std::min<int64_t>(nblocks, 256));  // one persistent workgroup per CU

@@ -65,10 +65,17 @@ class Kron:
 
     def decompose(self, damping: bool = False) -> "KronDecomposed":
         eigvecs, eigvals = [], []
+        prev = None  # (factor, eigenvalues, eigenvectors) of the previous block's first factor
         for F in self.kfacs:
             Qs, ls = [], []
-            for Hi in F:
-                lam, Q = symeig(Hi)
+            for k, Hi in enumerate(F):
+                # a bias block repeats the B factor of its weight block (curvlinops.py:64-66): decompose once
+                if k == 0 and prev is not None and prev[0].shape == Hi.shape and torch.equal(prev[0], Hi):
+                    lam, Q = prev[1], prev[2]
+                else:
+                    lam, Q = symeig(Hi)
+                if k == 0:
+                    prev = (Hi, lam, Q)
                 Qs.append(Q)
                 ls.append(lam)
             eigvecs.append(Qs)
