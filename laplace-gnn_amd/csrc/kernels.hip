@@ -149,6 +149,7 @@ struct GemmArgs {
   int out_act;
   int vecA, vecB;
   const uint8_t* row_active;  // optional, indexed like hact rows: inactive rows are not written
+  int64_t k_chunk;            // split-K: blockIdx.z covers [z*k_chunk, (z+1)*k_chunk); 0 = whole K
 };
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
@@ -167,8 +168,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  for (int64_t k0 = 0; k0 < g.K; k0 += GBK) {
-    const int kvalid = int(min(int64_t(GBK), g.K - k0));
+  const int64_t k_begin = g.k_chunk > 0 ? int64_t(blockIdx.z) * g.k_chunk : 0;
+  const int64_t k_end = g.k_chunk > 0 ? min(g.K, k_begin + g.k_chunk) : g.K;
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += GBK) {
+    const int kvalid = int(min(int64_t(GBK), k_end - k0));
     // A tile: 128 rows x 32 k ; thread -> (row = tid/8 + 32*it, k4 = (tid%8)*4)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int n = 0; n < 2; ++n) {
       const int64_t col = col0 + wc * 64 + n * 32 + l31;
       if (col >= g.Nout) continue;
-      const float bias = g.bias ? g.bias[col] : 0.f;
+      const float bias = (g.bias && (g.k_chunk == 0 || blockIdx.z == 0)) ? g.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int lr = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -246,7 +249,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         float v = acc[m][n][r] + bias;
         if (g.hact) v *= act_deriv_from_out(g.hact[hr * g.hact_ld + col], g.act);
         if (g.out_act >= 0) v = act_apply(v, g.out_act);
-        g.C[row * g.ldc + col] = v;
+        if (g.k_chunk > 0) atomicAdd(&g.C[row * g.ldc + col], v);
+        else g.C[row * g.ldc + col] = v;
       }
     }
   }
@@ -417,7 +421,21 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float*
       }
     }
   }
-  const dim3 grid{unsigned(cdiv(R, GBM)), unsigned(cdiv(Nout, GBN)), 1u};
+  // few output tiles but a long K (Cora-shaped X W^T: 22 tiles, K = 1433): split K over blockIdx.z and
+  // combine with float atomics.  Only for linear epilogues (bias is added by slice 0).
+  const int64_t tiles = cdiv(R, GBM) * cdiv(Nout, GBN);
+  unsigned splitk = 1;
+  if (tiles < 128 && K >= 256 && ep.hact == nullptr && ep.out_act < 0 && ep.row_active == nullptr && C != nullptr) {
+    const int64_t want = std::min<int64_t>(cdiv(256, tiles), cdiv(K, 64));
+    g.k_chunk = cdiv(cdiv(K, want), GBK) * GBK;
+    splitk = unsigned(cdiv(K, g.k_chunk));
+    if (splitk <= 1) { g.k_chunk = 0; splitk = 1; }
+    else {
+      if (ldc == Nout) LGNN_HIP_CHECK(hipMemsetAsync(C, 0, size_t(R) * Nout * 4, s));
+      else LGNN_HIP_CHECK(hipMemset2DAsync(C, size_t(ldc) * 4, 0, size_t(Nout) * 4, size_t(R), s));
+    }
+  }
+  const dim3 grid{unsigned(cdiv(R, GBM)), unsigned(cdiv(Nout, GBN)), splitk};
   hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, g);
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
