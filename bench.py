@@ -152,9 +152,20 @@ def main():
         if launches > 0 and kern_ms > 0:
             avg_ms = kern_ms / launches
             ach = flops_plane * planes / (kern_ms * 1e-3) / 1e12
+            # HBM-side bytes per launch come from a separate rocprofv3 --pmc pass of this same command
+            # (counters cannot be collected inside the timed run); the committed summary is quoted when
+            # it matches this workload, otherwise null.
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01_d_pmc_fused.json")
+            if args.workload == "arxiv" and structure == "kron" and os.path.exists(pmc):
+                with open(pmc) as fh:
+                    pj = json.load(fh)
+                traffic = pj["traffic_bytes_per_launch"] * (planes / launches) / pj["planes_per_launch"]
+                traffic_src = "profiles/r01_d_pmc_fused.json ((2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction)"
             roofline = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": bytes_plane * planes / launches,
                 "kernel": "spmm_gram256_kernel", "launches": launches, "avg_launch_ms": avg_ms,
                 "planes_per_launch": planes / launches,
                 "algorithmic_GBps": bytes_plane * planes / (kern_ms * 1e-3) / 1e9,

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256, 2) void backgemm_kernel(BackGemmArgs g) {
   float* __restrict__ Bs = smem;
   float* __restrict__ As = smem + K2 * NP;
   int32_t* __restrict__ nodes = reinterpret_cast<int32_t*>(As + BGM * KP);  // node id of every tile row
+  uint32_t* __restrict__ mask_s = reinterpret_cast<uint32_t*>(nodes + BGM);   // [BGM][8] ReLU mask words of the tile rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   for (int f = tid; f < K2 * NP; f += 256) {
@@ -52,10 +53,24 @@ __global__ __launch_bounds__(256, 2) void backgemm_kernel(BackGemmArgs g) {
     t0 = (tile - plane * tiles_per_plane) * BGM;
   };
   auto node_of = [&](int64_t t) -> int64_t { return g.rows ? int64_t(g.rows[t]) : t; };
+  uint4 mstage = make_uint4(~0u, ~0u, ~0u, ~0u);  // mask words (row tid>>1, half tid&1) of the prefetched tile
   auto load_tile = [&](int64_t tile) {
     int64_t plane, t0;
     tile_coords(tile, plane, t0);
     const float* __restrict__ base = g.G + plane * g.N * g.K;
+    if (g.mask_bits) {
+      // the mask words ride along with the tile prefetch and are parked in LDS: the epilogue then
+      // needs no global load at all (a dependent load per row group used to stall it 8 times per tile)
+      const int mr = tid >> 1, mh = (tid & 1) * 4;
+      mstage = make_uint4(~0u, ~0u, ~0u, ~0u);
+      if (t0 + mr < na) {
+        const uint32_t* __restrict__ mp = g.mask_bits + node_of(t0 + mr) * g.mask_words;
+        if (mh + 0 < g.mask_words) mstage.x = mp[mh + 0];
+        if (mh + 1 < g.mask_words) mstage.y = mp[mh + 1];
+        if (mh + 2 < g.mask_words) mstage.z = mp[mh + 2];
+        if (mh + 3 < g.mask_words) mstage.w = mp[mh + 3];
+      }
+    }
     int r = r_first, k = k_first;
 #pragma unroll
     for (int e = 0; e < MAXV; ++e) {
@@ -85,6 +100,7 @@ __global__ __launch_bounds__(256, 2) void backgemm_kernel(BackGemmArgs g) {
       if (k >= K) { k -= K; r += 1; }
     }
     if (tid < BGM) nodes[tid] = t0 + tid < na ? int32_t(node_of(t0 + tid)) : -1;
+    if (g.mask_bits) *reinterpret_cast<uint4*>(mask_s + (tid >> 1) * 8 + (tid & 1) * 4) = mstage;
   };
 
   int64_t tile = blockIdx.x;
@@ -130,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void backgemm_kernel(BackGemmArgs g) {
             hv[rr][n] = 1.f;
             const int col = colb + n * 32;
             if (g.mask_bits) {
-              if (live) mw[rr][n] = g.mask_bits[int64_t(nd[r]) * g.mask_words + pass * NTW + n];
+              mw[rr][n] = mask_s[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * 8 + pass * NTW + n];
             } else if (g.hact) {
               if (live && col < g.Nout) hv[rr][n] = g.hact[int64_t(nd[r]) * g.hact_ld + col];
             }
@@ -160,6 +176,14 @@ template <int NT>
 int backgemm_launch(const BackGemmArgs& g, size_t smem, bool vec, hipStream_t s) {
   const int64_t worst = cdiv(g.N, BGM) * g.planes;
   const unsigned grid = unsigned(std::min<int64_t>(worst, 512));
+  static bool attr_set = false;  // more than 64 KiB of dynamic LDS needs an explicit opt-in
+  if (!attr_set) {
+    LGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&backgemm_kernel<NT, 4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    LGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&backgemm_kernel<NT, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_set = true;
+  }
   if (vec) hipLaunchKernelGGL((backgemm_kernel<NT, 4>), dim3(grid), dim3(256), smem, s, g);
   else hipLaunchKernelGGL((backgemm_kernel<NT, 1>), dim3(grid), dim3(256), smem, s, g);
   LGNN_HIP_CHECK(hipGetLastError());
@@ -189,7 +213,7 @@ bool backgemm_supported(int64_t K, int64_t Nout) {
   if (K < 1 || K > 64 || Nout < 1 || Nout > 256) return false;
   const int nt = Nout <= 32 ? 1 : (Nout <= 64 ? 2 : (Nout <= 128 ? 4 : 8));
   const int K2 = int((K + 1) & ~int64_t(1)), KP = K2 | 1;
-  return (size_t(K2) * nt * 32 + size_t(BGM) * KP + BGM) * 4 <= 64 * 1024;
+  return (size_t(K2) * nt * 32 + size_t(BGM) * KP + BGM + BGM * 8) * 4 <= 64 * 1024 + 8 * 1024;
 }
 
 int launch_backgemm(const BackGemmArgs& g_in, hipStream_t s) {
@@ -201,7 +225,7 @@ int launch_backgemm(const BackGemmArgs& g_in, hipStream_t s) {
   LGNN_REQUIRE(backgemm_supported(g.K, g.Nout), "backgemm shape not supported");
   const int nt = g.Nout <= 32 ? 1 : (g.Nout <= 64 ? 2 : (g.Nout <= 128 ? 4 : 8));
   const int K2 = int((g.K + 1) & ~int64_t(1)), KP = K2 | 1;
-  const size_t smem = (size_t(K2) * nt * 32 + size_t(BGM) * KP + BGM) * 4;
+  const size_t smem = (size_t(K2) * nt * 32 + size_t(BGM) * KP + BGM + BGM * 8) * 4;
   const bool vec = g.K % 4 == 0 && (reinterpret_cast<uintptr_t>(g.G) & 15) == 0;
   switch (nt) {
     case 1: return backgemm_launch<1>(g, smem, vec, s);
