@@ -125,6 +125,15 @@ LGNN_API int lgnn_kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y
                          float* const* B_out /* host array of L device ptrs */, float* loss_out,
                          void* stream);
 
+/* The same for the class columns [class_begin, class_end) only.  B_l is a sum over the C class columns of
+ * the Hessian square root (one reference backward pass each, curvlinops/kfac.py:653-661), so class ranges
+ * are exact additive shares of a batch: a data-parallel caller can balance (batch, class-range) units over
+ * ranks without ever splitting a batch's samples.  The share that contains class 0 also adds the loss and
+ * the A increment (once per batch).                                                                  */
+LGNN_API int lgnn_kfac_accumulate_classes(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train,
+                                 uint32_t flags, int64_t class_begin, int64_t class_end,
+                                 float* const* A_out, float* const* B_out, float* loss_out, void* stream);
+
 /* ---- diagonal GGN of one mini-batch ----------------------------------------------------------
  * Replaces GGNInterface.diag (laplace/curvature/curvature.py:412-432 with jacobians :89-130 and
  * _get_functional_hessian :365-372):  diag_out[P] += einsum('bcp,bck,bkp->p', J, Lambda, J),

@@ -7,7 +7,7 @@ backend class and the thin ``Laplace`` front that drives it.
 """
 from . import _lib  # noqa: F401
 from .curvature import HipCurvatureInterface, HipGGN  # noqa: F401
-from .data import TensorBatchLoader, batches_of_rank  # noqa: F401
+from .data import TensorBatchLoader, batches_of_rank, units_of_rank  # noqa: F401
 from .engine import GraphEngine  # noqa: F401
 from .laplace import (BaseLaplace, DiagLaplace, FullLLLaplace, KronLaplace, Laplace,  # noqa: F401
                       ParametricLaplace, all_reduce_flat_)
@@ -16,4 +16,4 @@ from .models import GCN, GraphSAGE  # noqa: F401
 
 __all__ = ["GraphEngine", "HipGGN", "HipCurvatureInterface", "Laplace", "BaseLaplace", "ParametricLaplace",
            "KronLaplace", "DiagLaplace", "FullLLLaplace", "Kron", "KronDecomposed", "symeig", "GCN", "GraphSAGE",
-           "TensorBatchLoader", "batches_of_rank", "all_reduce_flat_"]
+           "TensorBatchLoader", "batches_of_rank", "units_of_rank", "all_reduce_flat_"]

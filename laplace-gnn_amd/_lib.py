@@ -36,6 +36,7 @@ SIGNATURES = {
     "lgnn_forward": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "lgnn_forward_all": (_i32, [_vp, _vp, _vp]),
     "lgnn_kfac_accumulate": (_i32, [_vp, _vp, _vp, _i64, _i64, _u32, _pp, _pp, _vp, _vp]),
+    "lgnn_kfac_accumulate_classes": (_i32, [_vp, _vp, _vp, _i64, _i64, _u32, _i64, _i64, _pp, _pp, _vp, _vp]),
     "lgnn_diag_accumulate": (_i32, [_vp, _vp, _vp, _i64, _u32, _vp, _vp, _vp]),
     "lgnn_lastlayer_full_accumulate": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "lgnn_enable_kernel_timing": (_i32, [_vp, _i32]),

@@ -293,7 +293,17 @@ extern "C" int lgnn_kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void*
                                     uint32_t flags, float* const* A_out, float* const* B_out, float* loss_out,
                                     void* stream) {
   if (!h) { set_error("null context"); return 2; }
-  return kfac_accumulate(h, idx, y, M, n_train, flags, A_out, B_out, loss_out, static_cast<hipStream_t>(stream));
+  LGNN_REQUIRE(h->L > 0, "no model bound");
+  return kfac_accumulate(h, idx, y, M, n_train, flags, 0, h->dims[h->L], A_out, B_out, loss_out,
+                         static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lgnn_kfac_accumulate_classes(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train,
+                                            uint32_t flags, int64_t class_begin, int64_t class_end,
+                                            float* const* A_out, float* const* B_out, float* loss_out, void* stream) {
+  if (!h) { set_error("null context"); return 2; }
+  return kfac_accumulate(h, idx, y, M, n_train, flags, class_begin, class_end, A_out, B_out, loss_out,
+                         static_cast<hipStream_t>(stream));
 }
 
 extern "C" int lgnn_diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags,

@@ -111,13 +111,14 @@ __global__ __launch_bounds__(64) void seed_kernel(const float* __restrict__ logi
 __global__ void seed_spmm_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                  const float* __restrict__ val, int64_t N, int64_t C,
                                  const int32_t* __restrict__ pos, const float* __restrict__ seeds,
-                                 float* __restrict__ g, uint8_t* __restrict__ active) {
+                                 float* __restrict__ g, uint8_t* __restrict__ active, int64_t cb, int64_t ce) {
   extern __shared__ float sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n = int64_t(blockIdx.x) * (blockDim.x >> 6) + wave;
   if (n >= N) return;
   const int64_t CC = C * C;
-  float* buf = sm + int64_t(wave) * CC;
+  const int64_t q0 = cb * C, nq = (ce - cb) * C;  // only the class planes [cb, ce) are built
+  float* buf = sm + int64_t(wave) * nq;
   bool any = false;
   const int32_t s = rowptr[n], e = rowptr[n + 1];
   for (int32_t base = s; base < e; base += 64) {
@@ -133,16 +134,16 @@ __global__ void seed_spmm_kernel(const int32_t* __restrict__ rowptr, const int32
       const float vv = __shfl(v, b);
       const float* __restrict__ src = seeds + mm * CC;
       if (!any) {
-        for (int64_t q = lane; q < CC; q += 64) buf[q] = vv * src[q];
+        for (int64_t q = lane; q < nq; q += 64) buf[q] = vv * src[q0 + q];
         any = true;
       } else {
-        for (int64_t q = lane; q < CC; q += 64) buf[q] += vv * src[q];
+        for (int64_t q = lane; q < nq; q += 64) buf[q] += vv * src[q0 + q];
       }
     }
   }
   // each lane re-reads only what it wrote itself (q = lane mod 64): no barrier needed
-  for (int64_t q = lane; q < CC; q += 64) {
-    const int64_t c = q / C, k = q - c * C;
+  for (int64_t q = lane; q < nq; q += 64) {
+    const int64_t c = (q0 + q) / C, k = (q0 + q) - c * C;
     g[(c * N + n) * C + k] = any ? buf[q] : 0.f;
   }
   if (lane == 0) active[n] = any ? 1 : 0;
@@ -164,12 +165,12 @@ __global__ void mask_values_kernel(const int32_t* __restrict__ col, const float*
 // scattered seed itself: G[c][idx[m]][k] = seeds[m][c][k] for first occurrences (planes pre-zeroed).
 __global__ void scatter_seed_planes_kernel(const int64_t* __restrict__ idx, int64_t M, int64_t N, int64_t C,
                                            const int32_t* __restrict__ pos, const float* __restrict__ seeds,
-                                           float* __restrict__ g) {
+                                           float* __restrict__ g, int64_t cb, int64_t ce) {
   const int64_t m = blockIdx.x;
   const int64_t n = idx[m];
   if (n < 0 || n >= N || pos[n] != m) return;
   const int64_t CC = C * C;
-  for (int64_t q = threadIdx.x; q < CC; q += blockDim.x) {
+  for (int64_t q = cb * C + threadIdx.x; q < ce * C; q += blockDim.x) {
     const int64_t c = q / C, k = q - c * C;
     g[(c * N + n) * C + k] = seeds[m * CC + q];
   }
@@ -230,8 +231,14 @@ int batch_check_flag(lgnn_ctx* h, hipStream_t s) {
 }
 
 int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train, uint32_t flags,
-                    float* const* A_out, float* const* B_out, float* loss_out, hipStream_t s) {
+                    int64_t cb, int64_t ce, float* const* A_out, float* const* B_out, float* loss_out, hipStream_t s) {
   LGNN_REQUIRE(M > 0 && idx && y, "empty batch or null batch pointers");
+  LGNN_REQUIRE(h->L > 0, "no model bound");
+  LGNN_REQUIRE(cb >= 0 && cb < ce && ce <= h->dims[h->L], "class range must satisfy 0 <= begin < end <= C");
+  // B_l = sum over class columns c of g_c^T g_c: a class range is an exact additive share of the batch.
+  // The share that contains class 0 also carries what exists once per batch: the loss and the A increment
+  // (and, for GraphSAGE, the whole top-layer Gram, which is only M*C rows).
+  const bool first = cb == 0;
   LGNN_REQUIRE(n_train > 0, "n_train must be positive");
   LGNN_REQUIRE(A_out && B_out && loss_out, "null output pointers");
   LGNN_CALL(forward_ensure_grams(h, s));
@@ -242,10 +249,10 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   const bool no_fuse = (flags & LGNN_FLAG_NO_FUSE) != 0;
   LGNN_REQUIRE(M < INT32_MAX, "batch too large");
 
-  LGNN_CALL(batch_prologue(h, idx, y, M, true, (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0, loss_out, s));
+  LGNN_CALL(batch_prologue(h, idx, y, M, true, (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0, first ? loss_out : nullptr, s));
 
   // A_l += in_l^T in_l / n_train   (kfac.py:870 divides by M, curvlinops.py:46-53 multiplies by M/N)
-  for (int l = 0; l < L; ++l)
+  for (int l = 0; first && l < L; ++l)
     LGNN_CALL(launch_sym_accumulate(h->fc.gram_raw[l].as<float>(), h->in_dim[l], 1.0f / float(n_train), A_out[l], s));
 
   for (int l = 0; l < L; ++l) {
@@ -262,20 +269,21 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   }
   LGNN_CALL(h->ws.active.reserve(size_t(N)));
   if (h->kind == LGNN_KIND_GCN) {
-    int waves = int(std::max<int64_t>(1, std::min<int64_t>(4, (48 * 1024) / (CC * 4))));
-    LGNN_REQUIRE(CC * 4 <= 150 * 1024, "too many classes for the seed SpMM kernel");
-    hipLaunchKernelGGL(seed_spmm_kernel, dim3(unsigned(cdiv(N, waves))), dim3(64 * waves), size_t(waves) * CC * 4, s,
+    const int64_t nq = (ce - cb) * C;
+    int waves = int(std::max<int64_t>(1, std::min<int64_t>(4, (48 * 1024) / (nq * 4))));
+    LGNN_REQUIRE(nq * 4 <= 60 * 1024, "too many classes for the seed SpMM kernel (use class ranges)");
+    hipLaunchKernelGGL(seed_spmm_kernel, dim3(unsigned(cdiv(N, waves))), dim3(64 * waves), size_t(waves) * nq * 4, s,
                        h->PT.rowptr, h->PT.col, h->PT.val, N, C, h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), gtop,
-                       h->ws.active.as<uint8_t>());
+                       h->ws.active.as<uint8_t>(), cb, ce);
     LGNN_HIP_CHECK(hipGetLastError());
-    LGNN_CALL(launch_gram(gtop, C, C * N, C, h->ws.gram_scratch[L - 1].as<float>(), s));
+    LGNN_CALL(launch_gram(gtop + cb * N * C, C, (ce - cb) * N, C, h->ws.gram_scratch[L - 1].as<float>(), s));
   } else {
     // rows (m, c) of the accumulated seeds; rows of non-first duplicates are zero
-    LGNN_CALL(launch_gram(h->ws.seeds.as<float>(), C, M * C, C, h->ws.gram_scratch[L - 1].as<float>(), s));
+    if (first) LGNN_CALL(launch_gram(h->ws.seeds.as<float>(), C, M * C, C, h->ws.gram_scratch[L - 1].as<float>(), s));
     if (L > 1) {
-      LGNN_HIP_CHECK(hipMemsetAsync(gtop, 0, size_t(N) * CC * 4, s));
+      LGNN_HIP_CHECK(hipMemsetAsync(gtop + cb * N * C, 0, size_t(N) * (ce - cb) * C * 4, s));
       hipLaunchKernelGGL(scatter_seed_planes_kernel, dim3(unsigned(M)), dim3(256), 0, s, idx, M, N, C,
-                         h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), gtop);
+                         h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), gtop, cb, ce);
       LGNN_HIP_CHECK(hipGetLastError());
     }
   }
@@ -309,8 +317,8 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
     int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(C, h->ws_limit / std::max<int64_t>(per_class, 1)));
     LGNN_CALL(h->ws.planes_a.reserve(size_t(cc_max) * N * maxw * 4));
     LGNN_CALL(h->ws.planes_b.reserve(size_t(cc_max) * N * maxw * 4));
-    for (int64_t c0 = 0; c0 < C; c0 += cc_max) {
-      const int64_t cc = std::min(cc_max, C - c0);
+    for (int64_t c0 = cb; c0 < ce; c0 += cc_max) {
+      const int64_t cc = std::min(cc_max, ce - c0);
       const float* g = gtop + c0 * N * C;  // planes [cc][N][dims[l+1]] of layer l
       float* ping = h->ws.planes_a.as<float>();
       float* pong = h->ws.planes_b.as<float>();

@@ -221,7 +221,7 @@ int launch_gather_rows(const float* in, int64_t ld, const int64_t* idx, int64_t 
 
 // ---- kfac.hip ---------------------------------------------------------------------------
 int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train, uint32_t flags,
-                    float* const* A_out, float* const* B_out, float* loss_out, hipStream_t s);
+                    int64_t class_begin, int64_t class_end, float* const* A_out, float* const* B_out, float* loss_out, hipStream_t s);
 int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bool want_seeds, bool fork_exact,
                    float* loss_out, hipStream_t s);
 int batch_epilogue(lgnn_ctx* h, const int64_t* idx, int64_t M, hipStream_t s);

@@ -69,9 +69,16 @@ class HipCurvatureInterface:
         return self.model.engine
 
     # ---- kron ----------------------------------------------------------------------------------
-    def kron_accumulate_(self, views, loss_buf, x: torch.Tensor, y: torch.Tensor, N: int, fuse: bool = True):
-        """Add this batch's RAW factors (A_l/N_train, B_l) and loss into caller-owned buffers."""
-        self.engine.kfac_accumulate(x, y, N, views, loss_buf, fork_exact=self.fork_exact_seed, fuse=fuse)
+    @property
+    def num_classes(self) -> int:
+        return self.engine.dims[-1]
+
+    def kron_accumulate_(self, views, loss_buf, x: torch.Tensor, y: torch.Tensor, N: int, fuse: bool = True,
+                         classes: tuple[int, int] | None = None):
+        """Add this batch's RAW factors (A_l/N_train, B_l) and loss into caller-owned buffers; ``classes``
+        restricts the call to a range of class columns (exact additive share, see the C ABI)."""
+        self.engine.kfac_accumulate(x, y, N, views, loss_buf, fork_exact=self.fork_exact_seed, fuse=fuse,
+                                    classes=classes)
 
     def pack_kron(self, views) -> Kron:
         """[[B0, A0], [B0], ...] in parameter order, times ``factor`` distributed like Kron.__mul__

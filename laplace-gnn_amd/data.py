@@ -39,3 +39,21 @@ class TensorBatchLoader:
 def batches_of_rank(num_batches: int, rank: int, world: int) -> list[int]:
     """Batch t belongs to rank t mod world: whole batches only."""
     return [t for t in range(num_batches) if t % world == rank]
+
+
+def units_of_rank(num_batches: int, num_classes: int, rank: int, world: int) -> list[tuple[int, int, int]]:
+    """Finer data-parallel decomposition of a KFAC fit: the work unit is (batch t, class column c) because
+    ``B_l = sum_t sum_c g_{t,c}^T g_{t,c}`` (one reference backward pass per class column,
+    curvlinops/kfac.py:653-661).  The T*C units are dealt in contiguous, equally sized runs; a rank gets
+    ``[(t, class_begin, class_end), ...]`` -- whole batches where its run covers them, class ranges at the
+    seams.  Batches are never split by SAMPLES (cross-sample terms inside a batch)."""
+    total = num_batches * num_classes
+    lo, hi = total * rank // world, total * (rank + 1) // world
+    out = []
+    u = lo
+    while u < hi:
+        t, c = divmod(u, num_classes)
+        ce = min(num_classes, c + (hi - u))
+        out.append((t, c, ce))
+        u += ce - c
+    return out

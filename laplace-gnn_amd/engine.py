@@ -191,16 +191,21 @@ class GraphEngine:
         loss = flat[off:off + 1]
         return flat, views, loss
 
-    def kfac_accumulate(self, idx, y, n_train: int, views, loss, fork_exact: bool = True, fuse: bool = True):
+    def kfac_accumulate(self, idx, y, n_train: int, views, loss, fork_exact: bool = True, fuse: bool = True,
+                        classes: tuple[int, int] | None = None):
+        """Add one batch's factors into the caller-owned buffers.  ``classes=(begin, end)`` restricts the call to
+        that range of class columns (an exact additive share of the batch; the share with class 0 also adds
+        the loss and the A increment)."""
         self._sync_versions()
         idx, y = idx.contiguous(), y.contiguous()
         flags = (_lib.FLAG_FORK_EXACT_SEED if fork_exact else 0) | (0 if fuse else _lib.FLAG_NO_FUSE)
         A = _lib.ptr_array([a.data_ptr() for a, _ in views])
         B = _lib.ptr_array([b.data_ptr() for _, b in views])
-        rc = self.lib.lgnn_kfac_accumulate(
+        cb, ce = (0, self.dims[-1]) if classes is None else (int(classes[0]), int(classes[1]))
+        rc = self.lib.lgnn_kfac_accumulate_classes(
             self._h, _dev_ptr(idx, torch.int64, "idx"), _dev_ptr(y, torch.int64, "y"), idx.shape[0], int(n_train),
-            flags, A, B, loss.data_ptr(), _stream(self.device))
-        _lib.check(rc, "lgnn_kfac_accumulate")
+            flags, cb, ce, A, B, loss.data_ptr(), _stream(self.device))
+        _lib.check(rc, "lgnn_kfac_accumulate_classes")
 
     def diag_accumulate(self, idx, y, diag: torch.Tensor, loss: torch.Tensor):
         self._sync_versions()

@@ -8,11 +8,15 @@ last-layer ``FullLLLaplace`` (laplace/lllaplace.py:369-378 intent).  Attributes 
 ``H``, ``H_facs`` (kron), ``loss``, ``n_data``, ``n_outputs``, ``n_params``, ``mean``,
 ``model.output_size``.
 
-Data parallelism (new; the reference is single process): whole mini-batches are dealt round-robin
-to the ranks of a ``torch.distributed`` process group (batch t -> rank t mod world) and the
-accumulated factors + loss are summed with ONE all-reduce of a flat fp32 buffer (RCCL over xGMI on
-GPUs, gloo in the CPU tests).  Batches are never split: the KFAC B factors have cross-sample terms
-inside a batch, so the reference loader's boundaries are part of the result.
+Data parallelism (new; the reference is single process).  The accumulated factors + loss are summed
+with ONE all-reduce of a flat fp32 buffer (RCCL over xGMI on GPUs, gloo in the CPU tests).  What is
+dealt to the ranks of the ``torch.distributed`` group depends on the structure:
+* kron: a batch's SAMPLES are never split -- the B factors have cross-sample terms inside a batch
+  (SURVEY.md 0.5), so the reference loader's boundaries are part of the result -- but
+  ``B = sum_batches sum_classes g_c^T g_c``, so the unit of work is (batch, class column) and the T*C
+  units are dealt in balanced contiguous runs (``data.units_of_rank``); backends without class-range
+  support get whole batches round-robin (batch t -> rank t mod world);
+* diag / last-layer full: plain sums over samples -> every rank takes its slice of every batch.
 """
 from __future__ import annotations
 
@@ -134,11 +138,19 @@ class ParametricLaplace(BaseLaplace):
         N = len(train_loader.dataset)
         rank, world = _dist_info(process_group)
         loss = torch.zeros((), dtype=torch.float32, device=self._device)
+        plan = self._shard_plan(train_loader, rank, world)
         for t, (X, y) in enumerate(train_loader):
-            if t % world != rank:
-                continue  # whole batches only: batch t belongs to rank t mod world
+            todo = plan(t, X.shape[0])
+            if todo is None:
+                continue
             X, y = X.to(self._device), y.to(self._device)
-            loss_batch, H_batch = self._curv_closure(X, y, N=N)
+            if isinstance(todo, slice):  # sample-additive structures: this rank's slice of the batch
+                X, y = X[todo], y[todo]
+                loss_batch, H_batch = self._curv_closure(X, y, N=N)
+            elif todo is True:  # the whole batch
+                loss_batch, H_batch = self._curv_closure(X, y, N=N)
+            else:  # (class_begin, class_end): an exact additive share of the batch's KFAC factors
+                loss_batch, H_batch = self._curv_closure(X, y, N=N, classes=todo)
             loss = loss + loss_batch
             self._accumulate(H_batch)
         self._finish_accumulate()
@@ -147,6 +159,20 @@ class ParametricLaplace(BaseLaplace):
             self._after_reduce()
         self.loss = self.loss + loss
         self.n_data += N
+
+    # how the work of one fit is dealt to the ranks of the process group
+    _sample_additive = False  # True: H is a plain sum over samples (diag, last-layer full) -> slice batches
+
+    def _shard_plan(self, train_loader, rank: int, world: int):
+        """Returns plan(t, M) -> None (skip) | True (whole batch) | slice (samples) | (c0, c1) (class range)."""
+        if world == 1:
+            return lambda t, M: True
+        if self._sample_additive:
+            def plan(t, M):
+                lo, hi = M * rank // world, M * (rank + 1) // world
+                return slice(lo, hi) if hi > lo else None
+            return plan
+        return lambda t, M: True if t % world == rank else None  # whole batches round-robin
 
     # hooks so that subclasses can keep H in a flat buffer
     def _accumulate(self, H_batch):
@@ -197,15 +223,27 @@ class KronLaplace(ParametricLaplace):
         self.H = Kron.init_from_model(self.params, self._device)
         self._flat = None
 
-    def _curv_closure(self, X, y, N):
+    def _curv_closure(self, X, y, N, classes=None):
         be = self.backend
         if hasattr(be, "kron_accumulate_"):  # in-place fast path of the HIP backend
             if self._flat is None:
-                self._flat = be.engine.new_kfac_buffers()
+                self._flat = be.new_kfac_buffers() if hasattr(be, "new_kfac_buffers") else be.engine.new_kfac_buffers()
             _, views, loss_buf = self._flat
-            be.kron_accumulate_(views, loss_buf, X, y, N)
+            be.kron_accumulate_(views, loss_buf, X, y, N, classes=classes)
             return 0.0, None
         return be.kron(X, y, N=N, **self._asdl_fisher_kwargs)
+
+    def _shard_plan(self, train_loader, rank: int, world: int):
+        """Backends that can restrict a call to a range of class columns get the balanced (batch, class)
+        decomposition of ``data.units_of_rank``; others fall back to whole batches round-robin."""
+        be = self.backend
+        if world == 1 or not (hasattr(be, "kron_accumulate_") and hasattr(be, "num_classes")):
+            return super()._shard_plan(train_loader, rank, world)
+        from .data import units_of_rank
+        mine = {}
+        for t, c0, c1 in units_of_rank(len(train_loader), be.num_classes, rank, world):
+            mine[t] = (c0, c1)
+        return lambda t, M: mine.get(t)
 
     def _accumulate(self, H_batch):
         if H_batch is not None:
@@ -215,8 +253,11 @@ class KronLaplace(ParametricLaplace):
         be = self.backend
         if hasattr(be, "kron_accumulate_"):
             if self._flat is None:  # a rank without local batches still takes part in the all-reduce
-                self._flat = be.engine.new_kfac_buffers()
-            return [self._flat[0]]
+                self._flat = be.new_kfac_buffers() if hasattr(be, "new_kfac_buffers") else be.engine.new_kfac_buffers()
+            flat, views, loss_buf = self._flat
+            if flat is not None:
+                return [flat]  # [A_0|B_0|...|loss] already is one buffer
+            return [t for pair in views for t in pair] + [loss_buf]
         return [Hi for F in self.H.kfacs for Hi in F]
 
     def _fold_flat(self):
@@ -268,6 +309,7 @@ class KronLaplace(ParametricLaplace):
 
 class DiagLaplace(ParametricLaplace):
     _key = ("all", "diag")
+    _sample_additive = True  # einsum('bcp,bck,bkp->p') is a sum over b: batches may be sliced by samples
 
     def _init_H(self):
         self.H = torch.zeros(self.n_params, device=self._device)
@@ -291,6 +333,7 @@ class FullLLLaplace(ParametricLaplace):
     """Last-layer full GGN (intent of laplace/lllaplace.py:369-378): parameters are the
     final ``nn.Linear``'s weight (row-major) then bias."""
     _key = ("last_layer", "full")
+    _sample_additive = True
 
     def __init__(self, model, likelihood, *args, **kwargs):
         super().__init__(model, likelihood, *args, **kwargs)

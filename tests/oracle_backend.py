@@ -54,3 +54,34 @@ class OracleBackend:
         self.calls.append(("full", tuple(x.tolist())))
         loss, H = O.lastlayer_full_batch(self.model.oracle_model(), x.numpy(), y.numpy())
         return torch.tensor(float(loss)), torch.from_numpy(H)
+
+
+class OracleClassBackend(OracleBackend):
+    """Adds the in-place, class-range capable fast path of HipGGN (kron_accumulate_ / pack_kron /
+    new_kfac_buffers / num_classes) on top of the oracle, to exercise the (batch, class) unit scheduling."""
+
+    @property
+    def num_classes(self):
+        return self.model.convs[-1].lin.weight.shape[0]
+
+    def new_kfac_buffers(self):
+        views = []
+        for conv in self.model.convs:
+            o, i = conv.lin.weight.shape
+            views.append((torch.zeros(i, i), torch.zeros(o, o)))
+        return None, views, torch.zeros(1)
+
+    def kron_accumulate_(self, views, loss_buf, x, y, N, classes=None):
+        self.calls.append(("kron_", tuple(x.tolist()), classes))
+        loss, kfacs = O.kfac_batch(self.model.oracle_model(), x.numpy(), y.numpy(), N, classes=classes)
+        for l, (A, B) in enumerate(views):
+            B += torch.from_numpy(kfacs[2 * l][0])
+            A += torch.from_numpy(kfacs[2 * l][1])
+        loss_buf += float(loss)
+
+    def pack_kron(self, views):
+        kfacs = []
+        for A, B in views:
+            kfacs.append([B.clone(), A.clone()])
+            kfacs.append([B.clone()])
+        return Kron(kfacs)

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, structure, out_dir):
+def _worker(rank, world, port, name, structure, out_dir, class_units=False):
     for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -31,19 +31,29 @@ def _worker(rank, world, port, name, structure, out_dir):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import laplace_gnn_amd as lg
-    from oracle_backend import OracleBackend
+    from oracle_backend import OracleBackend, OracleClassBackend
     from test_host_logic import _cpu_model
 
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     model = _cpu_model(g)
     loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"]),
                                   int(g["batch_size"]))
-    la = lg.Laplace(model, "classification", "all", structure, backend=OracleBackend)
+    la = lg.Laplace(model, "classification", "all", structure,
+                    backend=OracleClassBackend if class_units else OracleBackend)
     la.fit(loader)
-    mine = [c[1] for c in la.backend.calls]
-    expect = [tuple(loader.indices[s:s + loader.batch_size].tolist())
-              for t, s in enumerate(range(0, len(loader.dataset), loader.batch_size)) if t % world == rank]
-    assert mine == expect, "rank must process exactly the batches t % world == rank, unsplit"
+    batches = [tuple(loader.indices[s:s + loader.batch_size].tolist())
+               for s in range(0, len(loader.dataset), loader.batch_size)]
+    if structure == "diag":  # sample-additive: every rank takes its slice of every batch
+        mine = [c[1] for c in la.backend.calls]
+        expect = [b[len(b) * rank // world: len(b) * (rank + 1) // world] for b in batches]
+        assert mine == [e for e in expect if e]
+    elif class_units:  # balanced (batch, class-range) units; samples of a batch are never split
+        C = la.backend.num_classes
+        expect = [(batches[t], (c0, c1)) for t, c0, c1 in lg.units_of_rank(len(batches), C, rank, world)]
+        assert [(c[1], c[2]) for c in la.backend.calls] == expect
+    else:
+        mine = [c[1] for c in la.backend.calls]
+        assert mine == [b for t, b in enumerate(batches) if t % world == rank], "whole batches, round-robin"
     if structure == "kron":
         blocks = [h.numpy() for F in la.H_facs.kfacs for h in F]
     else:
@@ -54,12 +64,14 @@ def _worker(rank, world, port, name, structure, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world,class_units", [(2, False), (4, False), (2, True), (4, True), (8, True)])
 @pytest.mark.parametrize("structure,name", [("kron", "gcn_small_3batch_s0"), ("diag", "gcn_small_3batch_s1"),
                                             ("kron", "sage_small_3batch_s1")])
-def test_two_rank_fit_equals_single_process(tmp_path, world, structure, name):
+def test_multi_rank_fit_equals_single_process(tmp_path, world, class_units, structure, name):
+    if structure == "diag" and class_units:
+        pytest.skip("class units only exist for kron")
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, name, structure, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, name, structure, str(tmp_path), class_units), nprocs=world, join=True)
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     if structure == "kron":
         ref = [g[f"kron_{i}_{j}"] for i in range(int(g["kron_n_blocks"])) for j in range(2)

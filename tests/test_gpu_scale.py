@@ -186,3 +186,44 @@ def test_arxiv_shape_sampled_oracle_check(arxiv):
         g1 = PTs @ V[:, :, c]
         B1 += g1.T.astype(np.float64) @ g1
     assert rel(v[1][1].cpu().numpy(), B1) < RTOL
+
+
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
+def test_class_ranges_are_exact_shares_and_units_cover_a_fit(kind):
+    """lgnn_kfac_accumulate_classes: (a) disjoint class ranges of one batch add up to the whole batch;
+    (b) emulating 8 ranks with data.units_of_rank on one GPU and summing their buffers reproduces the
+    single-process fit (what the RCCL all-reduce does on a node)."""
+    import laplace_gnn_amd as lg
+
+    N, F, H, C, E = 3000, 48, 64, 10, 12000
+    ei, X, Ws, bs = _make(kind, N, F, H, C, E, seed=11)
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randperm(N, generator=g)[:700].cuda()
+    y = torch.randint(0, C, (700,), generator=g).cuda()
+    eng = _engine(kind, N, ei, X, Ws, bs)
+    _, v_full, l_full = eng.new_kfac_buffers()
+    eng.kfac_accumulate(idx[:300], y[:300], 700, v_full, l_full)
+    _, v_part, l_part = eng.new_kfac_buffers()
+    for r in ((0, 3), (3, 4), (4, 10)):
+        eng.kfac_accumulate(idx[:300], y[:300], 700, v_part, l_part, classes=r)
+    torch.cuda.synchronize()
+    for (Af, Bf), (Ap, Bp) in zip(v_full, v_part):
+        assert rel(Bp.cpu().numpy(), Bf.cpu().numpy()) < 1e-5 and rel(Ap.cpu().numpy(), Af.cpu().numpy()) < 1e-6
+    assert abs(float(l_part) - float(l_full)) < 1e-5 * abs(float(l_full))
+    with pytest.raises(lg._lib.HipLibraryError, match="class range"):
+        eng.kfac_accumulate(idx[:10], y[:10], 700, v_part, l_part, classes=(4, 4))
+
+    loader = lg.TensorBatchLoader(idx, y, 300)  # 300 / 300 / 100
+    views1, loss1 = kfac_fit_engine(eng, idx, y, 300)
+    flat_sum = None
+    for rank in range(8):
+        flat, views, loss = eng.new_kfac_buffers()
+        batches = list(loader)
+        for t, c0, c1 in lg.units_of_rank(len(loader), C, rank, 8):
+            eng.kfac_accumulate(batches[t][0], batches[t][1], 700, views, loss, classes=(c0, c1))
+        flat_sum = flat.clone() if flat_sum is None else flat_sum + flat
+    torch.cuda.synchronize()
+    ref = torch.cat([t.reshape(-1) for pair in views1 for t in pair]).cpu().numpy()
+    assert rel(flat_sum[:-1].cpu().numpy(), ref) < 1e-5
+    assert abs(float(flat_sum[-1]) - loss1) < 1e-5 * abs(loss1)
+    eng.close()

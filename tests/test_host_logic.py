@@ -138,6 +138,35 @@ def test_batches_of_rank_partition():
     assert [len(lg.batches_of_rank(10, r, 8)) for r in range(8)] == [2, 2, 1, 1, 1, 1, 1, 1]
 
 
+def test_units_of_rank_is_a_balanced_partition():
+    for T, C, world in [(10, 40, 8), (10, 40, 1), (3, 3, 8), (1, 7, 4), (10, 40, 3)]:
+        seen = []
+        sizes = []
+        for r in range(world):
+            units = lg.units_of_rank(T, C, r, world)
+            sizes.append(sum(c1 - c0 for _, c0, c1 in units))
+            assert len({t for t, _, _ in units}) == len(units)  # at most one class range per batch and rank
+            seen += [(t, c) for t, c0, c1 in units for c in range(c0, c1)]
+        assert sorted(seen) == [(t, c) for t in range(T) for c in range(C)]
+        assert max(sizes) - min(sizes) <= 1
+    assert [sum(c1 - c0 for _, c0, c1 in lg.units_of_rank(10, 40, r, 8)) for r in range(8)] == [50] * 8
+
+
+def test_oracle_class_ranges_are_additive():
+    import gnn_laplace_oracle as O
+    g = np.load(os.path.join(GOLDEN, "sage_small_1batch_s0.npz"))
+    for name in ("sage_small_1batch_s0", "gcn_small_1batch_s0"):
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        m = _cpu_model(g).oracle_model()
+        idx, y, n = g["train_idx"], g["train_y"], len(g["train_idx"])
+        full_loss, full = O.kfac_batch(m, idx, y, n)
+        parts = [O.kfac_batch(m, idx, y, n, classes=r) for r in ((0, 1), (1, 3))]
+        assert abs(sum(float(p[0]) for p in parts) - float(full_loss)) < 1e-6 * abs(float(full_loss))
+        for i, Fs in enumerate(full):
+            for j, Hm in enumerate(Fs):
+                assert rel(sum(p[1][i][j] for p in parts), Hm) < 1e-6
+
+
 # ---- front-end with an injected oracle backend ------------------------------------------------------------
 def _cpu_model(g):
     kind, L = str(g["kind"]), int(g["num_layers"])
