@@ -13,10 +13,12 @@ engine's cache is invalidated first), the 10 per-batch KFAC accumulations, the f
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, the graph / features / weights replicated, whole batches dealt
-round-robin (batch t -> rank t mod N, never split: B factors have cross-sample terms inside a
-batch), one RCCL all-reduce of the flat factor buffer.  Total work is fixed => "strong" scaling;
-with 10 batches the speed-up is bounded by ceil(10/N) (5x at N = 8).
+N > 1: one process per GPU, the graph / features / weights replicated.  A batch's SAMPLES are never
+split (B factors have cross-sample terms inside a batch), but B = sum over batches and class columns,
+so the 10 x 40 (batch, class) units are dealt in balanced runs of 400/N (laplace_gnn_amd.units_of_rank),
+one RCCL all-reduce sums the flat factor buffer, the eigendecomposition is dealt to the ranks and
+shared with a second all-reduce.  Total work is fixed => "strong" scaling; the forward pass and the
+per-batch seeds are replicated (Amdahl).
 """
 from __future__ import annotations
 
@@ -91,6 +93,9 @@ def main():
     ap.add_argument("--structure", default=None, choices=["kron", "diag"],
                     help="hessian_structure; default kron for arxiv (BASELINE configs[2]), diag for cora (configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="dev aid, 1 GPU: time only the share rank 0 of an N-rank job would execute (no all-reduce); "
+                         "prints the per-rank time, not a valid bench line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,6 +120,10 @@ def main():
     la = lg.Laplace(model, "classification", subset_of_weights="all", hessian_structure=structure)
     eng = model.engine
     nnz, N, H, C = eng.nnz, w["N"], w["H"], w["C"]
+
+    if args.emulate_world > 1:
+        plan = la._shard_plan
+        la._shard_plan = lambda tl, r, w_: plan(tl, 0, args.emulate_world)  # rank 0's share of an N-rank job
 
     def step():
         eng.invalidate()  # a fresh fit: forward + input Grams are recomputed, nothing carried over
@@ -182,7 +191,7 @@ def main():
                             f"(BASELINE configs[{2 if args.workload == 'arxiv' else 1}])",
                 "num_nodes": N, "nnz": nnz, "features": w["F"], "hidden": H, "classes": C,
                 "n_train": w["n_train"], "batch_size": w["batch"],
-                "batches": len(loader), "parallelism": f"dp{world} (whole batches round-robin)",
+                "batches": len(loader), "parallelism": f"dp{world} ((batch, class) units, contiguous balanced runs)",
             },
             "roofline": roofline,
         }
@@ -192,6 +201,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload, ei, X, Ws, bs, train_idx, train_y, w, structure)
         else:
             out["cpu_baseline"] = None
+        if args.emulate_world > 1:
+            out = {"emulated_rank0_of": args.emulate_world, "ms_per_rank_step": elapsed / args.steps * 1e3,
+                   "implied_samples_per_s": value, "note": "not a bench line: one rank's share, no all-reduce"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -293,7 +293,7 @@ class KronLaplace(ParametricLaplace):
         else:
             self.H = self._rescale_factors(self.H, n_data_new / (n_data_new + n_data_old))
             self.H_facs += self.H
-        self.H = self.H_facs.decompose(damping=self.damping)
+        self.H = self.H_facs.decompose(damping=self.damping, process_group=process_group)
 
     @property
     def posterior_precision(self) -> KronDecomposed:

@@ -56,6 +56,12 @@ def _worker(rank, world, port, name, structure, out_dir, class_units=False):
         assert mine == [b for t, b in enumerate(batches) if t % world == rank], "whole batches, round-robin"
     if structure == "kron":
         blocks = [h.numpy() for F in la.H_facs.kfacs for h in F]
+        # the distributed eigendecomposition (factors dealt to ranks + one all-reduce) must equal the local one
+        for Fs, ls, Qs in zip(la.H_facs.kfacs, la.H.eigenvalues, la.H.eigenvectors):
+            for Hm, lam, Q in zip(Fs, ls, Qs):
+                ref_lam, _ = lg.symeig(Hm)
+                assert torch.allclose(lam, ref_lam, rtol=1e-4, atol=1e-5 * float(ref_lam.abs().max()))
+                assert torch.allclose(Q @ torch.diag(lam) @ Q.T, Hm, rtol=1e-3, atol=1e-4 * float(Hm.abs().max()))
     else:
         blocks = [la.H.numpy()]
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=float(la.loss), n_data=la.n_data,
