@@ -38,6 +38,9 @@ WORKLOADS = {
     # name: N, undirected edges, F, H, C, N_train, batch
     "arxiv": dict(N=169_343, E=1_166_243, F=128, H=256, C=40, n_train=90_941, batch=10_000),
     "cora": dict(N=2_708, E=5_278, F=1_433, H=64, C=7, n_train=1_299, batch=10_000),
+    # BASELINE configs[4]: 3-layer GraphSAGE, last-layer full GGN (P_LL = 47 * 513 = 24 111), power-law degrees
+    "products": dict(N=2_449_029, E=61_859_140, F=100, H=256, C=47, n_train=196_615, batch=10_000, layers=3,
+                     kind="sage", powerlaw=0.5),
 }
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
@@ -48,7 +51,18 @@ def make_workload(name: str, device, seed: int = 0):
     every rank (and the CPU baseline) sees identical data."""
     w = WORKLOADS[name]
     g = torch.Generator().manual_seed(seed)
-    ei = torch.randint(0, w["N"], (2, w["E"]), generator=g, dtype=torch.int64)
+    if "powerlaw" in w:
+        # endpoints from P(i) ~ i^-alpha by inverse CDF, node ids shuffled; alpha = 0.5 gives hubs of ~1e4..1e5
+        # neighbours next to a median degree of a few tens (ogbn-products: max 17 481, median ~ 26)
+        a = w["powerlaw"]
+        perm = torch.randperm(w["N"], generator=g)
+        ends = []
+        for _ in range(2):
+            u = torch.rand(w["E"], generator=g, dtype=torch.float64)
+            ends.append(perm[(u.pow(1.0 / (1.0 - a)) * w["N"]).long().clamp_(max=w["N"] - 1)])
+        ei = torch.stack(ends)
+    else:
+        ei = torch.randint(0, w["N"], (2, w["E"]), generator=g, dtype=torch.int64)
     X = torch.randn(w["N"], w["F"], generator=g)
     y_all = torch.randint(0, w["C"], (w["N"],), generator=g, dtype=torch.int64)
     train_idx = torch.randperm(w["N"], generator=g)[: w["n_train"]]
@@ -90,8 +104,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="arxiv", choices=sorted(WORKLOADS))
-    ap.add_argument("--structure", default=None, choices=["kron", "diag"],
-                    help="hessian_structure; default kron for arxiv (BASELINE configs[2]), diag for cora (configs[1])")
+    ap.add_argument("--structure", default=None, choices=["kron", "diag", "lastlayer"],
+                    help="hessian_structure; default kron for arxiv (BASELINE configs[2]), diag for cora (configs[1]), "
+                         "last-layer full GGN for products (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="dev aid, 1 GPU: time only the share rank 0 of an N-rank job would execute (no all-reduce); "
@@ -114,10 +129,14 @@ def main():
 
     w, ei, X, train_idx, train_y = make_workload(args.workload, dev)
     torch.manual_seed(0)
-    model = lg.GCN(w["F"], w["H"], w["C"], 2, X, ei, symmetric=True).to(dev)
+    cls = lg.GraphSAGE if w.get("kind") == "sage" else lg.GCN
+    model = cls(w["F"], w["H"], w["C"], w.get("layers", 2), X, ei, symmetric=True).to(dev)
     loader = lg.TensorBatchLoader(train_idx.to(dev), train_y.to(dev), batch_size=w["batch"])
-    structure = args.structure or ("kron" if args.workload == "arxiv" else "diag")
-    la = lg.Laplace(model, "classification", subset_of_weights="all", hessian_structure=structure)
+    structure = args.structure or {"arxiv": "kron", "cora": "diag", "products": "lastlayer"}[args.workload]
+    if structure == "lastlayer":
+        la = lg.Laplace(model, "classification", subset_of_weights="last_layer", hessian_structure="full")
+    else:
+        la = lg.Laplace(model, "classification", subset_of_weights="all", hessian_structure=structure)
     eng = model.engine
     nnz, N, H, C = eng.nnz, w["N"], w["H"], w["C"]
 
@@ -181,21 +200,23 @@ def main():
                 "kernel_share_of_wall": kern_ms * 1e-3 / elapsed,
             }
         out = {
-            "metric": "la.fit() samples/sec (GCN, KFAC)" if structure == "kron" else "la.fit() samples/sec (GCN, diag GGN)",
+            "metric": {"kron": "la.fit() samples/sec (GCN, KFAC)", "diag": "la.fit() samples/sec (GCN, diag GGN)",
+                       "lastlayer": "la.fit() samples/sec (GraphSAGE, last-layer full GGN)"}[structure],
             "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}-shaped 2-layer GCN, hessian_structure={structure} "
-                            f"(BASELINE configs[{2 if args.workload == 'arxiv' else 1}])",
+                "workload": f"{args.workload}-shaped {w.get('layers', 2)}-layer {w.get('kind', 'gcn').upper()}, "
+                            f"hessian_structure={structure} "
+                            f"(BASELINE configs[{dict(arxiv=2, cora=1, products=4)[args.workload]}])",
                 "num_nodes": N, "nnz": nnz, "features": w["F"], "hidden": H, "classes": C,
                 "n_train": w["n_train"], "batch_size": w["batch"],
                 "batches": len(loader), "parallelism": f"dp{world} ((batch, class) units, contiguous balanced runs)",
             },
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and structure != "lastlayer":
             Ws = [c.lin.weight.detach().cpu().numpy() for c in model.convs]
             bs = [c.lin.bias.detach().cpu().numpy() for c in model.convs]
             out["cpu_baseline"] = cpu_baseline(args.workload, ei, X, Ws, bs, train_idx, train_y, w, structure)
