@@ -16,34 +16,41 @@ namespace lgnn {
 
 namespace {
 
-constexpr int BGM = 128;  // rows per tile
+constexpr int BGM = 64;  // rows per tile: 2 row groups of 32 x 2 column halves = 4 waves
 
+// LDS: W [K2][NT*32] once, then TWO copies of (A tile [64][KP], node ids [64], mask words [64][8]).
+// Per tile: issue the global loads of tile i+1 -> MFMAs on tile i -> park tile i+1 in the other LDS copy
+// (the loads landed during the MFMAs, and this wait comes BEFORE the epilogue's stores, so it never has
+// to drain them: vmcnt is in order) -> epilogue stores of tile i -> one barrier.
 template <int NT, int VECA>
 __global__ __launch_bounds__(256, 2) void backgemm_kernel(BackGemmArgs g) {
   extern __shared__ float smem[];
   const int K = int(g.K), K2 = (K + 1) & ~1, KP = K2 | 1;
   constexpr int NP = NT * 32;
-  constexpr int NTW = NT > 4 ? 4 : NT;  // column tiles per pass (64 accumulator registers)
+  constexpr int NTW = NT >= 2 ? NT / 2 : 1;  // column tiles per wave (<= 4: 64 accumulator registers)
   float* __restrict__ Bs = smem;
-  float* __restrict__ As = smem + K2 * NP;
-  int32_t* __restrict__ nodes = reinterpret_cast<int32_t*>(As + BGM * KP);  // node id of every tile row
-  uint32_t* __restrict__ mask_s = reinterpret_cast<uint32_t*>(nodes + BGM);   // [BGM][8] ReLU mask words of the tile rows
+  const int copy_words = BGM * KP + BGM + BGM * 8;
+  float* __restrict__ copy0 = smem + K2 * NP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
+  const int rg = wave >> 1, ch = wave & 1;
+  const bool wave_active = NT >= 2 || ch == 0;
   for (int f = tid; f < K2 * NP; f += 256) {
     const int k = f / NP, c = f - k * NP;
     Bs[f] = (k < K && c < g.Nout) ? g.W[int64_t(k) * g.ldw + c] : 0.f;
   }
   if (K2 != K)
-    for (int r = tid; r < BGM; r += 256) As[r * KP + K] = 0.f;
+    for (int r = tid; r < 2 * BGM; r += 256) (copy0 + (r / BGM) * copy_words)[(r % BGM) * KP + K] = 0.f;
 
   const int64_t na = g.rows ? int64_t(*g.na_dev) : g.N;
   const int64_t tiles_per_plane = (na + BGM - 1) / BGM;
   const int64_t ntiles = tiles_per_plane * g.planes;
 
-  constexpr int MAXV = VECA == 4 ? 8 : 32;
+  constexpr int MAXV = VECA == 4 ? 4 : 16;  // staged float4 / floats per thread (64 rows, K <= 64)
   float4 st4[VECA == 4 ? MAXV : 1];
   float st1[VECA == 1 ? MAXV : 1];
+  uint2 mstage = make_uint2(~0u, ~0u);  // mask words (row tid>>2, words (tid&3)*2 ..+1) of the staged tile
+  int32_t nstage = -1;                  // node id of row tid (tid < 64) of the staged tile
   const int step = 256 * VECA;
   const int q = step / K, rem = step - q * K;
   const int r_first = (tid * VECA) / K, k_first = (tid * VECA) - r_first * K;
@@ -53,24 +60,10 @@ __global__ __launch_bounds__(256, 2) void backgemm_kernel(BackGemmArgs g) {
     t0 = (tile - plane * tiles_per_plane) * BGM;
   };
   auto node_of = [&](int64_t t) -> int64_t { return g.rows ? int64_t(g.rows[t]) : t; };
-  uint4 mstage = make_uint4(~0u, ~0u, ~0u, ~0u);  // mask words (row tid>>1, half tid&1) of the prefetched tile
   auto load_tile = [&](int64_t tile) {
     int64_t plane, t0;
     tile_coords(tile, plane, t0);
     const float* __restrict__ base = g.G + plane * g.N * g.K;
-    if (g.mask_bits) {
-      // the mask words ride along with the tile prefetch and are parked in LDS: the epilogue then
-      // needs no global load at all (a dependent load per row group used to stall it 8 times per tile)
-      const int mr = tid >> 1, mh = (tid & 1) * 4;
-      mstage = make_uint4(~0u, ~0u, ~0u, ~0u);
-      if (t0 + mr < na) {
-        const uint32_t* __restrict__ mp = g.mask_bits + node_of(t0 + mr) * g.mask_words;
-        if (mh + 0 < g.mask_words) mstage.x = mp[mh + 0];
-        if (mh + 1 < g.mask_words) mstage.y = mp[mh + 1];
-        if (mh + 2 < g.mask_words) mstage.z = mp[mh + 2];
-        if (mh + 3 < g.mask_words) mstage.w = mp[mh + 3];
-      }
-    }
     int r = r_first, k = k_first;
 #pragma unroll
     for (int e = 0; e < MAXV; ++e) {
@@ -84,10 +77,21 @@ __global__ __launch_bounds__(256, 2) void backgemm_kernel(BackGemmArgs g) {
       r += q; k += rem;
       if (k >= K) { k -= K; r += 1; }
     }
+    nstage = (tid < BGM && t0 + tid < na) ? int32_t(node_of(t0 + tid)) : -1;
+    mstage = make_uint2(~0u, ~0u);
+    if (g.mask_bits) {
+      const int mr = tid >> 2, mw = (tid & 3) * 2;
+      if (t0 + mr < na) {
+        const uint32_t* __restrict__ mp = g.mask_bits + node_of(t0 + mr) * g.mask_words;
+        if (mw + 0 < g.mask_words) mstage.x = mp[mw + 0];
+        if (mw + 1 < g.mask_words) mstage.y = mp[mw + 1];
+      }
+    }
   };
-  auto store_tile = [&](int64_t tile) {
-    int64_t plane, t0;
-    tile_coords(tile, plane, t0);
+  auto park_tile = [&](int buf) {
+    float* __restrict__ As = copy0 + buf * copy_words;
+    int32_t* __restrict__ nodes = reinterpret_cast<int32_t*>(As + BGM * KP);
+    uint32_t* __restrict__ mask_s = reinterpret_cast<uint32_t*>(nodes + BGM);
     int r = r_first, k = k_first;
 #pragma unroll
     for (int e = 0; e < MAXV; ++e) {
@@ -99,72 +103,59 @@ __global__ __launch_bounds__(256, 2) void backgemm_kernel(BackGemmArgs g) {
       r += q; k += rem;
       if (k >= K) { k -= K; r += 1; }
     }
-    if (tid < BGM) nodes[tid] = t0 + tid < na ? int32_t(node_of(t0 + tid)) : -1;
-    if (g.mask_bits) *reinterpret_cast<uint4*>(mask_s + (tid >> 1) * 8 + (tid & 1) * 4) = mstage;
+    if (tid < BGM) nodes[tid] = nstage;
+    *reinterpret_cast<uint2*>(mask_s + (tid >> 2) * 8 + (tid & 3) * 2) = mstage;
   };
 
   int64_t tile = blockIdx.x;
-  if (tile < ntiles) load_tile(tile);
-  for (; tile < ntiles; tile += gridDim.x) {
-    store_tile(tile);
-    __syncthreads();
-    if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+  int buf = 0;
+  if (tile < ntiles) {
+    load_tile(tile);
+    park_tile(0);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    const bool has_next = tile + gridDim.x < ntiles;
+    if (has_next) load_tile(tile + gridDim.x);
+    const float* __restrict__ As = copy0 + buf * copy_words;
+    const int32_t* __restrict__ nodes = reinterpret_cast<const int32_t*>(As + BGM * KP);
+    const uint32_t* __restrict__ mask_s = reinterpret_cast<const uint32_t*>(nodes + BGM);
     int64_t plane, t0;
     tile_coords(tile, plane, t0);
     float* __restrict__ Up = g.U + plane * g.N * g.Nout;
-    int32_t nd[16];
+
+    f32x16 acc[NTW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) nd[r] = nodes[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
-    const float* __restrict__ arow = As + (wave * 32 + l31) * KP + lhi;
-#pragma unroll 1
-    for (int pass = 0; pass < NT / NTW; ++pass) {
-      f32x16 acc[NTW];
+    for (int n = 0; n < NTW; ++n)
 #pragma unroll
-      for (int n = 0; n < NTW; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-      const float* __restrict__ brow = Bs + lhi * NP + pass * NTW * 32 + l31;
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    if (wave_active) {
+      const float* __restrict__ arow = As + (rg * 32 + l31) * KP + lhi;
+      const float* __restrict__ brow = Bs + lhi * NP + ch * NTW * 32 + l31;
       for (int kk = 0; kk < (g.debug == 2 ? 1 : K2 / 2); ++kk) {
         const float av = arow[2 * kk];
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
           acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[2 * kk * NP + n * 32], acc[n], 0, 0, 0);
       }
-      const int colb = pass * NTW * 32 + l31;
+    }
+    // the prefetched tile goes to the other LDS copy now: its loads are older than every store below
+    if (has_next) park_tile(buf ^ 1);
+    if (wave_active) {
+      const int colb = ch * NTW * 32 + l31;
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        // all mask loads of 4 rows first, then math and stores
-        uint32_t mw[4][NTW];
-        float hv[4][NTW];
+      for (int r = 0; r < 16; ++r) {
+        const int lr = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int32_t nd = nodes[lr];
+        if (nd < 0) continue;
+        float* __restrict__ urow = Up + int64_t(nd) * g.Nout;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int r = rg * 4 + rr;
-          const bool live = nd[r] >= 0;
-#pragma unroll
-          for (int n = 0; n < NTW; ++n) {
-            mw[rr][n] = 0xffffffffu;
-            hv[rr][n] = 1.f;
-            const int col = colb + n * 32;
-            if (g.mask_bits) {
-              mw[rr][n] = mask_s[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * 8 + pass * NTW + n];
-            } else if (g.hact) {
-              if (live && col < g.Nout) hv[rr][n] = g.hact[int64_t(nd[r]) * g.hact_ld + col];
-            }
-          }
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int r = rg * 4 + rr;
-          if (nd[r] < 0) continue;
-          float* __restrict__ urow = Up + int64_t(nd[r]) * g.Nout;
-#pragma unroll
-          for (int n = 0; n < NTW; ++n) {
-            const int col = colb + n * 32;
-            float v = acc[n][r];
-            if (g.mask_bits) v = ((mw[rr][n] >> l31) & 1u) ? v : 0.f;
-            else if (g.hact) v *= act_deriv_from_out(hv[rr][n], g.act);
-            if (col < g.Nout && g.debug != 1) urow[col] = v;
-          }
+        for (int n = 0; n < NTW; ++n) {
+          const int col = colb + n * 32;
+          float v = acc[n][r];
+          if (g.mask_bits) v = ((mask_s[lr * 8 + ch * NTW + n] >> l31) & 1u) ? v : 0.f;
+          else if (g.hact && col < g.Nout) v *= act_deriv_from_out(g.hact[int64_t(nd) * g.hact_ld + col], g.act);
+          if (col < g.Nout && g.debug != 1) urow[col] = v;
         }
       }
     }
@@ -213,7 +204,7 @@ bool backgemm_supported(int64_t K, int64_t Nout) {
   if (K < 1 || K > 64 || Nout < 1 || Nout > 256) return false;
   const int nt = Nout <= 32 ? 1 : (Nout <= 64 ? 2 : (Nout <= 128 ? 4 : 8));
   const int K2 = int((K + 1) & ~int64_t(1)), KP = K2 | 1;
-  return (size_t(K2) * nt * 32 + size_t(BGM) * KP + BGM + BGM * 8) * 4 <= 64 * 1024 + 8 * 1024;
+  return (size_t(K2) * nt * 32 + 2 * (size_t(BGM) * KP + BGM + BGM * 8)) * 4 <= 78 * 1024;
 }
 
 int launch_backgemm(const BackGemmArgs& g_in, hipStream_t s) {
@@ -225,7 +216,7 @@ int launch_backgemm(const BackGemmArgs& g_in, hipStream_t s) {
   LGNN_REQUIRE(backgemm_supported(g.K, g.Nout), "backgemm shape not supported");
   const int nt = g.Nout <= 32 ? 1 : (g.Nout <= 64 ? 2 : (g.Nout <= 128 ? 4 : 8));
   const int K2 = int((g.K + 1) & ~int64_t(1)), KP = K2 | 1;
-  const size_t smem = (size_t(K2) * nt * 32 + size_t(BGM) * KP + BGM + BGM * 8) * 4;
+  const size_t smem = (size_t(K2) * nt * 32 + 2 * (size_t(BGM) * KP + BGM + BGM * 8)) * 4;
   const bool vec = g.K % 4 == 0 && (reinterpret_cast<uintptr_t>(g.G) & 15) == 0;
   switch (nt) {
     case 1: return backgemm_launch<1>(g, smem, vec, s);

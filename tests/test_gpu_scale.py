@@ -227,3 +227,32 @@ def test_class_ranges_are_exact_shares_and_units_cover_a_fit(kind):
     assert rel(flat_sum[:-1].cpu().numpy(), ref) < 1e-5
     assert abs(float(flat_sum[-1]) - loss1) < 1e-5 * abs(loss1)
     eng.close()
+
+
+@pytest.mark.parametrize("kind,H,C,L", [
+    ("gcn", 256, 47, 2),   # fused256 + backgemm with odd K (scalar staging), 8 column tiles
+    ("gcn", 256, 12, 3),   # fused256 with the store path (g needed by the layer below) + hidden->hidden GEMM (K = 256)
+    ("gcn", 128, 9, 2),    # generic fused kernel <128>, backgemm with 4 column tiles
+    ("gcn", 96, 5, 2),     # width not a multiple of 32
+    ("gcn", 30, 4, 2),     # width % 4 != 0: unfused fallback (SpMM + Gram through HBM)
+    ("gcn", 200, 70, 2),   # K > 64: generic GEMM instead of backgemm
+    ("sage", 256, 10, 2),  # GraphSAGE through fused256 with self path + mask epilogue
+    ("sage", 64, 33, 3),
+])
+def test_kfac_kernel_variants_vs_oracle(kind, H, C, L):
+    """Every kernel-selection branch of the KFAC path (tile widths, K ranges, store / self / fallback paths)."""
+    N, F, E = 1200, 40, 5000
+    ei, X, Ws, bs = _make(kind, N, F, H, C, E, L=L, seed=21)
+    g = torch.Generator().manual_seed(3)
+    idx = torch.randperm(N, generator=g)[:260]
+    y = torch.randint(0, C, (260,), generator=g)
+    eng = _engine(kind, N, ei, X, Ws, bs)
+    eng.set_workspace_limit(64 << 20)  # forces several class chunks
+    views, loss = kfac_fit_engine(eng, idx.cuda(), y.cuda(), 130)
+    om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], True)
+    oloss, oH = O.fit_kron(om, idx.numpy(), y.numpy(), 130)
+    for l, (A, B) in enumerate(views):
+        assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL, f"B_{l}"
+        assert rel(A.cpu().numpy(), oH[2 * l][1]) < RTOL, f"A_{l}"
+    assert abs(loss - float(oloss)) < RTOL * abs(float(oloss))
+    eng.close()
