@@ -149,6 +149,11 @@ LGNN_API int lgnn_diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y
 LGNN_API int lgnn_lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M,
                                    float* H_out, float* loss_out, void* stream);
 
+/* Invalid batch contents (node ids outside [0, N), labels outside [0, C)) are detected on the device: such
+ * samples contribute nothing and a sticky flag is raised.  This call synchronises `stream`, reports the flag
+ * (non-zero return + message) and clears it; call it once per fit, not per batch.                          */
+LGNN_API int lgnn_check_async_errors(lgnn_ctx* h, void* stream);
+
 /* ---- timing hook (bench.py roofline) -----------------------------------------------------------
  * While enabled, every launch of the dominant kernel of the KFAC path (the fused SpMM^T -> Gram
  * kernel of the lowest layer) is bracketed by HIP events recorded on `stream` itself

@@ -39,6 +39,7 @@ SIGNATURES = {
     "lgnn_kfac_accumulate_classes": (_i32, [_vp, _vp, _vp, _i64, _i64, _u32, _i64, _i64, _pp, _pp, _vp, _vp]),
     "lgnn_diag_accumulate": (_i32, [_vp, _vp, _vp, _i64, _u32, _vp, _vp, _vp]),
     "lgnn_lastlayer_full_accumulate": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "lgnn_check_async_errors": (_i32, [_vp, _vp]),
     "lgnn_enable_kernel_timing": (_i32, [_vp, _i32]),
     "lgnn_kernel_timing_read": (_i32, [_vp, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64)]),
 }

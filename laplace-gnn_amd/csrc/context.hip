@@ -172,6 +172,11 @@ extern "C" int lgnn_create(lgnn_ctx** out, int64_t num_nodes, const int64_t* edg
   if (rc == 0) {
     rc = h->ws.pos.reserve(size_t(num_nodes) * 4);
     if (rc == 0) rc = launch_fill_i32(h->ws.pos.as<int32_t>(), num_nodes, INT32_MAX, static_cast<hipStream_t>(stream));
+    if (rc == 0) rc = h->ws.flags.reserve(64);  // sticky asynchronous error flags, zero = clean
+    if (rc == 0 && hipMemsetAsync(h->ws.flags.p, 0, 64, static_cast<hipStream_t>(stream)) != hipSuccess) {
+      set_error("hipMemsetAsync(flags) failed");
+      rc = 1;
+    }
   }
   if (rc != 0) { lgnn_destroy(h); return rc; }
   *out = h;
@@ -263,7 +268,22 @@ extern "C" int lgnn_forward(lgnn_ctx* h, const int64_t* idx, int64_t M, float* o
   if (!h || (M > 0 && (!idx || !out))) { set_error("null argument"); return 2; }
   hipStream_t s = static_cast<hipStream_t>(stream);
   LGNN_CALL(forward_ensure(h, s));
-  return launch_gather_rows(h->fc.out.as<float>(), h->dims[h->L], idx, M, h->dims[h->L], out, s);
+  // out-of-range node ids read as zero rows and raise the asynchronous flag (lgnn_check_async_errors)
+  return launch_gather_rows(h->fc.out.as<float>(), h->dims[h->L], h->N, idx, M, h->dims[h->L], out,
+                            h->ws.flags.as<int>() + 2, s);
+}
+
+extern "C" int lgnn_check_async_errors(lgnn_ctx* h, void* stream) {
+  if (!h) { set_error("null context"); return 2; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!h->ws.flags.p) return 0;
+  int flags[4] = {0, 0, 0, 0};
+  LGNN_HIP_CHECK(hipMemcpyAsync(flags, h->ws.flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
+  LGNN_HIP_CHECK(hipStreamSynchronize(s));
+  LGNN_HIP_CHECK(hipMemsetAsync(h->ws.flags.p, 0, 64, s));
+  LGNN_REQUIRE(flags[1] == 0 && flags[0] != 1 && flags[2] == 0, "a batch contained a node index outside [0, num_nodes)");
+  LGNN_REQUIRE(flags[0] != 2, "a batch contained a label outside [0, num_classes)");
+  return 0;
 }
 
 extern "C" int lgnn_enable_kernel_timing(lgnn_ctx* h, int enable) {

@@ -31,9 +31,11 @@ struct FeatView {  // E[v, i]: i < width -> base[v*ld + i]; i == width -> bias c
   int64_t ld;
   int64_t width;
   const float* bias_col;  // per-node scale (rowsum) or nullptr for the constant 1
+  int64_t nrows;          // node ids outside [0, nrows) (flagged by the batch prologue) read as zero rows
 };
 
 __device__ __forceinline__ float feat(const FeatView& f, int64_t v, int64_t i) {
+  if (v < 0 || v >= f.nrows) return 0.f;
   if (i < f.width) return f.base[v * f.ld + i];
   return f.bias_col ? f.bias_col[v] : 1.f;
 }
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(256) void diag_first_layer_kernel(
   const int64_t m_begin = int64_t(blockIdx.z) * slab, m_end = min(M, m_begin + slab);
   for (int64_t m = m_begin; m < m_end; ++m) {
     const int64_t node = idx[m];
+    if (node < 0 || node >= E.nrows) continue;  // flagged by the batch prologue
     float T[JPT];
 #pragma unroll
     for (int jj = 0; jj < JPT; ++jj) T[jj] = 0.f;
@@ -203,6 +206,7 @@ __global__ void ll_place_block_kernel(const float* __restrict__ S, int64_t D, in
 }
 
 int feat_views(lgnn_ctx* h, int layer, FeatView& f) {
+  f.nrows = h->N;
   // what Linear `layer` multiplies, seen from an output node: propagated input (GCN) or cat (GraphSAGE)
   if (h->kind == LGNN_KIND_GCN) {
     f.base = h->fc.prop_in[layer].as<float>();

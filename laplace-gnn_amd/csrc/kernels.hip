@@ -813,11 +813,11 @@ __global__ void gather_rows_kernel(const float* __restrict__ in, int64_t ld, con
     out[q] = in[n * ld + c];
   }
 }
-int launch_gather_rows(const float* in, int64_t ld, const int64_t* idx, int64_t M, int64_t width, float* out,
-                       hipStream_t s) {
+int launch_gather_rows(const float* in, int64_t ld, int64_t nrows_in, const int64_t* idx, int64_t M, int64_t width,
+                       float* out, int* bad_flag, hipStream_t s) {
   if (M <= 0 || width <= 0) return 0;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M * width, 256), 2048))), dim3(256), 0,
-                     s, in, ld, idx, M, width, int64_t(1) << 62, out, (int*)nullptr);
+                     s, in, ld, idx, M, width, nrows_in, out, bad_flag);
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -23,7 +23,7 @@ __global__ void mark_batch_kernel(const int64_t* __restrict__ idx, int64_t M, in
   const int64_t m = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (m >= M) return;
   const int64_t n = idx[m];
-  if (n < 0 || n >= N) { *bad = 1; return; }
+  if (n < 0 || n >= N) { bad[1] = 1; return; }  // sticky flag word 1: node id out of range
   atomicMin(&pos[n], int32_t(m));  // duplicates: the first occurrence owns the accumulated seed row
 }
 __global__ void unmark_batch_kernel(const int64_t* __restrict__ idx, int64_t M, int64_t N, int32_t* __restrict__ pos) {
@@ -194,9 +194,7 @@ int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bo
   LGNN_REQUIRE(h->lik == LGNN_LIK_CLASSIFICATION, "only the classification likelihood is implemented on the GPU path");
   const int64_t N = h->N, C = h->dims[h->L];
   LGNN_REQUIRE(2 * C * 4 <= 64 * 1024, "too many classes for the seed kernel");
-  LGNN_CALL(h->ws.flags.reserve(64));
-  LGNN_HIP_CHECK(hipMemsetAsync(h->ws.flags.p, 0, 64, s));
-  int* bad = h->ws.flags.as<int>();
+  int* bad = h->ws.flags.as<int>();  // allocated and zeroed by lgnn_create; sticky until lgnn_check_async_errors
   hipLaunchKernelGGL(mark_batch_kernel, dim3(unsigned(cdiv(M, 256))), dim3(256), 0, s, idx, M, N,
                      h->ws.pos.as<int32_t>(), bad);
   LGNN_CALL(h->ws.probs.reserve(size_t(M) * C * 4));
@@ -217,16 +215,6 @@ int batch_epilogue(lgnn_ctx* h, const int64_t* idx, int64_t M, hipStream_t s) {
   hipLaunchKernelGGL(unmark_batch_kernel, dim3(unsigned(cdiv(M, 256))), dim3(256), 0, s, idx, M, h->N,
                      h->ws.pos.as<int32_t>());
   LGNN_HIP_CHECK(hipGetLastError());
-  return 0;
-}
-
-// out-of-range indices / labels are reported asynchronously through this flag (checked by callers that sync)
-int batch_check_flag(lgnn_ctx* h, hipStream_t s) {
-  int flag = 0;
-  LGNN_HIP_CHECK(hipMemcpyAsync(&flag, h->ws.flags.p, 4, hipMemcpyDeviceToHost, s));
-  LGNN_HIP_CHECK(hipStreamSynchronize(s));
-  LGNN_REQUIRE(flag != 1, "batch node index out of [0, num_nodes)");
-  LGNN_REQUIRE(flag != 2, "label out of [0, num_classes)");
   return 0;
 }
 

@@ -216,8 +216,8 @@ int launch_spmm_gram(const Csr& m, int64_t nrows, int64_t nplanes, const float* 
 
 int launch_transpose(const float* in, int64_t rows, int64_t cols, float* out, hipStream_t s);
 int launch_fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s);
-int launch_gather_rows(const float* in, int64_t ld, const int64_t* idx, int64_t M, int64_t width, float* out,
-                       hipStream_t s);
+int launch_gather_rows(const float* in, int64_t ld, int64_t nrows_in, const int64_t* idx, int64_t M, int64_t width,
+                       float* out, int* bad_flag, hipStream_t s);
 
 // ---- kfac.hip ---------------------------------------------------------------------------
 int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train, uint32_t flags,
@@ -225,7 +225,6 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
 int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bool want_seeds, bool fork_exact,
                    float* loss_out, hipStream_t s);
 int batch_epilogue(lgnn_ctx* h, const int64_t* idx, int64_t M, hipStream_t s);
-int batch_check_flag(lgnn_ctx* h, hipStream_t s);
 // ---- forward.hip ------------------------------------------------------------------------
 int forward_ensure(lgnn_ctx* h, hipStream_t s);
 int forward_ensure_grams(lgnn_ctx* h, hipStream_t s);

@@ -117,6 +117,9 @@ class HipCurvatureInterface:
         eng.lastlayer_full_accumulate(x, y, H, loss)
         return self.factor * loss[0], H
 
+    def check_async_errors(self):
+        self.engine.check_async_errors()
+
     def jacobians(self, x, enable_backprop: bool = True):
         raise NotImplementedError("explicit Jacobians (GLM predictive) are a 'next' row (SURVEY.md 8(f)-3)")
 

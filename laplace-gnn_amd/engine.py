@@ -223,6 +223,10 @@ class GraphEngine:
             _dev_ptr(H, torch.float32, "H"), loss.data_ptr(), _stream(self.device))
         _lib.check(rc, "lgnn_lastlayer_full_accumulate")
 
+    def check_async_errors(self):
+        """Synchronise and raise if any batch since the last check contained an invalid node id or label."""
+        _lib.check(self.lib.lgnn_check_async_errors(self._h, _stream(self.device)), "lgnn_check_async_errors")
+
     # -- timing hook ----------------------------------------------------------------------------
     def enable_kernel_timing(self, on: bool = True):
         _lib.check(self.lib.lgnn_enable_kernel_timing(self._h, int(on)), "lgnn_enable_kernel_timing")

@@ -154,6 +154,8 @@ class ParametricLaplace(BaseLaplace):
             loss = loss + loss_batch
             self._accumulate(H_batch)
         self._finish_accumulate()
+        if hasattr(self.backend, "check_async_errors"):
+            self.backend.check_async_errors()  # invalid node ids / labels are flagged on the device; one sync per fit
         if world > 1:
             all_reduce_flat_(self._reduce_tensors() + [loss], process_group)
             self._after_reduce()

@@ -151,3 +151,24 @@ def test_missing_gpu_model_fails_loudly():
     model = model_from_golden(g, device=None)  # stays on the CPU
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model(torch.arange(3))
+
+
+def test_invalid_labels_and_indices_are_reported_at_the_end_of_fit():
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, "gcn_small_1batch_s0.npz"))
+    model = model_from_golden(g)
+    idx = torch.from_numpy(g["train_idx"]).cuda()
+    y = torch.from_numpy(g["train_y"]).cuda().clone()
+    y[3] = 99  # label outside [0, C)
+    la = lg.KronLaplace(model, "classification")
+    with pytest.raises(lg._lib.HipLibraryError, match="label"):
+        la.fit(lg.TensorBatchLoader(idx, y, 10000))
+    bad_idx = idx.clone()
+    bad_idx[5] = 10_000  # node id outside [0, N)
+    ld = lg.DiagLaplace(model, "classification")
+    with pytest.raises(lg._lib.HipLibraryError, match="node index"):
+        ld.fit(lg.TensorBatchLoader(bad_idx, torch.from_numpy(g["train_y"]).cuda(), 10000))
+    # the context stays usable afterwards
+    la.fit(lg.TensorBatchLoader(idx, torch.from_numpy(g["train_y"]).cuda(), 10000))
+    assert rel(la.H_facs.kfacs[0][0].cpu().numpy(), g["kron_0_0"]) < RTOL
