@@ -208,8 +208,15 @@ class ParametricLaplace(BaseLaplace):
     def log_det_ratio(self) -> torch.Tensor:
         return self.log_det_posterior_precision - self.log_det_prior_precision
 
-    def log_marginal_likelihood(self) -> torch.Tensor:
-        """laplace/baselaplace.py:938-973."""
+    def log_marginal_likelihood(self, prior_precision=None, sigma_noise=None) -> torch.Tensor:
+        """laplace/baselaplace.py:938-973: ``log_lik - 0.5 (log det P - log det P_0 + scatter)``; passing
+        ``prior_precision`` overwrites the current value (useful when iterating on the marginal likelihood)."""
+        if prior_precision is not None:
+            self.prior_precision = prior_precision
+        if sigma_noise is not None:
+            if self.likelihood != "regression":
+                raise ValueError("Can only change sigma_noise for regression.")
+            self.sigma_noise = sigma_noise
         return self.log_likelihood - 0.5 * (self.log_det_ratio + self.scatter)
 
 

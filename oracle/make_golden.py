@@ -113,8 +113,18 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
         for j, lam in enumerate(ls):
             out[f"kron_eig_{i}_{j}"] = lam.detach().numpy().astype(np.float32)
 
+    # "next" row 8(f)-1: log marginal likelihood from the decomposed factors (baselaplace.py:938-973,
+    # matrix.py:371-394), scalar and per-parameter-group prior precision
+    out["kron_marglik_pp1"] = np.float64(float(la.log_marginal_likelihood()))
+    out["kron_marglik_pp07"] = np.float64(float(la.log_marginal_likelihood(prior_precision=torch.tensor(0.7))))
+    pp_layer = torch.tensor([0.5, 2.0, 1.5, 0.25] * (len(la.H_facs.kfacs) // 4) + [1.0] * (len(la.H_facs.kfacs) % 4))
+    out["kron_prior_layerwise"] = pp_layer.numpy()
+    out["kron_marglik_layerwise"] = np.float64(float(la.log_marginal_likelihood(prior_precision=pp_layer)))
+
     ld = bl.DiagLaplace(model, "classification")
     ld.fit(loader)
+    out["diag_marglik_pp1"] = np.float64(float(ld.log_marginal_likelihood()))
+    out["diag_marglik_pp07"] = np.float64(float(ld.log_marginal_likelihood(prior_precision=torch.tensor(0.7))))
     out["diag_loss"] = np.float32(float(ld.loss))
     out["diag_H"] = ld.H.detach().numpy().astype(np.float32)
     out["n_data"], out["n_outputs"], out["n_params"] = ld.n_data, ld.n_outputs, ld.n_params

@@ -60,6 +60,12 @@ def test_kron_laplace_fit(path):
         for j, lam in enumerate(ls):
             ref = g[f"kron_eig_{i}_{j}"]
             assert np.abs(lam.cpu().numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30), (i, j)
+    # "next" row 8(f)-1: marginal likelihood on the device from the decomposed factors (eigh + logdet)
+    for pp, key in ((None, "kron_marglik_pp1"), (torch.tensor(0.7), "kron_marglik_pp07"),
+                    (torch.from_numpy(g["kron_prior_layerwise"]), "kron_marglik_layerwise")):
+        got = float(la.log_marginal_likelihood(prior_precision=pp))
+        assert abs(got - float(g[key])) <= 2e-4 * abs(float(g[key])), key
+    la.prior_precision = 1.0
     # torch.utils.data.DataLoader (the reference's loader) gives the same batches
     from torch.utils.data import DataLoader, TensorDataset
     dl = DataLoader(TensorDataset(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"])),
@@ -84,6 +90,9 @@ def test_diag_laplace_fit(path):
     assert rel(la.H.cpu().numpy(), g["diag_H"]) < RTOL
     assert abs(float(la.loss) - float(g["diag_loss"])) <= RTOL * abs(float(g["diag_loss"]))
     assert la.mean.shape[0] == int(g["n_params"])
+    for pp, key in ((None, "diag_marglik_pp1"), (torch.tensor(0.7), "diag_marglik_pp07")):
+        got = float(la.log_marginal_likelihood(prior_precision=pp))
+        assert abs(got - float(g[key])) <= 2e-4 * abs(float(g[key])), key
 
 
 def test_backend_kron_returns_fresh_tensors_and_reference_layout():

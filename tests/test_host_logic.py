@@ -198,6 +198,16 @@ def test_fit_loop_with_oracle_backend_matches_reference(name):
     ld = lg.Laplace(model, "classification", "all", "diag", backend=OracleBackend)
     ld.fit(loader)
     assert rel(ld.H.numpy(), g["diag_H"]) < RTOL
+    # "next" row 8(f)-1: the reference's log marginal likelihood from the decomposed factors
+    def close(a, b):
+        return abs(float(a) - float(b)) <= 2e-4 * abs(float(b))
+    assert close(la.log_marginal_likelihood(), g["kron_marglik_pp1"])
+    assert close(la.log_marginal_likelihood(prior_precision=torch.tensor(0.7)), g["kron_marglik_pp07"])
+    assert close(la.log_marginal_likelihood(prior_precision=torch.from_numpy(g["kron_prior_layerwise"])),
+                 g["kron_marglik_layerwise"])
+    assert close(ld.log_marginal_likelihood(prior_precision=1.0), g["diag_marglik_pp1"])
+    assert close(ld.log_marginal_likelihood(prior_precision=torch.tensor(0.7)), g["diag_marglik_pp07"])
+    la.prior_precision, ld.prior_precision = 1.0, 1.0
     # marginal likelihood identity (laplace tests/test_baselaplace.py:308-384 pattern), diag case
     pp = 0.7
     ld.prior_precision = pp
