@@ -126,6 +126,7 @@ class GraphEngine:
                                       LIKS[likelihood])
         _lib.check(rc, "lgnn_bind_model")
         self._bound = (X, list(weights), list(biases))
+        self._bind_opts = (act, likelihood)
         self.dims = dims
         self.in_dims = [mult * d for d in dims[:-1]]
         self._versions = self._param_versions()
@@ -143,6 +144,10 @@ class GraphEngine:
             raise _lib.HipLibraryError("no model bound")
         v = self._param_versions()
         if v != self._versions:
+            if [p for p, _ in v] != [p for p, _ in self._versions]:
+                # storage replaced (``param.data = ...``, e.g. torch.nn.utils.vector_to_parameters): bind the new pointers
+                X, ws, bs = self._bound
+                self.bind(X, ws, bs, *self._bind_opts)
             self.invalidate()
             self._versions = v
 

@@ -186,6 +186,38 @@ class ParametricLaplace(BaseLaplace):
     def _after_reduce(self):
         pass
 
+    # ---- posterior samples and the sampling ("nn", link_approx="mc") predictive the GNN driver evaluates with
+    # (gnn/marglik_training.py:338-352 -> laplace/baselaplace.py:1183-1199): theta ~ N(mean, P^-1), one full-graph
+    # forward per sample through the HIP engine (the in-place parameter writes invalidate its cache), softmax, mean.
+    def sample(self, n_samples: int = 100, generator: torch.Generator | None = None, eps: torch.Tensor | None = None):
+        """``eps`` (n_samples x n_params standard normal draws) may be passed instead of a generator so that
+        results are reproducible across devices."""
+        if eps is None:
+            eps = torch.randn(n_samples, self.n_params, device=self._device, generator=generator)
+        return self.mean.reshape(1, self.n_params) + self._scale_samples(eps.to(self._device))
+
+    def _scale_samples(self, eps):
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def __call__(self, x, pred_type: str = "nn", link_approx: str = "mc", n_samples: int = 100,
+                 generator: torch.Generator | None = None, eps: torch.Tensor | None = None, **kwargs):
+        if pred_type != "nn" or link_approx != "mc":
+            raise NotImplementedError("only the sampling predictive (pred_type='nn', link_approx='mc') is implemented; "
+                                      "the GLM predictive needs explicit Jacobians (SURVEY.md 8(f)-3)")
+        if self.likelihood != "classification":
+            raise NotImplementedError("classification only")
+        from torch.nn.utils import vector_to_parameters
+        py = 0.0
+        samples = self.sample(n_samples, generator=generator, eps=eps)
+        try:
+            for theta in samples:
+                vector_to_parameters(theta, self.params)
+                py = py + torch.softmax(self.model(x.to(self._device)), dim=-1) / len(samples)
+        finally:
+            vector_to_parameters(self.mean.clone(), self.params)  # the parameters must not alias self.mean afterwards
+        return py
+
     @property
     def log_likelihood(self) -> torch.Tensor:
         """laplace/baselaplace.py:895-922: -H_factor * loss for classification."""
@@ -315,6 +347,9 @@ class KronLaplace(ParametricLaplace):
     def log_det_posterior_precision(self) -> torch.Tensor:
         return self.posterior_precision.logdet()
 
+    def _scale_samples(self, eps):  # laplace/baselaplace.py:1646-1655
+        return self.posterior_precision.bmm(eps, exponent=-0.5).reshape(eps.shape[0], self.n_params)
+
 
 class DiagLaplace(ParametricLaplace):
     _key = ("all", "diag")
@@ -336,6 +371,9 @@ class DiagLaplace(ParametricLaplace):
     @property
     def log_det_posterior_precision(self) -> torch.Tensor:
         return self.posterior_precision.log().sum()
+
+    def _scale_samples(self, eps):  # laplace/baselaplace.py:1912-1919: samples * posterior_scale
+        return eps * (1.0 / self.posterior_precision.sqrt()).reshape(1, self.n_params)
 
 
 class FullLLLaplace(ParametricLaplace):

@@ -194,6 +194,44 @@ class KronDecomposed:
                     ld = ld + torch.log(torch.outer(l1, l2) + delta).sum()
         return ld
 
+    def bmm(self, W: torch.Tensor, exponent: float = -1) -> torch.Tensor:
+        """``self ** exponent @ W`` for ``W`` of shape (batch, params) or (batch, classes, params)
+        (laplace/utils/matrix.py:396-483): per block ``Q (l + delta)^e Q^T w`` resp.
+        ``Q1 ((Q1^T W Q2) * (l1 (x) l2 + delta)^e) Q2^T`` -- invariant to the eigenvector gauge."""
+        if W.ndim == 1:
+            return self._bmm(W.unsqueeze(0).unsqueeze(0), exponent).squeeze()
+        if W.ndim == 2:
+            return self._bmm(W.unsqueeze(1), exponent).squeeze(1)
+        if W.ndim == 3:
+            return self._bmm(W, exponent)
+        raise ValueError("Invalid shape for W")
+
+    def _bmm(self, W: torch.Tensor, exponent: float) -> torch.Tensor:
+        B, K, P = W.size()
+        W = W.reshape(B * K, P)
+        cur, out = 0, []
+        for ls, Qs, delta in zip(self.eigenvalues, self.eigenvectors, self.deltas):
+            if len(ls) == 1:
+                Q, lam = Qs[0], ls[0]
+                p = len(lam)
+                scale = torch.pow(lam + delta, exponent).reshape(-1, 1)
+                Wp = W[:, cur:cur + p].T
+                out.append((Q @ (scale * (Q.T @ Wp))).T)
+            else:
+                (Q1, Q2), (l1, l2) = Qs, ls
+                p_in, p_out = len(l1), len(l2)
+                p = p_in * p_out
+                if self.damping:
+                    ds = torch.sqrt(delta)
+                    scale = torch.pow(torch.outer(l1 + ds, l2 + ds), exponent).unsqueeze(0)
+                else:
+                    scale = torch.pow(torch.outer(l1, l2) + delta, exponent).unsqueeze(0)
+                Wp = W[:, cur:cur + p].reshape(B * K, p_in, p_out)
+                Wp = Q1 @ ((Q1.T @ Wp @ Q2) * scale) @ Q2.T
+                out.append(Wp.reshape(B * K, p))
+            cur += p
+        return torch.cat(out, dim=1).reshape(B, K, P)
+
     def to_matrix(self, exponent: float = 1) -> torch.Tensor:
         blocks = []
         for Qs, ls, delta in zip(self.eigenvectors, self.eigenvalues, self.deltas):

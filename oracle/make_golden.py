@@ -121,8 +121,24 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
     out["kron_prior_layerwise"] = pp_layer.numpy()
     out["kron_marglik_layerwise"] = np.float64(float(la.log_marginal_likelihood(prior_precision=pp_layer)))
 
+    # posterior samples + the sampling predictive the GNN driver evaluates with (gnn/marglik_training.py:338-352):
+    # fixed standard-normal draws `eps` replace torch.randn so that the result is reproducible on any device
+    la.prior_precision = 1.0
+    S = 4
+    eps = torch.from_numpy(np.random.default_rng(seed).standard_normal((S, la.n_params)).astype(np.float32))
+    eval_idx = train_idx[:10].clone()
+    out["pred_eps"], out["pred_idx"] = eps.numpy(), eval_idx.numpy()
+    k_samples = la.mean.reshape(1, -1) + la.posterior_precision.bmm(eps, exponent=-0.5).reshape(S, -1)
+    out["kron_samples"] = k_samples.detach().numpy().astype(np.float32)
+    la.sample = lambda n_samples=S, generator=None: k_samples.detach()
+    out["kron_nn_py"] = la._nn_predictive_classification(eval_idx, n_samples=S).detach().numpy().astype(np.float32)
+
     ld = bl.DiagLaplace(model, "classification")
     ld.fit(loader)
+    d_samples = ld.mean.reshape(1, -1) + eps * ld.posterior_scale.reshape(1, -1)
+    out["diag_samples"] = d_samples.detach().numpy().astype(np.float32)
+    ld.sample = lambda n_samples=S, generator=None: d_samples.detach()
+    out["diag_nn_py"] = ld._nn_predictive_classification(eval_idx, n_samples=S).detach().numpy().astype(np.float32)
     out["diag_marglik_pp1"] = np.float64(float(ld.log_marginal_likelihood()))
     out["diag_marglik_pp07"] = np.float64(float(ld.log_marginal_likelihood(prior_precision=torch.tensor(0.7))))
     out["diag_loss"] = np.float32(float(ld.loss))

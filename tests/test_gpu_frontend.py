@@ -95,6 +95,33 @@ def test_diag_laplace_fit(path):
         assert abs(got - float(g[key])) <= 2e-4 * abs(float(g[key])), key
 
 
+@pytest.mark.parametrize("path", CASES, ids=IDS)
+def test_posterior_samples_and_sampling_predictive(path):
+    """"next" row 8(f)-2 on the GPU: reference-generated samples / Monte-Carlo predictive on fixed draws; every
+    sample's forward runs through the HIP engine, which must follow the parameter storage swaps of
+    torch.nn.utils.vector_to_parameters."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(path)
+    model = model_from_golden(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(),
+                                  batch_size=int(g["batch_size"]))
+    eps, idx = torch.from_numpy(g["pred_eps"]).cuda(), torch.from_numpy(g["pred_idx"]).cuda()
+    logits_before = model(idx).clone()
+    for structure in ("kron", "diag"):
+        la = lg.Laplace(model, "classification", "all", structure)
+        la.fit(loader)
+        assert rel(la.sample(eps=eps).cpu().numpy(), g[structure + "_samples"]) < 5e-4
+        py = la(idx, pred_type="nn", link_approx="mc", n_samples=len(eps), eps=eps)
+        assert np.abs(py.cpu().numpy() - g[structure + "_nn_py"]).max() < 5e-5
+        # mean restored, engine follows it back
+        assert torch.equal(model(idx), logits_before)
+        la.fit(loader)  # and a refit after predicting still sees the MAP weights
+        py2 = la(idx, n_samples=len(eps), eps=eps)
+        assert torch.allclose(py, py2, atol=5e-5)  # refit sums with float atomics: last-bit differences
+    model.engine.check_async_errors()
+
+
 def test_backend_kron_returns_fresh_tensors_and_reference_layout():
     """CurvatureInterface contract (laplace/curvature/curvlinops.py:55-108): fresh tensors per call,
     [[B,A],[B]] per Linear, A rescaled by M/N, callers may mutate the result."""

@@ -221,6 +221,55 @@ def test_fit_loop_with_oracle_backend_matches_reference(name):
     assert abs(float(la.log_marginal_likelihood()) - expect) < 1e-3 * abs(expect)
 
 
+@pytest.mark.parametrize("name", ["gcn_small_1batch_s0", "gcn_mid_3batch_sym_s1", "sage_small_3batch_s1"])
+def test_posterior_samples_and_sampling_predictive_match_reference(name):
+    """"next" row 8(f)-2: theta = mean + P^-1/2 eps and the Monte-Carlo softmax average the driver evaluates with
+    (gnn/marglik_training.py:338-352 -> laplace/baselaplace.py:1183-1199, :1646-1655, :1912-1919); the golden
+    values were computed by the reference's own code on the same fixed draws ``eps``."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = _cpu_model(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"]),
+                                  int(g["batch_size"]))
+    eps, idx = torch.from_numpy(g["pred_eps"]), torch.from_numpy(g["pred_idx"])
+    before = [p.detach().clone() for p in model.parameters()]
+    for structure, key in (("kron", "kron"), ("diag", "diag")):
+        la = lg.Laplace(model, "classification", "all", structure, backend=OracleBackend)
+        la.fit(loader)
+        assert rel(la.sample(eps=eps).numpy(), g[key + "_samples"]) < 2e-4
+        py = la(idx, pred_type="nn", link_approx="mc", n_samples=len(eps), eps=eps)
+        assert np.abs(py.numpy() - g[key + "_nn_py"]).max() < 2e-5
+        assert torch.allclose(py.sum(-1), torch.ones(len(idx)), atol=1e-5)
+        # the mean is restored and the parameters do not alias it
+        for p, b in zip(model.parameters(), before):
+            assert torch.equal(p.detach(), b) and p.data_ptr() != la.mean.data_ptr()
+        # generator path: reproducible, right shape, centred on the mean for many draws
+        gen = torch.Generator().manual_seed(3)
+        s1 = la.sample(64, generator=gen)
+        s2 = la.sample(64, generator=torch.Generator().manual_seed(3))
+        assert s1.shape == (64, la.n_params) and torch.equal(s1, s2)
+        with pytest.raises(NotImplementedError):
+            la(idx, pred_type="glm", link_approx="probit")
+
+
+def test_kron_decomposed_bmm_matches_dense_power():
+    """laplace tests/test_matrix.py bmm pattern: (Q diag(l + delta)^e Q^T) W against the dense matrix, for
+    1-, 2- and 3-dimensional W and exponents -1, -1/2, 1."""
+    K = _rand_kron(2)
+    dec = K.decompose() + torch.tensor(0.3)
+    P = dec.to_matrix().shape[0]
+    gen = torch.Generator().manual_seed(0)
+    for e in (-1.0, -0.5, 1.0):
+        M = dec.to_matrix(exponent=e).double()
+        W2 = torch.randn(5, P, generator=gen)
+        assert rel(dec.bmm(W2, exponent=e).numpy(), (W2.double() @ M.T).float().numpy()) < 1e-4
+        W3 = torch.randn(3, 4, P, generator=gen)
+        assert rel(dec.bmm(W3, exponent=e).numpy(), (W3.double() @ M.T).float().numpy()) < 1e-4
+        w1 = torch.randn(P, generator=gen)
+        assert rel(dec.bmm(w1, exponent=e).numpy(), (M @ w1.double()).float().numpy()) < 1e-4
+    with pytest.raises(ValueError):
+        dec.bmm(torch.zeros(1, 1, 1, P))
+
+
 def test_override_false_triples_and_override_true_is_idempotent():
     """tests/test_baselaplace.py:387-426 pattern: fit, fit(override=False), fit(override=False)."""
     g = np.load(os.path.join(GOLDEN, "gcn_small_1batch_s0.npz"))
