@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblaplace_gnn_hip.so")
+# LGNN_LIB_DIR: developer A/B builds (make OUT_DIR=../lib_<variant>); the default is the in-tree lib/
+LIB_PATH = os.path.join(_HERE, os.environ.get("LGNN_LIB_DIR", "lib"), "liblaplace_gnn_hip.so")
 
 KIND_GCN, KIND_SAGE = 0, 1
 ACT_RELU, ACT_TANH = 0, 1

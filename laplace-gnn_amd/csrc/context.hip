@@ -187,7 +187,7 @@ extern "C" void lgnn_destroy(lgnn_ctx* h) {
   if (!h) return;
   (void)hipDeviceSynchronize();
   DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
-                    &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.planes_a,
+                    &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult, &h->ws.planes_a,
                     &h->ws.planes_b, &h->ws.misc, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (DevBuf* b : bufs) b->release();
   for (int l = 0; l < kMaxLayers; ++l) {
@@ -247,7 +247,7 @@ extern "C" int64_t lgnn_device_bytes(const lgnn_ctx* h) {
   if (!h) return -1;
   size_t t = 0;
   const DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
-                          &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->ws.pos, &h->ws.seeds, &h->ws.probs,
+                          &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult,
                           &h->ws.planes_a, &h->ws.planes_b, &h->ws.misc, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (const DevBuf* b : bufs) t += b->bytes;
   for (int l = 0; l < kMaxLayers; ++l)

@@ -4,8 +4,8 @@
 //       y[r, :] = epi( self[r, :] + sum_j val[j] * in_p[col[j], :] )      r in block   (gather, 16 B / lane)
 //       S      += y^T y                                                     (fp32 MFMA, registers)
 //
-// Wave-specialised, one 512-thread workgroup per CU: waves 0-3 gather, waves 4-7 run the MFMAs; the
-// hardware places one wave of each kind on every SIMD.  The row block is double buffered in LDS
+// Wave-specialised, one 512-thread workgroup per CU: 4 waves gather (two on each of SIMD 0/1), 4 waves run
+// the MFMAs (two on each of SIMD 2/3).  The row block is double buffered in LDS
 // (2 x 32 KiB), one barrier per block: while the MFMA waves contract block i-1 the gather waves build
 // block i, so the kernel runs at max(gather, MFMA) per block and the gather waves keep all their
 // registers for loads in flight (16 neighbour rows = 16 KiB per wave).
@@ -132,7 +132,12 @@ __device__ __forceinline__ void mfma_wave(const FusedArgs& a, const float* __res
 __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
   __shared__ float tile[2][KT256][256];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Roles by SIMD: the 8 waves of a workgroup are dealt round-robin to the CU's 4 SIMDs, so hardware waves
+  // {0,1,4,5} (SIMD 0/1) gather and {2,3,6,7} (SIMD 2/3) run the MFMAs.  A gather wave and an fp32-MFMA wave on
+  // the SAME SIMD compete for its issue slot (every gather VALU instruction then costs twice); apart they do
+  // not: 4.43 -> 3.90 ms per 20-plane launch.  `wave` = role index (0-3 gather, 4-7 MFMA).
+  const int hwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = ((hwave & 2) ? 4 : 0) + (hwave & 1) + ((hwave >> 2) << 1);
   const int64_t blocks_per_plane = (a.nrows + KT256 - 1) / KT256;
   const int64_t nblocks = blocks_per_plane * a.nplanes;
   const int64_t nb = nblocks > int64_t(blockIdx.x) ? (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;

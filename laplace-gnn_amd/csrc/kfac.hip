@@ -49,59 +49,75 @@ __device__ __forceinline__ float wave_sum(float v) {
 //   upstream   : V[k,c] = sqrt(p_c) (d_kc - p_k)                       (kfac_utils.py:122-126)
 // written as seeds[first][c][k] (+=: duplicated node ids accumulate like x[x_indices]' backward).
 // loss += logsumexp(f) - f[y]   (CrossEntropyLoss(reduction='sum'))
-__global__ __launch_bounds__(64) void seed_kernel(const float* __restrict__ logits, int64_t C,
-                                                  const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
-                                                  int64_t M, int64_t N, const int32_t* __restrict__ pos, int fork_exact,
-                                                  float* __restrict__ seeds, float* __restrict__ probs,
-                                                  float* __restrict__ loss, int* __restrict__ bad) {
+__global__ __launch_bounds__(256) void seed_kernel(const float* __restrict__ logits, int64_t C,
+                                                   const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
+                                                   int64_t M, int64_t N, const int32_t* __restrict__ pos, int fork_exact,
+                                                   float* __restrict__ seeds, float* __restrict__ probs,
+                                                   float* __restrict__ loss, int* __restrict__ bad,
+                                                   int32_t* __restrict__ mult) {
   extern __shared__ float sm[];
-  float* f_s = sm;
-  float* p_s = sm + C;
-  const int lane = threadIdx.x;
-  const int64_t m = blockIdx.x;
-  const int64_t n = idx[m];
-  if (n < 0 || n >= N) return;  // flagged by mark_batch_kernel
-  float mx = -INFINITY;
-  for (int64_t k = lane; k < C; k += 64) {
-    const float v = logits[n * C + k];
-    f_s[k] = v;
-    mx = fmaxf(mx, v);
+  __shared__ float loss_part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* f_s = sm + size_t(wave) * 2 * C;
+  float* p_s = f_s + C;
+  float loss_acc = 0.f;  // lane 0: this wave's share of the batch loss (one atomic per workgroup, not per sample)
+  for (int64_t m = int64_t(blockIdx.x) * 4 + wave; m < M; m += int64_t(gridDim.x) * 4) {
+    const int64_t n = idx[m];
+    if (n < 0 || n >= N) continue;  // flagged by mark_batch_kernel
+    float mx = -INFINITY;
+    for (int64_t k = lane; k < C; k += 64) {
+      const float v = logits[n * C + k];
+      f_s[k] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int64_t k = lane; k < C; k += 64) {
+      const float e = expf(f_s[k] - mx);
+      p_s[k] = e;
+      se += e;
+    }
+    se = wave_sum(se);
+    const float inv = 1.0f / se;
+    float mb = 0.f;
+    for (int64_t k = lane; k < C; k += 64) {
+      const float p = p_s[k] * inv;
+      p_s[k] = p;
+      if (probs) probs[m * C + k] = p;
+      mb += p * f_s[k];
+    }
+    mb = wave_sum(mb);
+    // f_s / p_s are read across lanes below: same wave, LDS executes a wave's operations in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0 && loss) {
+      const int64_t yy = y[m];
+      if (yy < 0 || yy >= C) *bad = 2;
+      else loss_acc += logf(se) + mx - f_s[yy];
+    }
+    if (lane == 0 && mult) atomicAdd(&mult[pos[n]], 1);  // how often the node occurs in the batch, kept at its first place
+    if (seeds) {
+      const int64_t first = pos[n];
+      float* __restrict__ dst = seeds + first * C * C;
+      const int64_t CC = C * C;
+      for (int64_t q = lane; q < CC; q += 64) {
+        const int64_t c = q / C, k = q - c * C;
+        const float pc = p_s[c], pk = p_s[k];
+        const float d = (k == c) ? 1.f : 0.f;
+        float v;
+        if (fork_exact) v = sqrtf(pc) * (d - pk * (1.f + f_s[k] - mb) + 0.5f * (d - pk) * (f_s[c] - mb));
+        else v = sqrtf(pc) * (d - pk);
+        atomicAdd(&dst[q], v);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the next sample overwrites f_s / p_s
   }
-  mx = wave_max(mx);
-  float se = 0.f;
-  for (int64_t k = lane; k < C; k += 64) {
-    const float e = expf(f_s[k] - mx);
-    p_s[k] = e;
-    se += e;
-  }
-  se = wave_sum(se);
-  const float inv = 1.0f / se;
-  float mb = 0.f;
-  for (int64_t k = lane; k < C; k += 64) {
-    const float p = p_s[k] * inv;
-    p_s[k] = p;
-    if (probs) probs[m * C + k] = p;
-    mb += p * f_s[k];
-  }
-  mb = wave_sum(mb);
-  __syncthreads();
-  if (lane == 0 && loss) {
-    const int64_t yy = y[m];
-    if (yy < 0 || yy >= C) *bad = 2;
-    else atomicAdd(loss, logf(se) + mx - f_s[yy]);
-  }
-  if (!seeds) return;
-  const int64_t first = pos[n];
-  float* __restrict__ dst = seeds + first * C * C;
-  const int64_t CC = C * C;
-  for (int64_t q = lane; q < CC; q += 64) {
-    const int64_t c = q / C, k = q - c * C;
-    const float pc = p_s[c], pk = p_s[k];
-    const float d = (k == c) ? 1.f : 0.f;
-    float v;
-    if (fork_exact) v = sqrtf(pc) * (d - pk * (1.f + f_s[k] - mb) + 0.5f * (d - pk) * (f_s[c] - mb));
-    else v = sqrtf(pc) * (d - pk);
-    atomicAdd(&dst[q], v);
+  if (loss) {
+    if (lane == 0) loss_part[wave] = loss_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (loss_part[0] + loss_part[1]) + (loss_part[2] + loss_part[3]));
   }
 }
 
@@ -147,6 +163,275 @@ __global__ void seed_spmm_kernel(const int32_t* __restrict__ rowptr, const int32
     g[(c * N + n) * C + k] = any ? buf[q] : 0.f;
   }
   if (lane == 0) active[n] = any ? 1 : 0;
+}
+
+
+// active[v] = 1 for every node v that has a batch node among its P^T neighbours, i.e. every column of the P rows of
+// the batch nodes: these are the only rows of the top-layer gradient that are not identically zero.  One wave per sample.
+__global__ __launch_bounds__(256) void mark_active_kernel(const int64_t* __restrict__ idx, int64_t M, int64_t N,
+                                                          const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ col, uint8_t* __restrict__ active) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int64_t n = idx[m];
+  if (n < 0 || n >= N) return;  // flagged by mark_batch_kernel
+  const int32_t e = rowptr[n + 1];
+  for (int32_t p = rowptr[n] + lane; p < e; p += 64) active[col[p]] = 1;
+}
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// GCN top layer over the ACTIVE nodes only, with the top-layer Gram fused in:
+//     G_n[c][k] = sum_{v in row n of P^T, v in batch} val * V_v[k, c]                 (c in [cb, ce))
+//     g[c][n][:] = G_n[c][:]                        (class-major planes for the backward GEMM; skipped when !g)
+//     S        += G_n^T G_n = sum_c g_c[n]^T g_c[n]  (v_mfma_f32_16x16x4_f32 on the LDS copy of G_n)
+// One wave per active node, persistent: the NBLK*(NBLK+1)/2 upper 16x16 tiles of S stay in registers, are reduced
+// through LDS once per workgroup and leave with one float atomic per element.
+//
+// The seed block V_v of a batch sample is never materialised: it is diagonal plus rank two,
+//     fork exact : V[k,c] = sqrt(p_c) [d_kc - p_k (1 + f_k - mbar) + 1/2 (d_kc - p_k)(f_c - mbar)]
+//                         = alpha_c d_kc - beta_c u_k - gamma_c p_k
+//     upstream   : V[k,c] = sqrt(p_c) (d_kc - p_k)                      (gamma = 0, u = p)
+// so the wave loads the sample's C probabilities and logits (320 B instead of the 6.4 KB block), lane c keeps
+// (alpha, beta, gamma)_c, lane k keeps (u, p)_k, and row c of G_n is built by lane c from v_readlane broadcasts,
+// two columns per step.  The kernel is issue bound (a wave64 VALU instruction occupies its SIMD for 4 cycles), which
+// is why the instruction count per node, not the bytes, is what the layout below minimises.
+// Before: seed blocks written by seed_kernel (64 MB per arxiv-shaped batch), read back 1.5 times per active node,
+// planes for all N rows to HBM, a separate Gram kernel over them: 0.14 + 0.54 + 0.62 ms per batch.
+template <int NBLK>
+__global__ __launch_bounds__(1024) void seed_spmm_gram_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, int64_t N, int C,
+    const int32_t* __restrict__ pos, const float* __restrict__ probs, const float* __restrict__ logits,
+    const int32_t* __restrict__ mult, int fork_exact, float* __restrict__ g, const int32_t* __restrict__ act_list,
+    const int32_t* __restrict__ act_count, int cb, int ce, float* __restrict__ scratch, int ldb, int debug) {
+  constexpr int NT = NBLK * (NBLK + 1) / 2;
+  extern __shared__ float sm[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int nwaves = blockDim.x >> 6;
+  const int nrows = ce - cb, rp = (nrows + 3) & ~3;
+  // buf[r][k], r = c - cb < rp, k < ldb (>= C rounded up to 8; == 2 mod 4 so that the 16 lanes of an MFMA operand read and
+  // the 8-byte row writes of 16 consecutive lanes fall into distinct banks).  Rows >= nrows stay zero; columns >= C are
+  // masked when read.
+  float* __restrict__ buf = sm + size_t(wave) * rp * ldb;
+  for (int q = lane; q < rp * ldb; q += 64) buf[q] = 0.f;
+  const bool rowok = lane >= cb && lane < ce;
+  float* __restrict__ rowp = buf + (rowok ? lane - cb : 0) * ldb;
+  bool colok[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) colok[b] = b * 16 + (lane & 15) < C;
+  // plane stores: 16 bytes per lane when C % 4 == 0, else 4
+  const bool vec = (C & 3) == 0;
+  const int cw = vec ? C >> 2 : C;                // stored units per row
+  const int nunits = nrows * cw;
+  const int step_r = 64 / cw, step_k = 64 % cw, r0 = lane / cw, k0 = lane % cw;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int total = *act_count;
+  // Node j of this wave is act_list[gw + j * S].  list -> rowptr -> col -> pos is a chain of dependent loads; it is
+  // taken off the critical path: list and rowptr for 64 of the wave's nodes at once (one per lane), col/val two nodes
+  // ahead, pos one node ahead.
+  const int gw = blockIdx.x * nwaves + wave, S = gridDim.x * nwaves;
+  const int cnt = gw < total ? (total - gw + S - 1) / S : 0;
+  for (int c0 = 0; c0 < cnt; c0 += 64) {
+    const int cn = min(64, cnt - c0);
+    int32_t n_l = 0, s_l = 0, e_l = 0;
+    if (lane < cn) {
+      n_l = act_list[gw + int64_t(c0 + lane) * S];
+      s_l = rowptr[n_l];
+      e_l = rowptr[n_l + 1];
+    }
+    auto load_entries = [&](int j, int32_t& cj, float& vj) {
+      const int jj = min(j, 63);
+      const int32_t sj = __builtin_amdgcn_readlane(s_l, jj), ej = __builtin_amdgcn_readlane(e_l, jj);
+      cj = -1; vj = 0.f;
+      if (j < cn && sj + lane < ej) { cj = col[sj + lane]; vj = val[sj + lane]; }
+    };
+    int32_t cA, cB, cC, mpA, mpB;
+    float vA, vB, vC;
+    load_entries(0, cA, vA);
+    mpA = cA >= 0 ? pos[cA] : INT32_MAX;
+    load_entries(1, cB, vB);
+    for (int j = 0; j < cn; ++j) {
+      mpB = cB >= 0 ? pos[cB] : INT32_MAX;  // node j + 1
+      load_entries(j + 2, cC, vC);           // node j + 2
+      const int64_t n = __builtin_amdgcn_readlane(n_l, j);
+      const int32_t s = __builtin_amdgcn_readlane(s_l, j), e = __builtin_amdgcn_readlane(e_l, j);
+      bool any = false;
+      for (int32_t base = s; base < e; base += 64) {
+        int32_t mp = mpA, cu = cA;
+        float v = vA;
+        if (base > s) {  // rows with more than 64 stored entries: the rest is not prefetched
+          const int32_t p = base + lane;
+          mp = INT32_MAX; v = 0.f; cu = 0;
+          if (p < e) { cu = col[p]; mp = pos[cu]; v = val[p]; }
+        }
+        unsigned long long mask = __ballot(mp != INT32_MAX);
+        while (mask) {
+          const int b = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const int64_t mm = __shfl(mp, b);
+          const int64_t u = __shfl(cu, b);
+          float pk = 0.f, fk = 0.f;
+          if (lane < C) { pk = probs[mm * C + lane]; fk = logits[u * C + lane]; }
+          // a node listed t times in the batch counts t times (the dense reference's x[x_indices] backward)
+          const float vv = __shfl(v, b) * float(mult[mm]);
+          const float mb = wave_sum(pk * fk);  // same summation order as seed_kernel
+          const float sp = sqrtf(pk), t = fk - mb;
+          const float alpha = fork_exact ? sp * (1.f + 0.5f * t) : sp;
+          const float nbeta = -sp, ngamma = fork_exact ? -0.5f * sp * t : 0.f;
+          int uvi = __float_as_int(vv * (fork_exact ? pk * (1.f + t) : pk));
+          int pvi = __float_as_int(fork_exact ? vv * pk : 0.f);
+          // Both are read with v_readlane (which ignores EXEC) inside the rowok region below, from lanes that are not
+          // part of it: pin their computation here, for all lanes, so that it is not sunk into that region.
+          asm volatile("" : "+v"(uvi), "+v"(pvi));
+          // 4 column pairs per trip, no guards inside (ldb covers C rounded up to 8; lanes >= C hold zeros); the
+          // readlanes are convergent, so only constant trip counts unroll
+          if (rowok) {
+            if (!any) {
+              for (int k8 = 0; k8 < C; k8 += 8) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                  const int k = k8 + 2 * w;
+                  const float u0 = __int_as_float(__builtin_amdgcn_readlane(uvi, k));
+                  const float u1 = __int_as_float(__builtin_amdgcn_readlane(uvi, k + 1));
+                  const float p0 = __int_as_float(__builtin_amdgcn_readlane(pvi, k));
+                  const float p1 = __int_as_float(__builtin_amdgcn_readlane(pvi, k + 1));
+                  *reinterpret_cast<float2*>(rowp + k) = make_float2(nbeta * u0 + ngamma * p0, nbeta * u1 + ngamma * p1);
+                }
+              }
+            } else {
+              for (int k8 = 0; k8 < C; k8 += 8) {
+                float2 o[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) o[w] = *reinterpret_cast<float2*>(rowp + k8 + 2 * w);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                  const int k = k8 + 2 * w;
+                  const float u0 = __int_as_float(__builtin_amdgcn_readlane(uvi, k));
+                  const float u1 = __int_as_float(__builtin_amdgcn_readlane(uvi, k + 1));
+                  const float p0 = __int_as_float(__builtin_amdgcn_readlane(pvi, k));
+                  const float p1 = __int_as_float(__builtin_amdgcn_readlane(pvi, k + 1));
+                  o[w].x += nbeta * u0 + ngamma * p0; o[w].y += nbeta * u1 + ngamma * p1;
+                  *reinterpret_cast<float2*>(rowp + k) = o[w];
+                }
+              }
+            }
+          }
+          if (rowok) rowp[lane] += vv * alpha;  // the diagonal term, column k = c
+          any = true;
+        }
+      }
+      mpA = mpB; cA = cB; vA = vB; cB = cC; vB = vC;
+      if (!any) continue;  // cannot happen for a listed node; keeps the tile well defined regardless
+      // the other lanes' LDS writes are read below: same wave, LDS executes a wave's operations in order
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (g && debug != 1) {
+        int r = r0, k = k0;
+        float* __restrict__ gn = g + (int64_t(cb) * N + n) * C;
+        const int64_t plane = N * C;
+        for (int qb = lane; qb < nunits; qb += 64 * 4) {
+          float4 t4[4];
+          int64_t off[4];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const bool ok = qb + 64 * w < nunits;
+            if (vec) {
+              const float* src = buf + r * ldb + 4 * k;
+              const float2 lo = ok ? *reinterpret_cast<const float2*>(src) : make_float2(0.f, 0.f);
+              const float2 hi = ok ? *reinterpret_cast<const float2*>(src + 2) : make_float2(0.f, 0.f);
+              t4[w] = make_float4(lo.x, lo.y, hi.x, hi.y);
+              off[w] = r * plane + 4 * k;
+            } else {
+              t4[w].x = ok ? buf[r * ldb + k] : 0.f;
+              off[w] = r * plane + k;
+            }
+            r += step_r; k += step_k;
+            if (k >= cw) { k -= cw; ++r; }
+          }
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            if (qb + 64 * w < nunits) {
+              if (vec) *reinterpret_cast<float4*>(gn + off[w]) = t4[w];
+              else gn[off[w]] = t4[w].x;
+            }
+          }
+        }
+      }
+      const float* __restrict__ xb = buf + (lane >> 4) * ldb + (lane & 15);
+      for (int kk = 0; kk < (debug == 2 ? 0 : rp); kk += 4) {
+        float x[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) x[b] = colok[b] ? xb[kk * ldb + b * 16] : 0.f;
+        int t = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+          for (int bj = bi; bj < NBLK; ++bj, ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[bi], x[bj], acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  // workgroup reduction of the register tiles through LDS, then one atomic per upper-triangular element
+  __syncthreads();
+  float* __restrict__ red = sm;  // NT * 256 floats (the launcher sizes the allocation for it)
+  for (int q = threadIdx.x; q < NT * 256; q += blockDim.x) red[q] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(&red[t * 256 + (4 * (lane >> 4) + r) * 16 + (lane & 15)], acc[t][r]);
+  __syncthreads();
+  for (int q = threadIdx.x; q < NT * 256; q += blockDim.x) {
+    const int t = q >> 8, ii = (q >> 4) & 15, jj = q & 15;
+    int bi = 0, bj = 0, tt = t;  // t -> (bi <= bj)
+    for (bi = 0; bi < NBLK; ++bi) {
+      if (tt < NBLK - bi) { bj = bi + tt; break; }
+      tt -= NBLK - bi;
+    }
+    const int i = bi * 16 + ii, j = bj * 16 + jj;
+    if (i <= j && j < C && debug != 3) atomicAdd(&scratch[int64_t(i) * C + j], red[q]);
+  }
+}
+
+template <int NBLK>
+int seed_spmm_gram_launch(lgnn_ctx* h, bool fork_exact, float* g, int64_t cb, int64_t ce, float* scratch,
+                          hipStream_t s) {
+  const int C = int(h->dims[h->L]);
+  constexpr int NT = NBLK * (NBLK + 1) / 2;
+  const int rp = (int(ce - cb) + 3) & ~3;
+  const int ldb = ((C + 7) & ~7) + 2;  // rows hold C rounded up to 8 columns; == 2 mod 4 keeps the LDS banks apart
+  const size_t per_wave = size_t(rp) * ldb * 4;
+  const int waves = int(std::max<size_t>(1, std::min<size_t>(16, (150 * 1024) / per_wave)));
+  // + 64 floats: an MFMA operand read of the last row may run past it (those lanes are masked)
+  const size_t smem = std::max(per_wave * waves + 256, size_t(NT) * 256 * 4);
+  LGNN_REQUIRE(smem <= 158 * 1024, "too many classes for the seed SpMM kernel (use class ranges)");
+  static bool attr_set = false;  // more than 64 KiB of dynamic LDS needs an explicit opt-in
+  if (!attr_set) {
+    LGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&seed_spmm_gram_kernel<NBLK>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    attr_set = true;
+  }
+  const int per_cu = int(std::max<size_t>(1, std::min<size_t>(2048 / (64 * waves), (158 * 1024) / smem)));
+  int debug = 0;
+#ifdef LGNN_DEV  // make DEV=1: ablation switches (1 no plane stores, 2 no MFMA, 3 no global atomics)
+  if (const char* dbg = getenv("LGNN_SEED_DEBUG")) debug = atoi(dbg);
+#endif
+  hipLaunchKernelGGL(seed_spmm_gram_kernel<NBLK>, dim3(unsigned(256 * per_cu)), dim3(64 * waves), smem, s, h->PT.rowptr,
+                     h->PT.col, h->PT.val, h->N, C, h->ws.pos.as<int32_t>(), h->ws.probs.as<float>(),
+                     h->fc.out.as<float>(), h->ws.mult.as<int32_t>(), fork_exact ? 1 : 0, g,
+                     h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(), int(cb), int(ce), scratch, ldb, debug);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 // values of P^T with the columns of all-zero source rows removed: the fused SpMM issues no load for them
@@ -198,15 +483,19 @@ int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bo
   hipLaunchKernelGGL(mark_batch_kernel, dim3(unsigned(cdiv(M, 256))), dim3(256), 0, s, idx, M, N,
                      h->ws.pos.as<int32_t>(), bad);
   LGNN_CALL(h->ws.probs.reserve(size_t(M) * C * 4));
+  LGNN_CALL(h->ws.mult.reserve(size_t(M) * 4));
+  LGNN_HIP_CHECK(hipMemsetAsync(h->ws.mult.p, 0, size_t(M) * 4, s));
   float* seeds = nullptr;
   if (want_seeds) {
     LGNN_CALL(h->ws.seeds.reserve(size_t(M) * C * C * 4));
     LGNN_HIP_CHECK(hipMemsetAsync(h->ws.seeds.p, 0, size_t(M) * C * C * 4, s));
     seeds = h->ws.seeds.as<float>();
   }
-  hipLaunchKernelGGL(seed_kernel, dim3(unsigned(M)), dim3(64), size_t(2 * C) * 4, s, h->fc.out.as<float>(), C, idx,
+  LGNN_REQUIRE(8 * C * 4 <= 60 * 1024, "too many classes for the seed kernel");
+  hipLaunchKernelGGL(seed_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M, 4), 2048))), dim3(256), size_t(8 * C) * 4, s,
+                     h->fc.out.as<float>(), C, idx,
                      static_cast<const int64_t*>(y), M, N, h->ws.pos.as<int32_t>(), fork_exact ? 1 : 0, seeds,
-                     h->ws.probs.as<float>(), loss_out, bad);
+                     h->ws.probs.as<float>(), loss_out, bad, h->ws.mult.as<int32_t>());
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -237,7 +526,11 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   const bool no_fuse = (flags & LGNN_FLAG_NO_FUSE) != 0;
   LGNN_REQUIRE(M < INT32_MAX, "batch too large");
 
-  LGNN_CALL(batch_prologue(h, idx, y, M, true, (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0, first ? loss_out : nullptr, s));
+  const bool fork_exact = (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0;
+  // GCN, fused path: the top-layer kernel rebuilds each sample's C x C seed block from its probabilities and logits,
+  // so the blocks are never written (64 MB per arxiv-shaped batch); every other path reads them from ws.seeds
+  const bool seeds_on_the_fly = h->kind == LGNN_KIND_GCN && !no_fuse && C <= 64;
+  LGNN_CALL(batch_prologue(h, idx, y, M, !seeds_on_the_fly, fork_exact, first ? loss_out : nullptr, s));
 
   // A_l += in_l^T in_l / n_train   (kfac.py:870 divides by M, curvlinops.py:46-53 multiplies by M/N)
   for (int l = 0; first && l < L; ++l)
@@ -256,15 +549,40 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
     gtop = h->ws.top.as<float>();
   }
   LGNN_CALL(h->ws.active.reserve(size_t(N)));
+  bool have_act_list = false;
   if (h->kind == LGNN_KIND_GCN) {
     const int64_t nq = (ce - cb) * C;
-    int waves = int(std::max<int64_t>(1, std::min<int64_t>(4, (48 * 1024) / (nq * 4))));
-    LGNN_REQUIRE(nq * 4 <= 60 * 1024, "too many classes for the seed SpMM kernel (use class ranges)");
-    hipLaunchKernelGGL(seed_spmm_kernel, dim3(unsigned(cdiv(N, waves))), dim3(64 * waves), size_t(waves) * nq * 4, s,
-                       h->PT.rowptr, h->PT.col, h->PT.val, N, C, h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), gtop,
-                       h->ws.active.as<uint8_t>(), cb, ce);
-    LGNN_HIP_CHECK(hipGetLastError());
-    LGNN_CALL(launch_gram(gtop + cb * N * C, C, (ce - cb) * N, C, h->ws.gram_scratch[L - 1].as<float>(), s));
+    if (seeds_on_the_fly) {
+      // active rows first (columns of the batch nodes' P rows), then one pass over those rows only
+      LGNN_HIP_CHECK(hipMemsetAsync(h->ws.active.p, 0, size_t(N), s));
+      hipLaunchKernelGGL(mark_active_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, idx, M, N, h->P.rowptr,
+                         h->P.col, h->ws.active.as<uint8_t>());
+      LGNN_HIP_CHECK(hipGetLastError());
+      LGNN_CALL(h->ws.act_list.reserve(size_t(N) * 4));
+      LGNN_CALL(h->ws.act_count.reserve(64));
+      LGNN_CALL(compact_flags(h->ws.active.as<uint8_t>(), N, h->ws.act_list.as<int32_t>(),
+                              h->ws.act_count.as<int32_t>(), h->ws.select_tmp, s));
+      have_act_list = true;
+      float* gplanes = L > 1 ? gtop : nullptr;  // a single-layer model needs the Gram only
+      if (L > 1 && !fused_supported(h->dims[L - 1], h->dims[L - 1], N * h->dims[L - 1], gtop))
+        // the unfused lower path reads every row of the planes: the rows this kernel skips must be zero
+        LGNN_HIP_CHECK(hipMemsetAsync(gtop + cb * N * C, 0, size_t(N) * nq * 4, s));
+      float* sc = h->ws.gram_scratch[L - 1].as<float>();
+      switch (int(cdiv(C, 16))) {
+        case 1: LGNN_CALL(seed_spmm_gram_launch<1>(h, fork_exact, gplanes, cb, ce, sc, s)); break;
+        case 2: LGNN_CALL(seed_spmm_gram_launch<2>(h, fork_exact, gplanes, cb, ce, sc, s)); break;
+        case 3: LGNN_CALL(seed_spmm_gram_launch<3>(h, fork_exact, gplanes, cb, ce, sc, s)); break;
+        default: LGNN_CALL(seed_spmm_gram_launch<4>(h, fork_exact, gplanes, cb, ce, sc, s)); break;
+      }
+    } else {
+      int waves = int(std::max<int64_t>(1, std::min<int64_t>(4, (48 * 1024) / (nq * 4))));
+      LGNN_REQUIRE(nq * 4 <= 60 * 1024, "too many classes for the seed SpMM kernel (use class ranges)");
+      hipLaunchKernelGGL(seed_spmm_kernel, dim3(unsigned(cdiv(N, waves))), dim3(64 * waves), size_t(waves) * nq * 4, s,
+                         h->PT.rowptr, h->PT.col, h->PT.val, N, C, h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(),
+                         gtop, h->ws.active.as<uint8_t>(), cb, ce);
+      LGNN_HIP_CHECK(hipGetLastError());
+      LGNN_CALL(launch_gram(gtop + cb * N * C, C, (ce - cb) * N, C, h->ws.gram_scratch[L - 1].as<float>(), s));
+    }
   } else {
     // rows (m, c) of the accumulated seeds; rows of non-first duplicates are zero
     if (first) LGNN_CALL(launch_gram(h->ws.seeds.as<float>(), C, M * C, C, h->ws.gram_scratch[L - 1].as<float>(), s));
@@ -293,10 +611,12 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
       val_top = h->ws.val_act.as<float>();
       if (gcn) {
         row_active = h->ws.active.as<uint8_t>();
-        LGNN_CALL(h->ws.act_list.reserve(size_t(N) * 4));
-        LGNN_CALL(h->ws.act_count.reserve(64));
-        LGNN_CALL(compact_flags(row_active, N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(),
-                                h->ws.select_tmp, s));
+        if (!have_act_list) {
+          LGNN_CALL(h->ws.act_list.reserve(size_t(N) * 4));
+          LGNN_CALL(h->ws.act_count.reserve(64));
+          LGNN_CALL(compact_flags(row_active, N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(),
+                                  h->ws.select_tmp, s));
+        }
       }
     }
     int64_t maxw = 0;

@@ -78,6 +78,7 @@ struct Workspace {
   DevBuf pos;       // int32 [N]   batch position of a node, INT_MAX if not in batch
   DevBuf seeds;     // fp32 [M, C, C] (c-major rows inside a sample: [m][c][k])
   DevBuf probs;     // fp32 [M, C] softmax
+  DevBuf mult;      // int32 [M]: occurrences of the node whose first batch position this is (0 elsewhere)
   DevBuf planes_a;  // backward planes, ping
   DevBuf planes_b;  // backward planes, pong
   DevBuf gram_scratch[kMaxLayers];  // [out_l, out_l] per-call partial B (upper sub-tiles)
