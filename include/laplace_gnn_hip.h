@@ -163,6 +163,14 @@ LGNN_API int lgnn_check_async_errors(lgnn_ctx* h, void* stream);
 LGNN_API int lgnn_enable_kernel_timing(lgnn_ctx* h, int enable);
 LGNN_API int lgnn_kernel_timing_read(lgnn_ctx* h, int64_t* launches, double* total_ms, int64_t* planes);
 
+/* ---- decomposition of the fitted factors ("next" row: KronLaplace.fit -> Kron.decompose) ----------
+ * Replaces the per-factor torch.linalg.eigh calls of laplace/utils/matrix.py:118-145 (symeig,
+ * laplace/utils/utils.py:193-226) by ONE strided-batched rocSOLVER syevd over all factors.
+ * A: device fp32 [batch][n][n], symmetric (upper triangle read), overwritten with the eigenvectors: ROW j of
+ * matrix b is the unit eigenvector of eigenvalue W[b][j]; W: device fp32 [batch][n], ascending;
+ * info: device int32 [batch] (0 = converged).  Asynchronous on `stream`; no graph handle involved.    */
+LGNN_API int lgnn_symeig_batched(float* A, int64_t n, int64_t batch, float* W, int32_t* info, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,6 +122,37 @@ def test_posterior_samples_and_sampling_predictive(path):
     model.engine.check_async_errors()
 
 
+def test_batched_symeig_matches_float64_eigh():
+    """lgnn_symeig_batched behind Kron.decompose: factors of different sizes go through one padded batched solver
+    call; eigenvalues against float64 LAPACK, eigenvectors through gauge-free properties (orthonormal,
+    reconstruct the factor), rank-deficient and 1 x 1 factors included (symeig clamp semantics, utils.py:193-226)."""
+    import laplace_gnn_amd as lg
+    from laplace_gnn_amd.matrix import symeig_batched_hip
+
+    gen = torch.Generator().manual_seed(0)
+    mats = []
+    for n, rank in ((256, 256), (128, 128), (40, 40), (7, 3), (1, 1), (256, 100)):
+        R = torch.randn(max(rank, 1), n, generator=gen)
+        mats.append((R.T @ R / rank).cuda())
+    for (lam, Q), H in zip(symeig_batched_hip(mats), mats):
+        n = H.shape[0]
+        ref = torch.linalg.eigvalsh(H.double().cpu()).clamp(min=0).numpy()
+        assert lam.shape == (n,) and Q.shape == (n, n)
+        assert np.abs(lam.cpu().numpy() - ref).max() < 2e-5 * ref.max()
+        assert (lam >= 0).all() and (lam[1:] >= lam[:-1]).all()
+        Qd = Q.double().cpu()
+        assert (Qd.T @ Qd - torch.eye(n, dtype=torch.float64)).abs().max() < 1e-4
+        recon = (Qd * lam.double().cpu()) @ Qd.T
+        assert rel(recon.numpy(), H.double().cpu().numpy()) < 1e-5
+    # Kron.decompose uses it for CUDA factors and keeps the [[B, A], [B]] sharing
+    K = lg.Kron([[mats[2], mats[1]], [mats[2].clone()], [mats[3], mats[2]], [mats[3].clone()]])
+    dec = K.decompose()
+    assert dec.eigenvalues[1][0] is dec.eigenvalues[0][0] and dec.eigenvalues[3][0] is dec.eigenvalues[2][0]
+    dense = K.to_matrix().double().cpu() + 0.5 * torch.eye(40 * 128 + 40 + 7 * 40 + 7, dtype=torch.float64)
+    got = float((dec + torch.tensor(0.5, device="cuda")).logdet())
+    assert abs(got - float(torch.logdet(dense))) < 1e-4 * abs(float(torch.logdet(dense)))
+
+
 def test_backend_kron_returns_fresh_tensors_and_reference_layout():
     """CurvatureInterface contract (laplace/curvature/curvlinops.py:55-108): fresh tensors per call,
     [[B,A],[B]] per Linear, A rescaled by M/N, callers may mutate the result."""
