@@ -1,182 +1,225 @@
 // Backward plane GEMM of the KFAC path (GCN):  U[p][n][:] = act'(h[n][:]) * (G[p][n][:] @ W)
 // for the ACTIVE nodes n only (nodes whose top-layer gradient row is non-zero for this batch).
 //
-//   K  = width of G (number of classes at the top level, <= 64)  -> no K loop, W lives in LDS
-//   Nout <= 256                                                  -> a wave owns 32 rows x all columns
-// Persistent 256-thread workgroups walk (plane, 128-row tile) pairs of the compacted row list; the next
-// A tile is prefetched into registers while the MFMAs (v_mfma_f32_32x32x2_f32) of the current one run.
-// The activation derivative comes from a per-node bit mask for ReLU (32 B per node instead of a 1 KiB
-// float row) and from the float activations otherwise.  Inactive rows are never written: the fused
-// SpMM that consumes U skips them (their P^T values are zeroed, kfac.hip).
+//   K  = width of G (number of classes at the top level, <= 64)  -> no K loop
+//   Nout <= 256                                                  -> a wave owns 32 rows x 32 columns
+//
+// No LDS tiles, no barriers: every wave is an independent stream over its own work units (plane, 32-row tile of the
+// compacted row list), always for the same 32 output columns.
+//  * v_mfma_f32_32x32x2_f32 sums over k in any order as long as A and B agree, so k-step kk pairs k = kk (lanes 0-31)
+//    with k = H + kk (lanes 32-63), H = K2 / 2.  A lane then needs H CONSECUTIVE floats of one row of G -- the first
+//    or the second half of "its" row l & 31 -- which are plain aligned 16-byte loads straight into the MFMA operand
+//    registers; nothing passes through LDS and no element is selected or moved.
+//  * The wave's slice of W (32 columns, the same for all its units) is H registers per lane, loaded once.
+//  * Software pipeline: rows of unit u+2 and the list entry of unit u+3 are issued BEFORE the stores of unit u.  vmcnt
+//    is in order: a load younger than a store cannot be waited for without draining that store.
+//  * Every load is unconditional: a branch around a load makes the compiler drain vmcnt at the join.
+// The activation derivative comes from a per-node bit mask for ReLU (32 B per node instead of a 1 KiB float row), kept
+// with the node ids in a wave-private LDS strip.  Inactive rows are never written: the fused SpMM that consumes U skips
+// them (their P^T values are zeroed, kfac.hip).
+// History: 64-row tiles staged through LDS with one barrier per tile ran at 0.80 ms per arxiv-shaped launch (2 GB of
+// stores, 41 GFLOP), bound by neither the stores nor the MFMAs but by the serialisation between them.
 #include "device_utils.h"
 #include "gram256.h"  // f32x16
+#include <numeric>
+
 #include "lgnn_internal.h"
 
 namespace lgnn {
 
 namespace {
 
-constexpr int BGM = 64;  // rows per tile: 2 row groups of 32 x 2 column halves = 4 waves
+constexpr int BGM = 32;      // rows per unit
+constexpr int META_LD = 12;  // wave-private strips (two, alternating): [32][12] words = node id, 3 unused, 8 mask words
+constexpr int BG_THREADS = 256, BG_WAVES = BG_THREADS / 64;
+constexpr int BG_OCC = 3;  // waves per SIMD the register budget is set for
+using u4u = __attribute__((ext_vector_type(4), aligned(4))) unsigned int;
 
-// LDS: W [K2][NT*32] once, then TWO copies of (A tile [64][KP], node ids [64], mask words [64][8]).
-// Per tile: issue the global loads of tile i+1 -> MFMAs on tile i -> park tile i+1 in the other LDS copy
-// (the loads landed during the MFMAs, and this wait comes BEFORE the epilogue's stores, so it never has
-// to drain them: vmcnt is in order) -> epilogue stores of tile i -> one barrier.
-template <int NT, int VECA>
-__global__ __launch_bounds__(256, 2) void backgemm_kernel(BackGemmArgs g) {
-  extern __shared__ float smem[];
-  const int K = int(g.K), K2 = (K + 1) & ~1, KP = K2 | 1;
-  constexpr int NP = NT * 32;
-  constexpr int NTW = NT >= 2 ? NT / 2 : 1;  // column tiles per wave (<= 4: 64 accumulator registers)
-  float* __restrict__ Bs = smem;
-  const int copy_words = BGM * KP + BGM + BGM * 8;
-  float* __restrict__ copy0 = smem + K2 * NP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// KH: 16-byte pieces per half row (H = 4 KH floats >= ceil(K / 2)); VEC: K == 8 KH, rows are read with 16-byte loads
+template <int KH, bool VEC, bool RELU>
+__global__ __launch_bounds__(BG_THREADS, BG_OCC) void backgemm_kernel(BackGemmArgs g) {
+  extern __shared__ int32_t meta_all[];
+  constexpr int H = 4 * KH;  // k-steps
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int rg = wave >> 1, ch = wave & 1;
-  const bool wave_active = NT >= 2 || ch == 0;
-  for (int f = tid; f < K2 * NP; f += 256) {
-    const int k = f / NP, c = f - k * NP;
-    Bs[f] = (k < K && c < g.Nout) ? g.W[int64_t(k) * g.ldw + c] : 0.f;
-  }
-  if (K2 != K)
-    for (int r = tid; r < 2 * BGM; r += 256) (copy0 + (r / BGM) * copy_words)[(r % BGM) * KP + K] = 0.f;
+  const int K = int(g.K);
+  const int NCH = int((g.Nout + 31) / 32);  // column groups of 32 = units per row tile
+  int32_t* __restrict__ meta = meta_all + wave * (2 * BGM * META_LD);
 
   const int64_t na = g.rows ? int64_t(*g.na_dev) : g.N;
-  const int64_t tiles_per_plane = (na + BGM - 1) / BGM;
-  const int64_t ntiles = tiles_per_plane * g.planes;
+  const uint32_t tiles_per_plane = uint32_t((na + BGM - 1) / BGM);
+  const int64_t ntiles = int64_t(tiles_per_plane) * g.planes;
+  // wave w of the grid always works on column group w % NCH (the launcher makes the wave count a multiple of NCH)
+  const int64_t gwave = int64_t(blockIdx.x) * BG_WAVES + wave, nwaves = int64_t(gridDim.x) * BG_WAVES;
+  const int ch = int(gwave % NCH);
+  const int64_t first = gwave / NCH, stride = nwaves / NCH;  // tiles
+  if (first >= ntiles) return;
+  const int mw = int(g.mask_words);
+  const int col = ch * 32 + l31;
+  const bool col_ok = col < g.Nout;
 
-  constexpr int MAXV = VECA == 4 ? 4 : 16;  // staged float4 / floats per thread (64 rows, K <= 64)
-  float4 st4[VECA == 4 ? MAXV : 1];
-  float st1[VECA == 1 ? MAXV : 1];
-  uint2 mstage = make_uint2(~0u, ~0u);  // mask words (row tid>>2, words (tid&3)*2 ..+1) of the staged tile
-  int32_t nstage = -1;                  // node id of row tid (tid < 64) of the staged tile
-  const int step = 256 * VECA;
-  const int q = step / K, rem = step - q * K;
-  const int r_first = (tid * VECA) / K, k_first = (tid * VECA) - r_first * K;
-
-  auto tile_coords = [&](int64_t tile, int64_t& plane, int64_t& t0) {
-    plane = tile / tiles_per_plane;
-    t0 = (tile - plane * tiles_per_plane) * BGM;
-  };
-  auto node_of = [&](int64_t t) -> int64_t { return g.rows ? int64_t(g.rows[t]) : t; };
-  auto load_tile = [&](int64_t tile) {
-    int64_t plane, t0;
-    tile_coords(tile, plane, t0);
-    const float* __restrict__ base = g.G + plane * g.N * g.K;
-    int r = r_first, k = k_first;
+  // W[k][col] for this lane's k-steps: k = lhi * H + kk
+  float bw[H];
 #pragma unroll
-    for (int e = 0; e < MAXV; ++e) {
-      const bool ok = r < BGM && t0 + r < na;
-      if constexpr (VECA == 4) {
-        st4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) st4[e] = *reinterpret_cast<const float4*>(base + node_of(t0 + r) * g.K + k);
-      } else {
-        st1[e] = ok ? base[node_of(t0 + r) * g.K + k] : 0.f;
-      }
-      r += q; k += rem;
-      if (k >= K) { k -= K; r += 1; }
-    }
-    nstage = (tid < BGM && t0 + tid < na) ? int32_t(node_of(t0 + tid)) : -1;
-    mstage = make_uint2(~0u, ~0u);
-    if (g.mask_bits) {
-      const int mr = tid >> 2, mw = (tid & 3) * 2;
-      if (t0 + mr < na) {
-        const uint32_t* __restrict__ mp = g.mask_bits + node_of(t0 + mr) * g.mask_words;
-        if (mw + 0 < g.mask_words) mstage.x = mp[mw + 0];
-        if (mw + 1 < g.mask_words) mstage.y = mp[mw + 1];
-      }
-    }
-  };
-  auto park_tile = [&](int buf) {
-    float* __restrict__ As = copy0 + buf * copy_words;
-    int32_t* __restrict__ nodes = reinterpret_cast<int32_t*>(As + BGM * KP);
-    uint32_t* __restrict__ mask_s = reinterpret_cast<uint32_t*>(nodes + BGM);
-    int r = r_first, k = k_first;
-#pragma unroll
-    for (int e = 0; e < MAXV; ++e) {
-      if (r < BGM) {
-        float* d = As + r * KP + k;
-        if constexpr (VECA == 4) { d[0] = st4[e].x; d[1] = st4[e].y; d[2] = st4[e].z; d[3] = st4[e].w; }
-        else d[0] = st1[e];
-      }
-      r += q; k += rem;
-      if (k >= K) { k -= K; r += 1; }
-    }
-    if (tid < BGM) nodes[tid] = nstage;
-    *reinterpret_cast<uint2*>(mask_s + (tid >> 2) * 8 + (tid & 3) * 2) = mstage;
-  };
-
-  int64_t tile = blockIdx.x;
-  int buf = 0;
-  if (tile < ntiles) {
-    load_tile(tile);
-    park_tile(0);
+  for (int kk = 0; kk < H; ++kk) {
+    const int k = lhi * H + kk;
+    bw[kk] = (k < K && col_ok) ? g.W[int64_t(k) * g.ldw + col] : 0.f;
   }
-  __syncthreads();
-  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-    const bool has_next = tile + gridDim.x < ntiles;
-    if (has_next) load_tile(tile + gridDim.x);
-    const float* __restrict__ As = copy0 + buf * copy_words;
-    const int32_t* __restrict__ nodes = reinterpret_cast<const int32_t*>(As + BGM * KP);
-    const uint32_t* __restrict__ mask_s = reinterpret_cast<const uint32_t*>(nodes + BGM);
-    int64_t plane, t0;
-    tile_coords(tile, plane, t0);
-    float* __restrict__ Up = g.U + plane * g.N * g.Nout;
 
-    f32x16 acc[NTW];
+  auto tile_coords = [&](int64_t tile, uint32_t& plane, int64_t& t0) {  // 32-bit division (the launcher bounds ntiles)
+    plane = uint32_t(tile) / tiles_per_plane;
+    t0 = int64_t(uint32_t(tile) - plane * tiles_per_plane) * BGM;
+  };
+  const auto tile_at = [&](int64_t t) { return t < ntiles ? t : ntiles - 1; };  // past the end: loaded, never used
+  // node id of row l31 of a tile (rows past the end of the list re-read its last entry; valid = false keeps them
+  // from being stored)
+  auto load_id = [&](int64_t tile, int32_t& ndc, bool& valid) {
+    uint32_t plane;
+    int64_t t0;
+    tile_coords(tile, plane, t0);
+    const int64_t t = t0 + l31;
+    valid = t < na;
+    const int64_t tc = valid ? t : na - 1;
+    ndc = g.rows ? g.rows[tc] : int32_t(tc);
+  };
+  auto load_rows = [&](int64_t tile, int32_t ndc, float (&a)[H], u4u& m0, u4u& m1) {
+    uint32_t plane;
+    int64_t t0;
+    tile_coords(tile, plane, t0);
+    const float* __restrict__ src = g.G + (int64_t(plane) * g.N + ndc) * g.K;
+    if constexpr (VEC) {
 #pragma unroll
-    for (int n = 0; n < NTW; ++n)
+      for (int j = 0; j < KH; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(src + lhi * H + 4 * j);
+        a[4 * j + 0] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+      }
+    } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    if (wave_active) {
-      const float* __restrict__ arow = As + (rg * 32 + l31) * KP + lhi;
-      const float* __restrict__ brow = Bs + lhi * NP + ch * NTW * 32 + l31;
-      for (int kk = 0; kk < (g.debug == 2 ? 1 : K2 / 2); ++kk) {
-        const float av = arow[2 * kk];
-#pragma unroll
-        for (int n = 0; n < NTW; ++n)
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[2 * kk * NP + n * 32], acc[n], 0, 0, 0);
+      for (int kk = 0; kk < H; ++kk) {
+        const int k = lhi * H + kk;
+        a[kk] = src[k < K ? k : K - 1];  // k >= K meets a zero of W
       }
     }
-    // the prefetched tile goes to the other LDS copy now: its loads are older than every store below
-    if (has_next) park_tile(buf ^ 1);
-    if (wave_active) {
-      const int colb = ch * NTW * 32 + l31;
+    if constexpr (RELU) {
+      // 8 words are read whatever mask_words is (the buffer carries the slack)
+      const uint32_t* __restrict__ mp = g.mask_bits + int64_t(ndc) * mw;
+      m0 = *reinterpret_cast<const u4u*>(mp);
+      m1 = *reinterpret_cast<const u4u*>(mp + 4);
+    } else {
+      m0 = u4u{~0u, ~0u, ~0u, ~0u};
+      m1 = m0;
+    }
+  };
+  auto park_meta = [&](int32_t* strip, int32_t nd, const u4u& m0, const u4u& m1) {
+    if (lhi == 0) {
+      strip[l31 * META_LD] = nd;
+      *reinterpret_cast<uint4*>(strip + l31 * META_LD + 4) = make_uint4(m0.x, m0.y, m0.z, m0.w);
+      *reinterpret_cast<uint4*>(strip + l31 * META_LD + 8) = make_uint4(m1.x, m1.y, m1.z, m1.w);
+    }
+    // read back by other lanes of this wave: LDS executes a wave's operations in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  const int32_t rowb = int32_t(g.Nout) * 4;  // the strip keeps a row's BYTE offset inside its plane (< 2^31, launcher)
+  float ac[H], an[H];              // MFMA A operands of the current unit, rows of the next one in flight
+  int32_t nd_n, nd_nn, nd_nnn;     // ids of tiles +1, +2 (rows in flight), +3 (id in flight)
+  bool ok_n, ok_nn, ok_nnn;
+  u4u m0n, m1n;
+  {
+    int32_t nd0;
+    bool ok0;
+    u4u m0, m1;
+    load_id(first, nd0, ok0);
+    load_id(tile_at(first + stride), nd_n, ok_n);
+    load_id(tile_at(first + 2 * stride), nd_nn, ok_nn);
+    load_rows(first, nd0, ac, m0, m1);
+    park_meta(meta, ok0 ? nd0 * rowb : -1, m0, m1);
+    load_rows(tile_at(first + stride), nd_n, an, m0n, m1n);
+  }
+  const int sh = 31 - l31;
+  int it = 0;
+  for (int64_t tile = first; tile < ntiles; tile += stride, ++it) {
+    uint32_t plane;
+    int64_t t0;
+    tile_coords(tile, plane, t0);
+    char* __restrict__ Up = reinterpret_cast<char*>(g.U + int64_t(plane) * g.N * g.Nout + col);  // wave-uniform + lane column
+    const int32_t* __restrict__ mcur = meta + (it & 1) * (BGM * META_LD);
+
+    f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lr = rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const int32_t nd = nodes[lr];
-        if (nd < 0) continue;
-        float* __restrict__ urow = Up + int64_t(nd) * g.Nout;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (g.debug != 2) {
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-          const int col = colb + n * 32;
-          float v = acc[n][r];
-          if (g.mask_bits) v = ((mask_s[lr * 8 + ch * NTW + n] >> l31) & 1u) ? v : 0.f;
-          else if (g.hact && col < g.Nout) v *= act_deriv_from_out(g.hact[int64_t(nd) * g.hact_ld + col], g.act);
-          if (col < g.Nout && g.debug != 1) urow[col] = v;
+      for (int kk = 0; kk < H; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[kk], bw[kk], acc, 0, 0, 0);
+    }
+    // land tile +1 (its ids / mask words go to the other LDS strip), then issue rows(+2) and id(+3)
+#pragma unroll
+    for (int kk = 0; kk < H; ++kk) {
+      asm volatile("" : "+v"(an[kk]));
+      ac[kk] = an[kk];
+    }
+    park_meta(meta + ((it + 1) & 1) * (BGM * META_LD), ok_n ? nd_n * rowb : -1, m0n, m1n);
+    load_rows(tile_at(tile + 2 * stride), nd_nn, an, m0n, m1n);
+    load_id(tile_at(tile + 3 * stride), nd_nnn, ok_nnn);
+    nd_n = nd_nn; ok_n = ok_nn; nd_nn = nd_nnn; ok_nn = ok_nnn;
+
+    if (g.debug == 4) continue;
+    if (RELU && t0 + BGM <= na && col_ok) {
+      // whole tile: ids and mask words of 8 rows at a time, then their stores, nothing conditional
+#pragma unroll
+      for (int rq = 0; rq < 2; ++rq) {
+        int32_t nds[8];
+        uint32_t wd[8];
+#pragma unroll
+        for (int ri = 0; ri < 8; ++ri) {
+          const int r = rq * 8 + ri;
+          const int lr = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          nds[ri] = mcur[lr * META_LD];
+          wd[ri] = uint32_t(mcur[lr * META_LD + 4 + ch]);
+        }
+#pragma unroll
+        for (int ri = 0; ri < 8; ++ri) {
+          const float v = int32_t(wd[ri] << sh) < 0 ? acc[rq * 8 + ri] : 0.f;
+          if (g.debug != 1) *reinterpret_cast<float*>(Up + uint32_t(nds[ri])) = v;
         }
       }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int32_t nd = mcur[lr * META_LD];
+        if (nd < 0 || !col_ok) continue;
+        float v = acc[r];
+        if constexpr (RELU) {
+          v = int32_t(uint32_t(mcur[lr * META_LD + 4 + ch]) << sh) < 0 ? v : 0.f;
+        } else if (g.hact) {
+          v *= act_deriv_from_out(g.hact[int64_t(nd / rowb) * g.hact_ld + col], g.act);
+        }
+        if (g.debug != 1) *reinterpret_cast<float*>(Up + uint32_t(nd)) = v;
+      }
     }
-    __syncthreads();
   }
 }
 
-template <int NT>
-int backgemm_launch(const BackGemmArgs& g, size_t smem, bool vec, hipStream_t s) {
-  const int64_t worst = cdiv(g.N, BGM) * g.planes;
-  const unsigned grid = unsigned(std::min<int64_t>(worst, 512));
-  static bool attr_set = false;  // more than 64 KiB of dynamic LDS needs an explicit opt-in
-  if (!attr_set) {
-    LGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&backgemm_kernel<NT, 4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    LGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&backgemm_kernel<NT, 1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_set = true;
-  }
-  if (vec) hipLaunchKernelGGL((backgemm_kernel<NT, 4>), dim3(grid), dim3(256), smem, s, g);
-  else hipLaunchKernelGGL((backgemm_kernel<NT, 1>), dim3(grid), dim3(256), smem, s, g);
+template <int KH>
+int backgemm_launch(const BackGemmArgs& g, hipStream_t s) {
+  const size_t smem = size_t(2 * BG_WAVES * BGM * META_LD) * 4;
+  const int64_t nch = cdiv(g.Nout, 32);
+  const int64_t units = cdiv(g.N, BGM) * g.planes * nch;
+  // waves: a multiple of the column groups and of the workgroup size; at most BG_OCC waves per SIMD on 256 CUs
+  const int64_t quantum = nch * BG_WAVES / std::gcd<int64_t>(nch, BG_WAVES);
+  int64_t waves = std::min<int64_t>(units, 256 * 4 * (BG_OCC + 1));  // K = 40 compiles to 126 VGPRs: 4 waves fit
+  waves = std::max<int64_t>(quantum, waves / quantum * quantum);
+  const unsigned grid = unsigned(waves / BG_WAVES);
+  const bool vec = g.K == 8 * KH && (reinterpret_cast<uintptr_t>(g.G) & 15) == 0;
+  const bool relu = g.mask_bits != nullptr;
+  if (vec && relu) hipLaunchKernelGGL((backgemm_kernel<KH, true, true>), dim3(grid), dim3(BG_THREADS), smem, s, g);
+  else if (vec) hipLaunchKernelGGL((backgemm_kernel<KH, true, false>), dim3(grid), dim3(BG_THREADS), smem, s, g);
+  else if (relu) hipLaunchKernelGGL((backgemm_kernel<KH, false, true>), dim3(grid), dim3(BG_THREADS), smem, s, g);
+  else hipLaunchKernelGGL((backgemm_kernel<KH, false, false>), dim3(grid), dim3(BG_THREADS), smem, s, g);
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -200,29 +243,28 @@ __global__ void relu_mask_bits_kernel(const float* __restrict__ h, int64_t ld, i
 
 }  // namespace
 
-bool backgemm_supported(int64_t K, int64_t Nout) {
-  if (K < 1 || K > 64 || Nout < 1 || Nout > 256) return false;
-  const int nt = Nout <= 32 ? 1 : (Nout <= 64 ? 2 : (Nout <= 128 ? 4 : 8));
-  const int K2 = int((K + 1) & ~int64_t(1)), KP = K2 | 1;
-  return (size_t(K2) * nt * 32 + 2 * (size_t(BGM) * KP + BGM + BGM * 8)) * 4 <= 78 * 1024;
-}
+bool backgemm_supported(int64_t K, int64_t Nout) { return K >= 1 && K <= 64 && Nout >= 1 && Nout <= 256; }
 
 int launch_backgemm(const BackGemmArgs& g_in, hipStream_t s) {
   BackGemmArgs g = g_in;
-#ifdef LGNN_DEV  // make DEV=1: ablation switches for tools/time_kernels.py
+#ifdef LGNN_DEV  // make DEV=1: ablation switches (1 no stores, 2 no MFMA, 4 no epilogue)
   if (const char* dbg = getenv("LGNN_BACKGEMM_DEBUG")) g.debug = atoi(dbg);
 #endif
   if (g.planes <= 0 || g.N <= 0) return 0;
   LGNN_REQUIRE(backgemm_supported(g.K, g.Nout), "backgemm shape not supported");
-  const int nt = g.Nout <= 32 ? 1 : (g.Nout <= 64 ? 2 : (g.Nout <= 128 ? 4 : 8));
-  const int K2 = int((g.K + 1) & ~int64_t(1)), KP = K2 | 1;
-  const size_t smem = (size_t(K2) * nt * 32 + 2 * (size_t(BGM) * KP + BGM + BGM * 8)) * 4;
-  const bool vec = g.K % 4 == 0 && (reinterpret_cast<uintptr_t>(g.G) & 15) == 0;
-  switch (nt) {
-    case 1: return backgemm_launch<1>(g, smem, vec, s);
-    case 2: return backgemm_launch<2>(g, smem, vec, s);
-    case 4: return backgemm_launch<4>(g, smem, vec, s);
-    default: return backgemm_launch<8>(g, smem, vec, s);
+  LGNN_REQUIRE(g.mask_bits == nullptr || g.mask_words <= 8, "backgemm: at most 8 mask words per node");
+  LGNN_REQUIRE(cdiv(g.N, BGM) * g.planes < (int64_t(1) << 31), "backgemm: too many row tiles for 32-bit indices");
+  LGNN_REQUIRE(g.N * g.Nout * 4 < (int64_t(1) << 31), "backgemm: plane too large for 32-bit row offsets");
+  const int kh = int(cdiv(cdiv(g.K, 2), 4));  // 16-byte pieces per half row
+  switch (kh) {
+    case 1: return backgemm_launch<1>(g, s);
+    case 2: return backgemm_launch<2>(g, s);
+    case 3: return backgemm_launch<3>(g, s);
+    case 4: return backgemm_launch<4>(g, s);
+    case 5: return backgemm_launch<5>(g, s);
+    case 6: return backgemm_launch<6>(g, s);
+    case 7: return backgemm_launch<7>(g, s);
+    default: return backgemm_launch<8>(g, s);
   }
 }
 

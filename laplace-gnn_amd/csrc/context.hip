@@ -64,7 +64,7 @@ static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
         fc.hact_p[l] = fc.act_out[l].as<float>();
         fc.hact_ld[l] = dout;
         if (h->act == LGNN_ACT_RELU) {
-          LGNN_CALL(fc.mask_bits[l].reserve(size_t(N) * cdiv(dout, 32) * 4));
+          LGNN_CALL(fc.mask_bits[l].reserve(size_t(N) * cdiv(dout, 32) * 4 + 32));  // + 32: backgemm reads 8 words per node
           LGNN_CALL(launch_relu_mask_bits(fc.hact_p[l], dout, N, dout, fc.mask_bits[l].as<uint32_t>(), s));
         }
         fc.lin_in_p[l + 1] = fc.hact_p[l];

@@ -545,7 +545,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   // ---- top layer ---------------------------------------------------------------------------------
   float* gtop = nullptr;  // planes [C][N][C]
   if (h->kind == LGNN_KIND_GCN || L > 1) {
-    LGNN_CALL(h->ws.top.reserve(size_t(N) * CC * 4));
+    LGNN_CALL(h->ws.top.reserve(size_t(N) * CC * 4 + 16));  // + 16: the backward GEMM reads rows shifted by one float
     gtop = h->ws.top.as<float>();
   }
   LGNN_CALL(h->ws.active.reserve(size_t(N)));
