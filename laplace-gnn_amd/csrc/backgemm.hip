@@ -47,7 +47,7 @@ __global__ __launch_bounds__(BG_THREADS, BG_OCC) void backgemm_kernel(BackGemmAr
   const int NCH = int((g.Nout + 31) / 32);  // column groups of 32 = units per row tile
   int32_t* __restrict__ meta = meta_all + wave * (2 * BGM * META_LD);
 
-  const int64_t na = g.rows ? int64_t(*g.na_dev) : g.N;
+  const int64_t na = int64_t(*g.na_dev);
   const uint32_t tiles_per_plane = uint32_t((na + BGM - 1) / BGM);
   const int64_t ntiles = int64_t(tiles_per_plane) * g.planes;
   // wave w of the grid always works on column group w % NCH (the launcher makes the wave count a multiple of NCH)
@@ -58,6 +58,9 @@ __global__ __launch_bounds__(BG_THREADS, BG_OCC) void backgemm_kernel(BackGemmAr
   const int mw = int(g.mask_words);
   const int col = ch * 32 + l31;
   const bool col_ok = col < g.Nout;
+  const int colx = col_ok ? col : int(col % g.Nout);  // a column that exists, for the lanes past Nout
+  const int32_t rowb = int32_t(g.Nout) * 4;           // the strip keeps a row's BYTE offset inside its plane (< 2^31)
+  const int32_t trash = int32_t(g.N) * rowb;           // the plane's spare row
 
   // W[k][col] for this lane's k-steps: k = lhi * H + kk
   float bw[H];
@@ -72,16 +75,19 @@ __global__ __launch_bounds__(BG_THREADS, BG_OCC) void backgemm_kernel(BackGemmAr
     t0 = int64_t(uint32_t(tile) - plane * tiles_per_plane) * BGM;
   };
   const auto tile_at = [&](int64_t t) { return t < ntiles ? t : ntiles - 1; };  // past the end: loaded, never used
-  // node id of row l31 of a tile (rows past the end of the list re-read its last entry; valid = false keeps them
-  // from being stored)
+  // NOTHING below is conditional on a memory operation: a branch around a load or a store makes the compiler drain
+  // vmcnt at the join (also a wave-uniform branch, also at the loop latch), which serialises every unit's stores with
+  // the next unit's loads and MFMAs.  Rows past the end of the row list re-read its last entry and are stored to the
+  // plane's spare row N; lanes past Nout do the same in a column that exists.
+  // (the loaded id is not touched by any ALU instruction here: using it would make the wave wait for the load, and
+  //  for every older load, at the point of use)
   auto load_id = [&](int64_t tile, int32_t& ndc, bool& valid) {
     uint32_t plane;
     int64_t t0;
     tile_coords(tile, plane, t0);
     const int64_t t = t0 + l31;
     valid = t < na;
-    const int64_t tc = valid ? t : na - 1;
-    ndc = g.rows ? g.rows[tc] : int32_t(tc);
+    ndc = g.rows[valid ? t : na - 1];
   };
   auto load_rows = [&](int64_t tile, int32_t ndc, float (&a)[H], u4u& m0, u4u& m1) {
     uint32_t plane;
@@ -107,13 +113,14 @@ __global__ __launch_bounds__(BG_THREADS, BG_OCC) void backgemm_kernel(BackGemmAr
       m0 = *reinterpret_cast<const u4u*>(mp);
       m1 = *reinterpret_cast<const u4u*>(mp + 4);
     } else {
-      m0 = u4u{~0u, ~0u, ~0u, ~0u};
-      m1 = m0;
+      // no bit mask: the strip carries the node id (for the activation rows) in the first mask slot
+      m0 = u4u{uint32_t(ndc), 0u, 0u, 0u};
+      m1 = u4u{0u, 0u, 0u, 0u};
     }
   };
-  auto park_meta = [&](int32_t* strip, int32_t nd, const u4u& m0, const u4u& m1) {
+  auto park_meta = [&](int32_t* strip, int32_t off, const u4u& m0, const u4u& m1) {
     if (lhi == 0) {
-      strip[l31 * META_LD] = nd;
+      strip[l31 * META_LD] = off;
       *reinterpret_cast<uint4*>(strip + l31 * META_LD + 4) = make_uint4(m0.x, m0.y, m0.z, m0.w);
       *reinterpret_cast<uint4*>(strip + l31 * META_LD + 8) = make_uint4(m1.x, m1.y, m1.z, m1.w);
     }
@@ -123,11 +130,11 @@ __global__ __launch_bounds__(BG_THREADS, BG_OCC) void backgemm_kernel(BackGemmAr
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
 
-  const int32_t rowb = int32_t(g.Nout) * 4;  // the strip keeps a row's BYTE offset inside its plane (< 2^31, launcher)
   float ac[H], an[H];              // MFMA A operands of the current unit, rows of the next one in flight
-  int32_t nd_n, nd_nn, nd_nnn;     // ids of tiles +1, +2 (rows in flight), +3 (id in flight)
-  bool ok_n, ok_nn, ok_nnn;
+  int32_t nd_n, nd_nn, nd_nnn;     // node ids of tiles +1, +2 (rows in flight), +3 (id in flight)
+  bool ok_n, ok_nn, ok_nnn;        // row inside the list (else it is stored to the spare row)
   u4u m0n, m1n;
+  const auto row_offset = [&](int32_t nd, bool ok) { return (ok ? nd : int32_t(g.N)) * rowb; };
   {
     int32_t nd0;
     bool ok0;
@@ -136,69 +143,54 @@ __global__ __launch_bounds__(BG_THREADS, BG_OCC) void backgemm_kernel(BackGemmAr
     load_id(tile_at(first + stride), nd_n, ok_n);
     load_id(tile_at(first + 2 * stride), nd_nn, ok_nn);
     load_rows(first, nd0, ac, m0, m1);
-    park_meta(meta, ok0 ? nd0 * rowb : -1, m0, m1);
+    park_meta(meta, row_offset(nd0, ok0), m0, m1);
     load_rows(tile_at(first + stride), nd_n, an, m0n, m1n);
   }
   const int sh = 31 - l31;
   int it = 0;
+  // The wait-count pass merges the loop entry and the back edge at the loop header and keeps the stricter count: with
+  // prologue loads pending it would re-issue their waits on every iteration, draining the stores of the iteration
+  // before.  Entering the loop with nothing pending leaves only the back edge's own counts.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int64_t tile = first; tile < ntiles; tile += stride, ++it) {
-    uint32_t plane;
-    int64_t t0;
-    tile_coords(tile, plane, t0);
-    char* __restrict__ Up = reinterpret_cast<char*>(g.U + int64_t(plane) * g.N * g.Nout + col);  // wave-uniform + lane column
+    const uint32_t plane = uint32_t(tile) / tiles_per_plane;
+    char* __restrict__ Up = reinterpret_cast<char*>(g.U + int64_t(plane) * g.u_plane_stride + colx);
     const int32_t* __restrict__ mcur = meta + (it & 1) * (BGM * META_LD);
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if (g.debug != 2) {
 #pragma unroll
-      for (int kk = 0; kk < H; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[kk], bw[kk], acc, 0, 0, 0);
-    }
-    // land tile +1 (its ids / mask words go to the other LDS strip), then issue rows(+2) and id(+3)
+    for (int kk = 0; kk < H; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[kk], bw[kk], acc, 0, 0, 0);
+    // land tile +1 (its offsets / mask words go to the other LDS strip), then issue rows(+2) and id(+3)
 #pragma unroll
     for (int kk = 0; kk < H; ++kk) {
       asm volatile("" : "+v"(an[kk]));
       ac[kk] = an[kk];
     }
-    park_meta(meta + ((it + 1) & 1) * (BGM * META_LD), ok_n ? nd_n * rowb : -1, m0n, m1n);
+    park_meta(meta + ((it + 1) & 1) * (BGM * META_LD), row_offset(nd_n, ok_n), m0n, m1n);
     load_rows(tile_at(tile + 2 * stride), nd_nn, an, m0n, m1n);
     load_id(tile_at(tile + 3 * stride), nd_nnn, ok_nnn);
     nd_n = nd_nn; ok_n = ok_nn; nd_nn = nd_nnn; ok_nn = ok_nnn;
 
-    if (g.debug == 4) continue;
-    if (RELU && t0 + BGM <= na && col_ok) {
-      // whole tile: ids and mask words of 8 rows at a time, then their stores, nothing conditional
+    // epilogue: offsets and mask words of 8 rows at a time, then their stores
 #pragma unroll
-      for (int rq = 0; rq < 2; ++rq) {
-        int32_t nds[8];
-        uint32_t wd[8];
+    for (int rq = 0; rq < 2; ++rq) {
+      int32_t offs[8];
+      uint32_t wd[8];
 #pragma unroll
-        for (int ri = 0; ri < 8; ++ri) {
-          const int r = rq * 8 + ri;
-          const int lr = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          nds[ri] = mcur[lr * META_LD];
-          wd[ri] = uint32_t(mcur[lr * META_LD + 4 + ch]);
-        }
-#pragma unroll
-        for (int ri = 0; ri < 8; ++ri) {
-          const float v = int32_t(wd[ri] << sh) < 0 ? acc[rq * 8 + ri] : 0.f;
-          if (g.debug != 1) *reinterpret_cast<float*>(Up + uint32_t(nds[ri])) = v;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int ri = 0; ri < 8; ++ri) {
+        const int r = rq * 8 + ri;
         const int lr = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const int32_t nd = mcur[lr * META_LD];
-        if (nd < 0 || !col_ok) continue;
-        float v = acc[r];
-        if constexpr (RELU) {
-          v = int32_t(uint32_t(mcur[lr * META_LD + 4 + ch]) << sh) < 0 ? v : 0.f;
-        } else if (g.hact) {
-          v *= act_deriv_from_out(g.hact[int64_t(nd / rowb) * g.hact_ld + col], g.act);
-        }
-        if (g.debug != 1) *reinterpret_cast<float*>(Up + uint32_t(nd)) = v;
+        offs[ri] = mcur[lr * META_LD];
+        wd[ri] = uint32_t(mcur[lr * META_LD + 4 + (RELU ? ch : 0)]);
+      }
+#pragma unroll
+      for (int ri = 0; ri < 8; ++ri) {
+        float v = acc[rq * 8 + ri];
+        if constexpr (RELU) v = int32_t(wd[ri] << sh) < 0 ? v : 0.f;
+        else if (g.hact) v *= act_deriv_from_out(g.hact[int64_t(wd[ri]) * g.hact_ld + colx], g.act);
+        *reinterpret_cast<float*>(Up + uint32_t(col_ok ? offs[ri] : trash)) = v;
       }
     }
   }
@@ -247,14 +239,13 @@ bool backgemm_supported(int64_t K, int64_t Nout) { return K >= 1 && K <= 64 && N
 
 int launch_backgemm(const BackGemmArgs& g_in, hipStream_t s) {
   BackGemmArgs g = g_in;
-#ifdef LGNN_DEV  // make DEV=1: ablation switches (1 no stores, 2 no MFMA, 4 no epilogue)
-  if (const char* dbg = getenv("LGNN_BACKGEMM_DEBUG")) g.debug = atoi(dbg);
-#endif
   if (g.planes <= 0 || g.N <= 0) return 0;
   LGNN_REQUIRE(backgemm_supported(g.K, g.Nout), "backgemm shape not supported");
   LGNN_REQUIRE(g.mask_bits == nullptr || g.mask_words <= 8, "backgemm: at most 8 mask words per node");
   LGNN_REQUIRE(cdiv(g.N, BGM) * g.planes < (int64_t(1) << 31), "backgemm: too many row tiles for 32-bit indices");
-  LGNN_REQUIRE(g.N * g.Nout * 4 < (int64_t(1) << 31), "backgemm: plane too large for 32-bit row offsets");
+  LGNN_REQUIRE((g.N + 1) * g.Nout * 4 < (int64_t(1) << 31), "backgemm: plane too large for 32-bit row offsets");
+  LGNN_REQUIRE(g.rows && g.na_dev, "backgemm needs the compacted row list");
+  LGNN_REQUIRE(g.u_plane_stride >= (g.N + 1) * g.Nout, "backgemm: planes of U need a spare row");
   const int kh = int(cdiv(cdiv(g.K, 2), 4));  // 16-byte pieces per half row
   switch (kh) {
     case 1: return backgemm_launch<1>(g, s);

@@ -623,7 +623,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
     for (int l = 0; l < L - 1; ++l) maxw = std::max(maxw, h->in_dim[l + 1]);  // GEMM output width of layer l+1
     const int64_t per_class = N * maxw * 4 * 2;  // ping + pong
     int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(C, h->ws_limit / std::max<int64_t>(per_class, 1)));
-    LGNN_CALL(h->ws.planes_a.reserve(size_t(cc_max) * N * maxw * 4));
+    LGNN_CALL(h->ws.planes_a.reserve(size_t(cc_max) * (N + 1) * maxw * 4));  // + 1: the backward GEMM's spare row per plane
     LGNN_CALL(h->ws.planes_b.reserve(size_t(cc_max) * N * maxw * 4));
     for (int64_t c0 = cb; c0 < ce; c0 += cc_max) {
       const int64_t cc = std::min(cc_max, ce - c0);
@@ -643,8 +643,11 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           const bool top_level = l == L - 1;
           const bool fuse_here = !no_fuse && fused_supported(d, d, N * d, ping);
           if (top_level && fuse_here) ep.row_active = row_active;  // inactive rows are never read below
+          int64_t ping_stride = N * d;
           if (top_level && fuse_here && row_active && backgemm_supported(dout, d)) {
+            ping_stride = (N + 1) * d;  // row N of every plane takes the stores of rows past the end of the list
             BackGemmArgs bg{};
+            bg.u_plane_stride = ping_stride;
             bg.G = g; bg.W = h->W[l]; bg.ldw = d; bg.U = ping; bg.N = N; bg.K = dout; bg.Nout = d; bg.planes = cc;
             bg.rows = h->ws.act_list.as<int32_t>(); bg.na_dev = h->ws.act_count.as<int32_t>();
             if (h->act == LGNN_ACT_RELU) { bg.mask_bits = h->fc.mask_bits[l - 1].as<uint32_t>(); bg.mask_words = cdiv(d, 32); }
@@ -656,7 +659,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           FusedArgs a{};
           a.rowptr = h->PT.rowptr; a.col = h->PT.col; a.val = (top_level && fuse_here) ? val_top : h->PT.val;
           a.nrows = N; a.nplanes = cc;
-          a.in = ping; a.in_ld = d; a.in_plane_stride = N * d;
+          a.in = ping; a.in_ld = d; a.in_plane_stride = ping_stride;
           a.store = store ? pong : nullptr; a.store_ld = d; a.store_plane_stride = N * d;
           a.width = d; a.scratch = scratch;
           if (fuse_here) {

@@ -164,7 +164,8 @@ struct BackGemmArgs {
   const float* G;   // planes [P][N][K]
   const float* W;   // [K][ldw] row major, Nout columns used
   int64_t ldw;
-  float* U;         // planes [P][N][Nout]
+  float* U;         // planes [P][N + 1][Nout]: row N of a plane is a spare row (takes the stores of padding rows)
+  int64_t u_plane_stride;  // floats between planes of U, >= (N + 1) * Nout
   int64_t N, K, Nout;
   int64_t planes;
   const int32_t* rows;      // optional sorted list of active nodes (null: all N)
