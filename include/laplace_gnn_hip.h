@@ -102,7 +102,7 @@ LGNN_API int lgnn_bind_model(lgnn_ctx* h, int num_layers, const int64_t* dims /*
 LGNN_API int lgnn_invalidate(lgnn_ctx* h);
 /* bytes currently held by the context (graph + caches + workspace).  host value. */
 LGNN_API int64_t lgnn_device_bytes(const lgnn_ctx* h);
-/* cap for the backward workspace (chunks over classes are sized to fit); default 8 GiB */
+/* cap for the backward workspace (chunks over classes are sized to fit); default 32 GiB */
 LGNN_API int lgnn_set_workspace_limit(lgnn_ctx* h, int64_t bytes);
 
 /* ---- forward: model(x_indices) -> [M, C]  (gnn/models/base_gnn.py:136-161, eval mode) ----- */

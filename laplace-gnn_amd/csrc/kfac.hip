@@ -621,15 +621,25 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
     }
     int64_t maxw = 0;
     for (int l = 0; l < L - 1; ++l) maxw = std::max(maxw, h->in_dim[l + 1]);  // GEMM output width of layer l+1
-    const int64_t per_class = N * maxw * 4 * 2;  // ping + pong
+    // The pong buffer holds g_{l-1} when a lower layer needs it (L > 2) and the SpMM output of the unfused path;
+    // the fused two-layer path never touches it.
+    bool need_pong = L > 2 || no_fuse;
+    for (int l = 1; l < L && !need_pong; ++l) {
+      const int64_t d = h->dims[l];
+      const bool fusable = h->kind == LGNN_KIND_GCN
+                               ? fused_supported(d, d, N * d, h->ws.top.p)
+                               : fused_supported(d, 2 * d, N * 2 * d, h->ws.top.p) && h->fc.hact_ld[l - 1] % 4 == 0;
+      need_pong = !fusable;
+    }
+    const int64_t per_class = (N + 1) * maxw * 4 * (need_pong ? 2 : 1);
     int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(C, h->ws_limit / std::max<int64_t>(per_class, 1)));
     LGNN_CALL(h->ws.planes_a.reserve(size_t(cc_max) * (N + 1) * maxw * 4));  // + 1: the backward GEMM's spare row per plane
-    LGNN_CALL(h->ws.planes_b.reserve(size_t(cc_max) * N * maxw * 4));
+    if (need_pong) LGNN_CALL(h->ws.planes_b.reserve(size_t(cc_max) * N * maxw * 4));
     for (int64_t c0 = cb; c0 < ce; c0 += cc_max) {
       const int64_t cc = std::min(cc_max, ce - c0);
       const float* g = gtop + c0 * N * C;  // planes [cc][N][dims[l+1]] of layer l
       float* ping = h->ws.planes_a.as<float>();
-      float* pong = h->ws.planes_b.as<float>();
+      float* pong = need_pong ? h->ws.planes_b.as<float>() : nullptr;
       for (int l = L - 1; l >= 1; --l) {
         const int64_t dout = h->dims[l + 1];  // width of g
         const int64_t d = h->dims[l];         // width of g_{l-1}
@@ -660,6 +670,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           a.rowptr = h->PT.rowptr; a.col = h->PT.col; a.val = (top_level && fuse_here) ? val_top : h->PT.val;
           a.nrows = N; a.nplanes = cc;
           a.in = ping; a.in_ld = d; a.in_plane_stride = ping_stride;
+          LGNN_REQUIRE(!store || pong != nullptr, "internal: stored planes without a buffer");
           a.store = store ? pong : nullptr; a.store_ld = d; a.store_plane_stride = N * d;
           a.width = d; a.scratch = scratch;
           if (fuse_here) {
@@ -667,6 +678,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
             LGNN_CALL(launch_spmm_gram_ex(a, s));
             if (h->timing && dominant) { LGNN_CALL(record_event(h, s)); h->ev_planes += cc; }
           } else {
+            LGNN_REQUIRE(pong != nullptr, "internal: unfused path without its output planes");
             SpmmArgs sa{};
             sa.rowptr = a.rowptr; sa.col = a.col; sa.val = a.val; sa.nrows = N;
             sa.in = ping; sa.in_ld = d; sa.in_plane_stride = N * d;
@@ -684,6 +696,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           a.in = ping + d; a.in_ld = 2 * d; a.in_plane_stride = N * 2 * d;
           a.self = ping; a.self_ld = 2 * d; a.self_plane_stride = N * 2 * d;
           a.hact = h->fc.hact_p[l - 1]; a.hact_ld = h->fc.hact_ld[l - 1]; a.act = h->act;
+          LGNN_REQUIRE(!store || pong != nullptr, "internal: stored planes without a buffer");
           a.store = store ? pong : nullptr; a.store_ld = d; a.store_plane_stride = N * d;
           a.width = d; a.scratch = scratch;
           if (!no_fuse && fused_supported(d, a.in_ld, a.in_plane_stride, a.in) && h->fc.hact_ld[l - 1] % 4 == 0) {
@@ -691,6 +704,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
             LGNN_CALL(launch_spmm_gram_ex(a, s));
             if (h->timing && dominant) { LGNN_CALL(record_event(h, s)); h->ev_planes += cc; }
           } else {
+            LGNN_REQUIRE(pong != nullptr, "internal: unfused path without its output planes");
             SpmmArgs sa{};
             sa.rowptr = a.rowptr; sa.col = a.col; sa.val = a.val; sa.nrows = N;
             sa.in = a.in; sa.in_ld = a.in_ld; sa.in_plane_stride = a.in_plane_stride;

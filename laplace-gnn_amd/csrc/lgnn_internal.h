@@ -116,7 +116,7 @@ struct lgnn_ctx {
   lgnn::DevBuf Wt[lgnn::kMaxLayers];  // W_l^T [in_l, out_l] (forward GEMM operand)
   lgnn::ForwardCache fc;
   lgnn::Workspace ws;
-  int64_t ws_limit = int64_t(8) << 30;
+  int64_t ws_limit = int64_t(32) << 30;  // backward planes (ping + pong) per class chunk: 288 GB of HBM, keep chunks large
   // timing of the dominant kernel
   bool timing = false;
   std::vector<hipEvent_t> ev;   // pairs (start, stop), grown on demand
