@@ -38,6 +38,8 @@ WORKLOADS = {
     # name: N, undirected edges, F, H, C, N_train, batch
     "arxiv": dict(N=169_343, E=1_166_243, F=128, H=256, C=40, n_train=90_941, batch=10_000),
     "cora": dict(N=2_708, E=5_278, F=1_433, H=64, C=7, n_train=1_299, batch=10_000),
+    # same graph and widths as "arxiv" with the other model family of the path (GraphSAGE, mean aggregation)
+    "arxiv_sage": dict(N=169_343, E=1_166_243, F=128, H=256, C=40, n_train=90_941, batch=10_000, kind="sage"),
     # BASELINE configs[4]: 3-layer GraphSAGE, last-layer full GGN (P_LL = 47 * 513 = 24 111), power-law degrees
     "products": dict(N=2_449_029, E=61_859_140, F=100, H=256, C=47, n_train=196_615, batch=10_000, layers=3,
                      kind="sage", powerlaw=0.5),
@@ -82,8 +84,9 @@ def cpu_baseline(name: str, ei, X, Ws, bs, train_idx, train_y, w, structure="kro
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         cores = os.cpu_count() or 1
-    rp, col = O.edge_index_to_adj_csr(ei.numpy(), w["N"], "gcn", True)
-    om = O.GnnModel("gcn", rp, col, X.numpy(), Ws, bs)
+    kind = w.get("kind", "gcn")
+    rp, col = O.edge_index_to_adj_csr(ei.numpy(), w["N"], kind, True)
+    om = O.GnnModel(kind, rp, col, X.numpy(), Ws, bs)
     M = min(w["batch"], w["n_train"])
     t0 = time.perf_counter()
     if structure == "kron":
@@ -132,7 +135,8 @@ def main():
     cls = lg.GraphSAGE if w.get("kind") == "sage" else lg.GCN
     model = cls(w["F"], w["H"], w["C"], w.get("layers", 2), X, ei, symmetric=True).to(dev)
     loader = lg.TensorBatchLoader(train_idx.to(dev), train_y.to(dev), batch_size=w["batch"])
-    structure = args.structure or {"arxiv": "kron", "cora": "diag", "products": "lastlayer"}[args.workload]
+    structure = args.structure or {"arxiv": "kron", "arxiv_sage": "kron", "cora": "diag",
+                                   "products": "lastlayer"}[args.workload]
     if structure == "lastlayer":
         la = lg.Laplace(model, "classification", subset_of_weights="last_layer", hessian_structure="full")
     else:
@@ -200,7 +204,8 @@ def main():
                 "kernel_share_of_wall": kern_ms * 1e-3 / elapsed,
             }
         out = {
-            "metric": {"kron": "la.fit() samples/sec (GCN, KFAC)", "diag": "la.fit() samples/sec (GCN, diag GGN)",
+            "metric": {"kron": f"la.fit() samples/sec ({'GraphSAGE' if w.get('kind') == 'sage' else 'GCN'}, KFAC)",
+                       "diag": "la.fit() samples/sec (GCN, diag GGN)",
                        "lastlayer": "la.fit() samples/sec (GraphSAGE, last-layer full GGN)"}[structure],
             "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,7 +214,8 @@ def main():
             "config": {
                 "workload": f"{args.workload}-shaped {w.get('layers', 2)}-layer {w.get('kind', 'gcn').upper()}, "
                             f"hessian_structure={structure} "
-                            f"(BASELINE configs[{dict(arxiv=2, cora=1, products=4)[args.workload]}])",
+                            + (f"(BASELINE configs[{dict(arxiv=2, cora=1, products=4)[args.workload]}])"
+                               if args.workload in ("arxiv", "cora", "products") else "(not a BASELINE config)"),
                 "num_nodes": N, "nnz": nnz, "features": w["F"], "hidden": H, "classes": C,
                 "n_train": w["n_train"], "batch_size": w["batch"],
                 "batches": len(loader), "parallelism": f"dp{world} ((batch, class) units, contiguous balanced runs)",

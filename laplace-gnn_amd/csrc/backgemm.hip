@@ -235,12 +235,16 @@ __global__ void relu_mask_bits_kernel(const float* __restrict__ h, int64_t ld, i
 
 }  // namespace
 
-bool backgemm_supported(int64_t K, int64_t Nout) { return K >= 1 && K <= 64 && Nout >= 1 && Nout <= 256; }
+// with_mask: the ReLU bit mask has 8 words per node (256 columns); without it the width is only bounded by the
+// 32-bit row offsets (checked at launch)
+bool backgemm_supported(int64_t K, int64_t Nout, bool with_mask) {
+  return K >= 1 && K <= 64 && Nout >= 1 && Nout <= (with_mask ? 256 : 1024);
+}
 
 int launch_backgemm(const BackGemmArgs& g_in, hipStream_t s) {
   BackGemmArgs g = g_in;
   if (g.planes <= 0 || g.N <= 0) return 0;
-  LGNN_REQUIRE(backgemm_supported(g.K, g.Nout), "backgemm shape not supported");
+  LGNN_REQUIRE(backgemm_supported(g.K, g.Nout, g.mask_bits != nullptr), "backgemm shape not supported");
   LGNN_REQUIRE(g.mask_bits == nullptr || g.mask_words <= 8, "backgemm: at most 8 mask words per node");
   LGNN_REQUIRE(cdiv(g.N, BGM) * g.planes < (int64_t(1) << 31), "backgemm: too many row tiles for 32-bit indices");
   LGNN_REQUIRE((g.N + 1) * g.Nout * 4 < (int64_t(1) << 31), "backgemm: plane too large for 32-bit row offsets");

@@ -180,6 +180,26 @@ __global__ __launch_bounds__(256) void mark_active_kernel(const int64_t* __restr
   for (int32_t p = rowptr[n] + lane; p < e; p += 64) active[col[p]] = 1;
 }
 
+// GraphSAGE: the rows of the top-layer gradient that are not identically zero are the batch nodes themselves
+__global__ void mark_batch_flags_kernel(const int64_t* __restrict__ idx, int64_t M, int64_t N, uint8_t* __restrict__ active) {
+  const int64_t m = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int64_t n = idx[m];
+  if (n >= 0 && n < N) active[n] = 1;
+}
+
+// zero the listed rows of every plane again (16 bytes per thread): U[p][rows[i]][0 .. width)
+__global__ void clear_rows_kernel(float* __restrict__ U, int64_t plane_stride, int64_t width, int64_t planes,
+                                  const int32_t* __restrict__ rows, const int32_t* __restrict__ count) {
+  const int64_t w4 = width / 4, per_plane = int64_t(*count) * w4, total = per_plane * planes;
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < total; q += stride) {
+    const int64_t p = q / per_plane, r = q - p * per_plane;
+    const int64_t i = r / w4, c4 = r - i * w4;
+    *reinterpret_cast<float4*>(U + p * plane_stride + int64_t(rows[i]) * width + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // GCN top layer over the ACTIVE nodes only, with the top-layer Gram fused in:
@@ -550,6 +570,13 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   }
   LGNN_CALL(h->ws.active.reserve(size_t(N)));
   bool have_act_list = false;
+  // GraphSAGE, fused path: the top-level GEMM g W_l runs over the (distinct) batch nodes only -- 6 % of the rows at
+  // the arxiv shape -- through the compacted-row backward GEMM; the other rows of its output stay zero (see below)
+  const int64_t d_top = L > 1 ? h->dims[L - 1] : 0;
+  const bool sage_compact = h->kind == LGNN_KIND_SAGE && L > 1 && !no_fuse && h->nnz > 0 &&
+                            backgemm_supported(C, 2 * d_top, false) && (N + 1) * 2 * d_top * 4 < (int64_t(1) << 31) &&
+                            fused_supported(d_top, 2 * d_top, (N + 1) * 2 * d_top, h->ws.top.p) &&
+                            h->fc.hact_ld[L - 2] % 4 == 0;
   if (h->kind == LGNN_KIND_GCN) {
     const int64_t nq = (ce - cb) * C;
     if (seeds_on_the_fly) {
@@ -587,7 +614,8 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
     // rows (m, c) of the accumulated seeds; rows of non-first duplicates are zero
     if (first) LGNN_CALL(launch_gram(h->ws.seeds.as<float>(), C, M * C, C, h->ws.gram_scratch[L - 1].as<float>(), s));
     if (L > 1) {
-      LGNN_HIP_CHECK(hipMemsetAsync(gtop + cb * N * C, 0, size_t(N) * (ce - cb) * C * 4, s));
+      // the compact top level reads the planes at the batch nodes only; every other path reads all rows
+      if (!sage_compact) LGNN_HIP_CHECK(hipMemsetAsync(gtop + cb * N * C, 0, size_t(N) * (ce - cb) * C * 4, s));
       hipLaunchKernelGGL(scatter_seed_planes_kernel, dim3(unsigned(M)), dim3(256), 0, s, idx, M, N, C,
                          h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), gtop, cb, ce);
       LGNN_HIP_CHECK(hipGetLastError());
@@ -609,6 +637,16 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
                          h->ws.pos.as<int32_t>(), h->ws.val_act.as<float>());
       LGNN_HIP_CHECK(hipGetLastError());
       val_top = h->ws.val_act.as<float>();
+      if (sage_compact) {
+        LGNN_HIP_CHECK(hipMemsetAsync(h->ws.active.p, 0, size_t(N), s));
+        hipLaunchKernelGGL(mark_batch_flags_kernel, dim3(unsigned(cdiv(M, 256))), dim3(256), 0, s, idx, M, N,
+                           h->ws.active.as<uint8_t>());
+        LGNN_HIP_CHECK(hipGetLastError());
+        LGNN_CALL(h->ws.act_list.reserve(size_t(N) * 4));
+        LGNN_CALL(h->ws.act_count.reserve(64));
+        LGNN_CALL(compact_flags(h->ws.active.as<uint8_t>(), N, h->ws.act_list.as<int32_t>(),
+                                h->ws.act_count.as<int32_t>(), h->ws.select_tmp, s));
+      }
       if (gcn) {
         row_active = h->ws.active.as<uint8_t>();
         if (!have_act_list) {
@@ -654,7 +692,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           const bool fuse_here = !no_fuse && fused_supported(d, d, N * d, ping);
           if (top_level && fuse_here) ep.row_active = row_active;  // inactive rows are never read below
           int64_t ping_stride = N * d;
-          if (top_level && fuse_here && row_active && backgemm_supported(dout, d)) {
+          if (top_level && fuse_here && row_active && backgemm_supported(dout, d, h->act == LGNN_ACT_RELU)) {
             ping_stride = (N + 1) * d;  // row N of every plane takes the stores of rows past the end of the list
             BackGemmArgs bg{};
             bg.u_plane_stride = ping_stride;
@@ -688,13 +726,33 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           }
         } else {
           // dcat = g W_l  [cc*N, 2d];  g_{l-1} = act'(h_l) * (dcat[:, :d] + P^T dcat[:, d:])
-          GemmEpilogue ep;
-          LGNN_CALL(launch_gemm(g, dout, h->W[l], 2 * d, ping, 2 * d, cc * N, dout, 2 * d, ep, s));
+          const bool compact = sage_compact && l == L - 1;
+          int64_t ping_stride = N * 2 * d;
+          if (compact) {
+            // rows of dcat other than the batch nodes' are zero: the buffer is zeroed once (per allocation / extent)
+            // and the rows written here are cleared again after the fused kernel has consumed them
+            ping_stride = (N + 1) * 2 * d;
+            const size_t extent = size_t(cc) * ping_stride * 4;
+            if (h->ws.planes_a_zero_ptr != h->ws.planes_a.p || h->ws.planes_a_zero_bytes < extent) {
+              LGNN_HIP_CHECK(hipMemsetAsync(h->ws.planes_a.p, 0, extent, s));
+              h->ws.planes_a_zero_ptr = h->ws.planes_a.p;
+              h->ws.planes_a_zero_bytes = extent;
+            }
+            BackGemmArgs bg{};
+            bg.G = g; bg.W = h->W[l]; bg.ldw = 2 * d; bg.U = ping; bg.N = N; bg.K = dout; bg.Nout = 2 * d; bg.planes = cc;
+            bg.u_plane_stride = ping_stride;
+            bg.rows = h->ws.act_list.as<int32_t>(); bg.na_dev = h->ws.act_count.as<int32_t>();
+            LGNN_CALL(launch_backgemm(bg, s));
+          } else {
+            GemmEpilogue ep;
+            LGNN_CALL(launch_gemm(g, dout, h->W[l], 2 * d, ping, 2 * d, cc * N, dout, 2 * d, ep, s));
+            h->ws.planes_a_zero_ptr = nullptr;  // every row written
+          }
           FusedArgs a{};
           a.rowptr = h->PT.rowptr; a.col = h->PT.col; a.val = (l == L - 1) ? val_top : h->PT.val;
           a.nrows = N; a.nplanes = cc;
-          a.in = ping + d; a.in_ld = 2 * d; a.in_plane_stride = N * 2 * d;
-          a.self = ping; a.self_ld = 2 * d; a.self_plane_stride = N * 2 * d;
+          a.in = ping + d; a.in_ld = 2 * d; a.in_plane_stride = ping_stride;
+          a.self = ping; a.self_ld = 2 * d; a.self_plane_stride = ping_stride;
           a.hact = h->fc.hact_p[l - 1]; a.hact_ld = h->fc.hact_ld[l - 1]; a.act = h->act;
           LGNN_REQUIRE(!store || pong != nullptr, "internal: stored planes without a buffer");
           a.store = store ? pong : nullptr; a.store_ld = d; a.store_plane_stride = N * d;
@@ -703,7 +761,13 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
             if (h->timing && dominant) LGNN_CALL(record_event(h, s));
             LGNN_CALL(launch_spmm_gram_ex(a, s));
             if (h->timing && dominant) { LGNN_CALL(record_event(h, s)); h->ev_planes += cc; }
+            if (compact) {
+              hipLaunchKernelGGL(clear_rows_kernel, dim3(2048), dim3(256), 0, s, ping, ping_stride, 2 * d, cc,
+                                 h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>());
+              LGNN_HIP_CHECK(hipGetLastError());
+            }
           } else {
+            LGNN_REQUIRE(!compact, "internal: compact GraphSAGE top level without the fused kernel");
             LGNN_REQUIRE(pong != nullptr, "internal: unfused path without its output planes");
             SpmmArgs sa{};
             sa.rowptr = a.rowptr; sa.col = a.col; sa.val = a.val; sa.nrows = N;

@@ -80,6 +80,10 @@ struct Workspace {
   DevBuf probs;     // fp32 [M, C] softmax
   DevBuf mult;      // int32 [M]: occurrences of the node whose first batch position this is (0 elsewhere)
   DevBuf planes_a;  // backward planes, ping
+  // GraphSAGE compact top level: planes_a is kept all zero outside the rows of the current batch (which are cleared
+  // again after use); these remember for which buffer / extent that holds
+  const void* planes_a_zero_ptr = nullptr;
+  size_t planes_a_zero_bytes = 0;
   DevBuf planes_b;  // backward planes, pong
   DevBuf gram_scratch[kMaxLayers];  // [out_l, out_l] per-call partial B (upper sub-tiles)
   DevBuf misc;
@@ -174,7 +178,7 @@ struct BackGemmArgs {
   const float* hact; int64_t hact_ld; int act;    // float activations otherwise
   int debug;
 };
-bool backgemm_supported(int64_t K, int64_t Nout);
+bool backgemm_supported(int64_t K, int64_t Nout, bool with_mask);
 int launch_backgemm(const BackGemmArgs& g, hipStream_t s);
 int launch_relu_mask_bits(const float* h, int64_t ld, int64_t N, int64_t H, uint32_t* bits, hipStream_t s);
 // out[0:count) = sorted indices i with flags[i] != 0; *count_dev = count   (graph.hip, rocPRIM select)
