@@ -98,6 +98,10 @@ static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
         LGNN_CALL(launch_gemm(cat, 2 * d, h->Wt[l].as<float>(), dout, nxt, 2 * dout, N, 2 * d, dout, ep, s));
         fc.hact_p[l] = nxt;
         fc.hact_ld[l] = 2 * dout;
+        if (h->act == LGNN_ACT_RELU) {  // bit masks of the ReLU derivative for the fused backward kernel
+          LGNN_CALL(fc.mask_bits[l].reserve(size_t(N) * cdiv(dout, 32) * 4 + 32));
+          LGNN_CALL(launch_relu_mask_bits(fc.hact_p[l], 2 * dout, N, dout, fc.mask_bits[l].as<uint32_t>(), s));
+        }
       } else {
         LGNN_CALL(launch_gemm(cat, 2 * d, h->Wt[l].as<float>(), dout, fc.out.as<float>(), dout, N, 2 * d, dout, ep, s));
       }

@@ -129,6 +129,11 @@ __device__ __forceinline__ void mfma_wave(const FusedArgs& a, const float* __res
   gram256_flush<W>(a.scratch, a.width, lane, acc);
 }
 
+// MODE 0: general (optional self / float activation rows behind wave-uniform branches; the GCN path uses neither).
+// MODE 1: GraphSAGE with ReLU, nothing conditional in the row loop: the self row is a buffer load whose offset is out
+//         of range for rows flagged as all zero (no memory access), the derivative comes from the row's bit mask
+//         (32 B instead of 1 KiB), both fetched one row ahead.
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
   __shared__ float tile[2][KT256][256];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -182,8 +187,17 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
         ent[it] = load_entries(colp, valp, s, e, lane);
       }
     };
+    // MODE 1: self-row flags of the block's 32 rows, one per lane, fetched with the row pointers
+    auto load_fl = [&](int64_t i) -> int32_t {
+      if constexpr (MODE != 1) return 0;
+      int64_t plane = 0, rb = 0;
+      block_coords(i < nb ? i : (nb > 0 ? nb - 1 : 0), plane, rb);
+      const int64_t r = rb + (lane & 31);
+      return a.self_rows[r < a.nrows ? r : a.nrows - 1];
+    };
     RowEntries ent[RPWB], ent_next[RPWB];
     int32_t rp_next = load_rp(0);
+    int32_t fl_cur = load_fl(0), fl_next = 0;
     load_block_entries(0, rp_next, ent);
     rp_next = load_rp(1);
     for (int64_t i = 0; i <= nb; ++i) {
@@ -196,6 +210,27 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
         float* __restrict__ t = &tile[i & 1][0][0];
 #pragma unroll
         for (int it = 0; it < RPWB; ++it) compact_entries(ent[it], lane, row_bytes);
+        // MODE 1: self row (zeros without a memory access when the row's flag is 0 or the row does not exist) and
+        // mask word of row `itn` of this wave
+        float4 q_nx = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t mw_nx = 0;
+        srd_t srd_self = srd;
+        if constexpr (MODE == 1)
+          srd_self = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.self + plane * a.self_plane_stride), 0,
+                                                       int(uint32_t(a.nrows * a.self_ld * 4)), 0x00020000);
+        auto fetch_self_mask = [&](int itn) {
+          if constexpr (MODE == 1) {
+            const int rn = itn * 4 + wave;
+            const int64_t rown = rb + rn;
+            const bool have = rown < a.nrows && __builtin_amdgcn_readlane(fl_cur, rn) != 0;
+            const int32_t soff = have ? int32_t(uint32_t(rown) * uint32_t(a.self_ld * 4)) : int32_t(0xfffffff0u);
+            const u32x4 tq = __builtin_amdgcn_raw_buffer_load_b128(srd_self, voff, soff, 0);
+            q_nx = make_float4(__uint_as_float(tq.x), __uint_as_float(tq.y), __uint_as_float(tq.z), __uint_as_float(tq.w));
+            const int64_t rc = rown < a.nrows ? rown : a.nrows - 1;
+            mw_nx = a.mask_bits[rc * a.mask_words + (c0 < int(a.width) ? (c0 >> 5) : 0)];
+          }
+        };
+        fetch_self_mask(0);
         // gathers DEPTH rows deep: rows it+1 .. it+DEPTH-1 are in flight while row it is consumed
         float4 x[DEPTH][UNR];
 #pragma unroll
@@ -208,6 +243,7 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
           if (it + DEPTH - 1 == RPWB - 1) {  // all gathers of this block are issued: fetch the next block's rows
             load_block_entries(i + 1, rp_next, ent_next);
             rp_next = load_rp(i + 2);
+            fl_next = load_fl(i + 1);
           }
           float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
           accumulate<true>(y, ent[it], 0, x[it % DEPTH]);
@@ -215,7 +251,19 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
             gather_rest(y, ent[it], colp, valp, srd, voff, row_bytes, lane);
           const int r = it * 4 + wave;
           const int64_t row = rb + r;
-          if (row < a.nrows && col_ok) {
+          if constexpr (MODE == 1) {
+            // self row and mask word of THIS row were issued one row ahead (q_nx / mw_nx); issue the next row's now
+            const float4 q = q_nx;
+            const uint32_t mword = mw_nx;
+            if (it + 1 < RPWB) fetch_self_mask(it + 1);
+            y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w;
+            const uint32_t bits = mword >> (c0 & 31);
+            y.x = (bits & 1u) ? y.x : 0.f; y.y = (bits & 2u) ? y.y : 0.f;
+            y.z = (bits & 4u) ? y.z : 0.f; y.w = (bits & 8u) ? y.w : 0.f;
+            if (!(row < a.nrows && col_ok)) y = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.store && row < a.nrows && col_ok)
+              *reinterpret_cast<float4*>(a.store + plane * a.store_plane_stride + row * a.store_ld + c0) = y;
+          } else if (row < a.nrows && col_ok) {
             if (a.self) {
               const float4 q =
                   *reinterpret_cast<const float4*>(a.self + plane * a.self_plane_stride + row * a.self_ld + c0);
@@ -235,6 +283,7 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
         }
 #pragma unroll
         for (int it = 0; it < RPWB; ++it) ent[it] = ent_next[it];
+        fl_cur = fl_next;
       }
       if (a.debug != 4) __syncthreads();
     }
@@ -260,7 +309,13 @@ int launch_spmm_gram256(const FusedArgs& a_in, hipStream_t s) {
   LGNN_REQUIRE(a.nrows * a.in_ld * 4 < (int64_t(1) << 32) - 4096, "plane too large for 32-bit buffer offsets");
   const int64_t nblocks = cdiv(a.nrows, KT256) * a.nplanes;
   const unsigned grid = unsigned(std::min<int64_t>(nblocks, 256));  // one persistent workgroup per CU
-  hipLaunchKernelGGL(spmm_gram256_kernel, dim3(grid), dim3(512), 0, s, a);
+  if (a.self && a.self_rows && a.mask_bits) {
+    LGNN_REQUIRE(a.nrows * a.self_ld * 4 < (int64_t(1) << 32) - 4096, "self plane too large for 32-bit buffer offsets");
+    LGNN_REQUIRE(a.mask_words * 32 >= a.width, "mask words do not cover the plane width");
+    hipLaunchKernelGGL(spmm_gram256_kernel<1>, dim3(grid), dim3(512), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(spmm_gram256_kernel<0>, dim3(grid), dim3(512), 0, s, a);
+  }
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }

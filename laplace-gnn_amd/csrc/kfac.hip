@@ -754,6 +754,13 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           a.in = ping + d; a.in_ld = 2 * d; a.in_plane_stride = ping_stride;
           a.self = ping; a.self_ld = 2 * d; a.self_plane_stride = ping_stride;
           a.hact = h->fc.hact_p[l - 1]; a.hact_ld = h->fc.hact_ld[l - 1]; a.act = h->act;
+          if (compact && h->act == LGNN_ACT_RELU && d > 128) {
+            // 256-wide kernel, nothing conditional in its row loop: self rows exist for the batch nodes only (flags),
+            // the ReLU derivative comes from the bit masks of the forward
+            a.self_rows = h->ws.active.as<uint8_t>();
+            a.mask_bits = h->fc.mask_bits[l - 1].as<uint32_t>();
+            a.mask_words = int(cdiv(d, 32));
+          }
           LGNN_REQUIRE(!store || pong != nullptr, "internal: stored planes without a buffer");
           a.store = store ? pong : nullptr; a.store_ld = d; a.store_plane_stride = N * d;
           a.width = d; a.scratch = scratch;

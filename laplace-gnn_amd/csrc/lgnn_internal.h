@@ -159,6 +159,9 @@ struct FusedArgs {
   float* store; int64_t store_ld; int64_t store_plane_stride;  // optional
   const float* self; int64_t self_ld; int64_t self_plane_stride;  // optional
   const float* hact; int64_t hact_ld; int act;                    // optional
+  // GraphSAGE fast path of the 256-wide kernel (both set): rows whose flag is 0 have an all-zero self row (not read);
+  // ReLU derivative from bit masks [nrows][mask_words] instead of the float activations
+  const uint8_t* self_rows; const uint32_t* mask_bits; int mask_words;
   int64_t width;     // D <= DT
   float* scratch;    // [D, D]
   int debug;         // dev experiments: 1 = skip MFMAs, 2 = skip gathers

@@ -236,7 +236,9 @@ def test_class_ranges_are_exact_shares_and_units_cover_a_fit(kind):
     ("gcn", 96, 5, 2),     # width not a multiple of 32
     ("gcn", 30, 4, 2),     # width % 4 != 0: unfused fallback (SpMM + Gram through HBM)
     ("gcn", 200, 70, 2),   # K > 64: generic GEMM instead of backgemm
-    ("sage", 256, 10, 2),  # GraphSAGE through fused256 with self path + mask epilogue
+    ("sage", 256, 10, 2),  # GraphSAGE through fused256 MODE 1: self rows by flag, mask bits at the destination
+    ("sage", 256, 40, 2),  # the same at the arxiv widths (8 mask words, 40 planes)
+    ("sage", 192, 9, 3),   # three layers: compact top level, then the general path with stored planes
     ("sage", 64, 33, 3),
 ])
 def test_kfac_kernel_variants_vs_oracle(kind, H, C, L):
