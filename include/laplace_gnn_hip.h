@@ -163,6 +163,13 @@ LGNN_API int lgnn_check_async_errors(lgnn_ctx* h, void* stream);
 LGNN_API int lgnn_enable_kernel_timing(lgnn_ctx* h, int enable);
 LGNN_API int lgnn_kernel_timing_read(lgnn_ctx* h, int64_t* launches, double* total_ms, int64_t* planes);
 
+/* ---- per-sample Jacobians for the GLM predictive ("next" row) ------------------------------------
+ * Replaces CurvatureInterface.jacobians (laplace/curvature/curvature.py:89-130, torch.func.jacrev of the dense
+ * model): J [M, C, P] fp32 with J[m][c][:] = d f[idx[m], c] / d theta, parameters in named_parameters order
+ * (per layer: weight [out, in] row major, then bias); f_out [M, C] = logits[idx] or NULL.  M*C*P floats, as the
+ * reference; the samples are processed in chunks that fit the workspace cap.                              */
+LGNN_API int lgnn_jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out, void* stream);
+
 /* ---- decomposition of the fitted factors ("next" row: KronLaplace.fit -> Kron.decompose) ----------
  * Replaces the per-factor torch.linalg.eigh calls of laplace/utils/matrix.py:118-145 (symeig,
  * laplace/utils/utils.py:193-226) by ONE strided-batched rocSOLVER syevd over all factors.

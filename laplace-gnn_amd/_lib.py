@@ -44,6 +44,7 @@ SIGNATURES = {
     "lgnn_enable_kernel_timing": (_i32, [_vp, _i32]),
     "lgnn_kernel_timing_read": (_i32, [_vp, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "lgnn_symeig_batched": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "lgnn_jacobians": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -18,6 +18,15 @@ DevBuf g_e;  // off-diagonal workspace [batch, n]
 }  // namespace
 }  // namespace lgnn
 
+namespace lgnn {
+// the process-wide rocBLAS handle, bound to stream `s` (also used by jacobian.hip); nullptr on failure
+void* blas_handle(hipStream_t s) {
+  if (!g_handle && rocblas_create_handle(&g_handle) != rocblas_status_success) return nullptr;
+  if (rocblas_set_stream(g_handle, s) != rocblas_status_success) return nullptr;
+  return g_handle;
+}
+}  // namespace lgnn
+
 using namespace lgnn;
 
 // A: [batch][n][n] fp32, symmetric, overwritten: row j of matrix b = eigenvector j (unit norm) for eigenvalue W[b][j],
@@ -26,11 +35,8 @@ using namespace lgnn;
 extern "C" int lgnn_symeig_batched(float* A, int64_t n, int64_t batch, float* W, int32_t* info, void* stream) {
   if (!A || !W || !info) { set_error("null argument"); return 2; }
   LGNN_REQUIRE(n > 0 && n <= 32768 && batch > 0 && batch <= 65535, "symeig: bad shape");
-  if (!g_handle) {
-    if (rocblas_create_handle(&g_handle) != rocblas_status_success) { set_error("rocblas_create_handle failed"); return 3; }
-  }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (rocblas_set_stream(g_handle, s) != rocblas_status_success) { set_error("rocblas_set_stream failed"); return 3; }
+  if (!blas_handle(s)) { set_error("rocBLAS handle / stream setup failed"); return 3; }
   LGNN_CALL(g_e.reserve(size_t(batch) * n * 4));
   const rocblas_status st = rocsolver_ssyevd_strided_batched(
       g_handle, rocblas_evect_original, rocblas_fill_upper, rocblas_int(n), A, rocblas_int(n), rocblas_stride(n * n), W,

@@ -120,11 +120,19 @@ class HipCurvatureInterface:
     def check_async_errors(self):
         self.engine.check_async_errors()
 
-    def jacobians(self, x, enable_backprop: bool = True):
-        raise NotImplementedError("explicit Jacobians (GLM predictive) are a 'next' row (SURVEY.md 8(f)-3)")
+    def jacobians(self, x: torch.Tensor, enable_backprop: bool = False):
+        """(Js [M, C, P], f [M, C]) as CurvatureInterface.jacobians (laplace/curvature/curvature.py:89-130); the
+        M * C backward passes run as planes through the HIP engine (csrc/jacobian.hip).  No autograd graph."""
+        if enable_backprop:
+            raise NotImplementedError("the HIP Jacobians carry no autograd graph (enable_backprop=False only)")
+        if self.last_layer:
+            raise NotImplementedError("last-layer Jacobians: use the all-weights Jacobians' last block")
+        return self.engine.jacobians(x)
 
-    last_layer_jacobians = jacobians
     functorch_jacobians = jacobians
+
+    def last_layer_jacobians(self, x, enable_backprop: bool = False):
+        raise NotImplementedError("last-layer Jacobians (GLM predictive of last-layer Laplace) are not implemented")
 
     def gradients(self, x, y):
         raise NotImplementedError("per-sample gradients (empirical Fisher) are out of scope")

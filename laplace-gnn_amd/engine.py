@@ -228,6 +228,18 @@ class GraphEngine:
             _dev_ptr(H, torch.float32, "H"), loss.data_ptr(), _stream(self.device))
         _lib.check(rc, "lgnn_lastlayer_full_accumulate")
 
+    def jacobians(self, idx: torch.Tensor):
+        """(J [M, C, P], f [M, C]): per-sample Jacobians of the logits w.r.t. all parameters, parameters in
+        module order (weight row major, bias) -- laplace/curvature/curvature.py:89-130."""
+        self._sync_versions()
+        idx = idx.contiguous()
+        M, C = idx.shape[0], self.dims[-1]
+        J = torch.empty(M, C, self.n_params, dtype=torch.float32, device=self.device)
+        f = torch.empty(M, C, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.lgnn_jacobians(self._h, _dev_ptr(idx, torch.int64, "idx"), M, J.data_ptr(), f.data_ptr(),
+                                           _stream(self.device)), "lgnn_jacobians")
+        return J, f
+
     def check_async_errors(self):
         """Synchronise and raise if any batch since the last check contained an invalid node id or label."""
         _lib.check(self.lib.lgnn_check_async_errors(self._h, _stream(self.device)), "lgnn_check_async_errors")

@@ -200,23 +200,86 @@ class ParametricLaplace(BaseLaplace):
         raise NotImplementedError
 
     @torch.no_grad()
-    def __call__(self, x, pred_type: str = "nn", link_approx: str = "mc", n_samples: int = 100,
-                 generator: torch.Generator | None = None, eps: torch.Tensor | None = None, **kwargs):
-        if pred_type != "nn" or link_approx != "mc":
-            raise NotImplementedError("only the sampling predictive (pred_type='nn', link_approx='mc') is implemented; "
-                                      "the GLM predictive needs explicit Jacobians (SURVEY.md 8(f)-3)")
+    def __call__(self, x, pred_type: str = "glm", link_approx: str = "probit", n_samples: int = 100,
+                 diagonal_output: bool = False, generator: torch.Generator | None = None,
+                 eps: torch.Tensor | None = None, **kwargs):
+        """Posterior predictive (laplace/baselaplace.py:975-1072), classification.
+
+        ``pred_type="glm"`` (default, with ``link_approx`` in probit / mc / bridge / bridge_norm): linearised model,
+        ``f ~ N(f_mu, J P^-1 J^T)`` from explicit Jacobians (:1123-1158, :570-665).  ``pred_type="nn"`` with
+        ``link_approx="mc"``: parameter samples, one forward each (:1183-1199).  ``eps`` replaces the random draws
+        (standard normal, [n_samples, n_params] for "nn", [n_outputs, n_samples] for "glm"/"mc")."""
         if self.likelihood != "classification":
             raise NotImplementedError("classification only")
+        if pred_type not in ("glm", "nn"):
+            raise ValueError("Only glm and nn supported as prediction types.")
+        if link_approx not in ("mc", "probit", "bridge", "bridge_norm"):
+            raise ValueError(f"Unsupported link approximation {link_approx}.")
+        if pred_type == "nn" and link_approx != "mc":
+            raise ValueError("Only mc link approximation is supported for nn prediction type.")
+        x = x.to(self._device)
+        if pred_type == "glm":
+            return self._glm_forward_call(x, link_approx, n_samples, diagonal_output, generator, eps)
         from torch.nn.utils import vector_to_parameters
         py = 0.0
         samples = self.sample(n_samples, generator=generator, eps=eps)
         try:
             for theta in samples:
                 vector_to_parameters(theta, self.params)
-                py = py + torch.softmax(self.model(x.to(self._device)), dim=-1) / len(samples)
+                py = py + torch.softmax(self.model(x), dim=-1) / len(samples)
         finally:
             vector_to_parameters(self.mean.clone(), self.params)  # the parameters must not alias self.mean afterwards
         return py
+
+    # ---- GLM predictive ("next" row 8(f)-3) ---------------------------------------------------------------------
+    def functional_variance(self, Js: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def _glm_predictive_distribution(self, x, diagonal_output: bool = False):
+        """(f_mu [M, C], f_var [M, C, C]) (laplace/baselaplace.py:1123-1158)."""
+        Js, f_mu = self.backend.jacobians(x, enable_backprop=False)
+        if Js.shape[1:] != (self.n_outputs, self.n_params):
+            raise ValueError("Invalid Jacobians shape for Laplace posterior approx.")
+        f_var = self.functional_variance(Js)
+        if diagonal_output:
+            f_var = torch.diagonal(f_var, dim1=-2, dim2=-1)
+        return f_mu, f_var
+
+    def _glm_forward_call(self, x, link_approx, n_samples, diagonal_output, generator, eps):
+        """laplace/baselaplace.py:570-665 (classification branches)."""
+        f_mu, f_var = self._glm_predictive_distribution(x)
+        if link_approx == "mc":
+            return self._glm_predictive_samples(f_mu, f_var, n_samples, diagonal_output, generator, eps).mean(dim=0)
+        if link_approx == "probit":
+            kappa = 1 / torch.sqrt(1.0 + pi / 8 * f_var.diagonal(dim1=1, dim2=2))
+            return torch.softmax(kappa * f_mu, dim=-1)
+        # Laplace bridge with zero-mean correction (:630-660)
+        f_mu = f_mu - (f_var.sum(-1) * f_mu.sum(-1).reshape(-1, 1) / f_var.sum(dim=(1, 2)).reshape(-1, 1))
+        f_var = f_var - torch.einsum("bi,bj->bij", f_var.sum(-1), f_var.sum(-2)) / f_var.sum(dim=(1, 2)).reshape(-1, 1, 1)
+        K = f_mu.size(-1)
+        f_var_diag = torch.diagonal(f_var, dim1=1, dim2=2).clone()
+        if link_approx == "bridge_norm":
+            f_var_diag_mean = f_var_diag.mean(dim=1)
+            f_var_diag_mean = f_var_diag_mean / torch.as_tensor([K / 2], device=self._device).sqrt()
+            f_mu = f_mu / f_var_diag_mean.sqrt().unsqueeze(-1)
+            f_var_diag = f_var_diag / f_var_diag_mean.unsqueeze(-1)
+        sum_exp = torch.exp(-f_mu).sum(dim=1).unsqueeze(-1)
+        alpha = (1 - 2 / K + f_mu.exp() / K ** 2 * sum_exp) / f_var_diag
+        return torch.nan_to_num(alpha / alpha.sum(dim=1).unsqueeze(-1), nan=1.0)
+
+    def _glm_predictive_samples(self, f_mu, f_var, n_samples, diagonal_output=False, generator=None, eps=None):
+        """softmax of samples of N(f_mu, f_var): laplace/baselaplace.py:667-709 + utils.normal_samples (:329-369)."""
+        if diagonal_output:
+            f_var = torch.diagonal(f_var, dim1=1, dim2=2)
+        C = f_mu.shape[1]
+        if eps is None:
+            eps = torch.randn((C, n_samples), device=f_mu.device, dtype=f_mu.dtype, generator=generator)
+        eps = eps.to(f_mu.device)
+        if f_var.ndim == 2:
+            scaled = f_var.sqrt().unsqueeze(-1) * eps.unsqueeze(0)
+        else:
+            scaled = torch.matmul(torch.linalg.cholesky(f_var), eps.unsqueeze(0))
+        return torch.softmax((f_mu.unsqueeze(-1) + scaled).permute((2, 0, 1)), dim=-1)
 
     @property
     def log_likelihood(self) -> torch.Tensor:
@@ -350,6 +413,9 @@ class KronLaplace(ParametricLaplace):
     def _scale_samples(self, eps):  # laplace/baselaplace.py:1646-1655
         return self.posterior_precision.bmm(eps, exponent=-0.5).reshape(eps.shape[0], self.n_params)
 
+    def functional_variance(self, Js):  # laplace/baselaplace.py:1635-1636
+        return self.posterior_precision.inv_square_form(Js)
+
 
 class DiagLaplace(ParametricLaplace):
     _key = ("all", "diag")
@@ -374,6 +440,9 @@ class DiagLaplace(ParametricLaplace):
 
     def _scale_samples(self, eps):  # laplace/baselaplace.py:1912-1919: samples * posterior_scale
         return eps * (1.0 / self.posterior_precision.sqrt()).reshape(1, self.n_params)
+
+    def functional_variance(self, Js):  # laplace/baselaplace.py:1901-1903
+        return torch.einsum("ncp,p,nkp->nck", Js, 1.0 / self.posterior_precision, Js)
 
 
 class FullLLLaplace(ParametricLaplace):

@@ -244,6 +244,11 @@ class KronDecomposed:
             return self._bmm(W, exponent)
         raise ValueError("Invalid shape for W")
 
+    def inv_square_form(self, W: torch.Tensor) -> torch.Tensor:
+        """``W P^-1 W^T`` per batch element for W [batch, K, params] (laplace/utils/matrix.py:448-451)."""
+        SW = self._bmm(W, -1)
+        return torch.bmm(W, SW.transpose(1, 2))
+
     def _bmm(self, W: torch.Tensor, exponent: float) -> torch.Tensor:
         B, K, P = W.size()
         W = W.reshape(B * K, P)

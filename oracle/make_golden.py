@@ -132,6 +132,26 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
     out["kron_samples"] = k_samples.detach().numpy().astype(np.float32)
     la.sample = lambda n_samples=S, generator=None: k_samples.detach()
     out["kron_nn_py"] = la._nn_predictive_classification(eval_idx, n_samples=S).detach().numpy().astype(np.float32)
+    # GLM predictive (the reference's default la(x)): explicit Jacobians, f_var = J P^-1 J^T, link approximations
+    # (laplace/baselaplace.py:570-665, 1123-1158).  glm_eps: fixed standard-normal draws for link_approx="mc".
+    import laplace.utils.utils as _lu
+    glm_eps = torch.from_numpy(np.random.default_rng(seed + 100).standard_normal((int(out["n_outputs"]) if "n_outputs" in out
+                               else model.output_size, 6)).astype(np.float32))
+    out["glm_eps"] = glm_eps.numpy()
+
+    def _glm_all(L_, key):
+        f_mu, f_var = L_._glm_predictive_distribution(eval_idx)
+        out[key + "_glm_fmu"] = f_mu.detach().numpy().astype(np.float32)
+        out[key + "_glm_fvar"] = f_var.detach().numpy().astype(np.float32)
+        for link in ("probit", "bridge", "bridge_norm"):
+            out[f"{key}_glm_{link}"] = L_(eval_idx, pred_type="glm", link_approx=link).detach().numpy().astype(np.float32)
+        real_randn = torch.randn
+        try:  # the reference's normal_samples draws torch.randn((C, n_samples)): hand it the fixed draws
+            _lu.torch.randn = lambda *a, **k: glm_eps.clone()
+            out[key + "_glm_mc"] = L_(eval_idx, pred_type="glm", link_approx="mc", n_samples=6).detach().numpy().astype(np.float32)
+        finally:
+            _lu.torch.randn = real_randn
+    _glm_all(la, "kron")
 
     ld = bl.DiagLaplace(model, "classification")
     ld.fit(loader)
@@ -139,6 +159,7 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
     out["diag_samples"] = d_samples.detach().numpy().astype(np.float32)
     ld.sample = lambda n_samples=S, generator=None: d_samples.detach()
     out["diag_nn_py"] = ld._nn_predictive_classification(eval_idx, n_samples=S).detach().numpy().astype(np.float32)
+    _glm_all(ld, "diag")
     out["diag_marglik_pp1"] = np.float64(float(ld.log_marginal_likelihood()))
     out["diag_marglik_pp07"] = np.float64(float(ld.log_marginal_likelihood(prior_precision=torch.tensor(0.7))))
     out["diag_loss"] = np.float32(float(ld.loss))

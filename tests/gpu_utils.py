@@ -29,6 +29,12 @@ def oracle_from_arrays(kind, n, edge_index, X, Ws, bs, symmetric=False):
     return O.GnnModel(kind, rp, col, X, Ws, bs)
 
 
+def oracle_model_from_golden(g):
+    L = int(g["num_layers"])
+    return oracle_from_arrays(str(g["kind"]), int(g["num_nodes"]), g["edge_index"], g["X"],
+                              [g[f"W{l}"] for l in range(L)], [g[f"b{l}"] for l in range(L)], bool(g["symmetric"]))
+
+
 def kfac_fit_engine(eng, train_idx, train_y, batch_size, fork_exact=True, fuse=True):
     flat, views, loss = eng.new_kfac_buffers()
     n_train = len(train_idx)

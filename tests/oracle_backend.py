@@ -45,6 +45,11 @@ class OracleBackend:
         loss, kfacs = O.kfac_batch(self.model.oracle_model(), x.numpy(), y.numpy(), N)
         return torch.tensor(float(loss)), Kron([[torch.from_numpy(np.ascontiguousarray(h)) for h in F] for F in kfacs])
 
+    def jacobians(self, x, enable_backprop=False):
+        self.calls.append(("jacobians", tuple(x.tolist())))
+        Js, f = O.jacobians_batch(self.model.oracle_model(), x.numpy())
+        return torch.from_numpy(Js), torch.from_numpy(f)
+
     def diag(self, x, y, **kw):
         self.calls.append(("diag", tuple(x.tolist())))
         loss, H = O.diag_batch(self.model.oracle_model(), x.numpy(), y.numpy())

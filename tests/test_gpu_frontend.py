@@ -117,8 +117,47 @@ def test_posterior_samples_and_sampling_predictive(path):
         # mean restored, engine follows it back
         assert torch.equal(model(idx), logits_before)
         la.fit(loader)  # and a refit after predicting still sees the MAP weights
-        py2 = la(idx, n_samples=len(eps), eps=eps)
+        py2 = la(idx, pred_type="nn", link_approx="mc", n_samples=len(eps), eps=eps)
         assert torch.allclose(py, py2, atol=5e-5)  # refit sums with float atomics: last-bit differences
+    model.engine.check_async_errors()
+
+
+@pytest.mark.parametrize("path", CASES, ids=IDS)
+def test_jacobians_and_glm_predictive(path):
+    """"next" row 8(f)-3 on the GPU: lgnn_jacobians against the reference's torch.func Jacobians (goldens of the
+    1-batch small cases) and against the oracle everywhere; the GLM predictive (default la(x): glm + probit, plus
+    bridge, bridge_norm, mc on fixed draws) against the reference's own output."""
+    import gnn_laplace_oracle as O
+    import laplace_gnn_amd as lg
+    from gpu_utils import oracle_model_from_golden
+
+    g = np.load(path)
+    model = model_from_golden(g)
+    idx_all = torch.from_numpy(g["train_idx"]).cuda()
+    Js, f = model.engine.jacobians(idx_all)
+    oJ, of = O.jacobians_batch(oracle_model_from_golden(g), g["train_idx"])
+    assert rel(Js.cpu().numpy(), oJ) < RTOL and rel(f.cpu().numpy(), of) < RTOL
+    if "jac_first_batch" in g.files:
+        assert rel(Js.cpu().numpy(), g["jac_first_batch"]) < RTOL and rel(f.cpu().numpy(), g["f_first_batch"]) < RTOL
+    # a node listed twice gets the same Jacobian twice; an empty request is fine
+    twice = torch.cat([idx_all[:3], idx_all[:3]])
+    J2, _ = model.engine.jacobians(twice)
+    assert torch.equal(J2[:3], J2[3:]) and model.engine.jacobians(idx_all[:0])[0].shape[0] == 0
+
+    loader = lg.TensorBatchLoader(idx_all, torch.from_numpy(g["train_y"]).cuda(), batch_size=int(g["batch_size"]))
+    idx = torch.from_numpy(g["pred_idx"]).cuda()
+    for structure in ("kron", "diag"):
+        la = lg.Laplace(model, "classification", "all", structure)
+        la.fit(loader)
+        f_mu, f_var = la._glm_predictive_distribution(idx)
+        assert rel(f_mu.cpu().numpy(), g[structure + "_glm_fmu"]) < RTOL
+        assert rel(f_var.cpu().numpy(), g[structure + "_glm_fvar"]) < 5e-4
+        assert np.abs(la(idx).cpu().numpy() - g[structure + "_glm_probit"]).max() < 5e-5
+        for link in ("bridge", "bridge_norm"):
+            got = la(idx, pred_type="glm", link_approx=link).cpu().numpy()
+            assert np.abs(got - g[f"{structure}_glm_{link}"]).max() < 2e-4, link
+        mc = la(idx, pred_type="glm", link_approx="mc", n_samples=6, eps=torch.from_numpy(g["glm_eps"]).cuda())
+        assert np.abs(mc.cpu().numpy() - g[structure + "_glm_mc"]).max() < 2e-4
     model.engine.check_async_errors()
 
 

@@ -247,8 +247,19 @@ def test_posterior_samples_and_sampling_predictive_match_reference(name):
         s1 = la.sample(64, generator=gen)
         s2 = la.sample(64, generator=torch.Generator().manual_seed(3))
         assert s1.shape == (64, la.n_params) and torch.equal(s1, s2)
-        with pytest.raises(NotImplementedError):
-            la(idx, pred_type="glm", link_approx="probit")
+        # "next" row 8(f)-3: the GLM predictive (the reference's default la(x)), every link approximation, against
+        # the reference's own output on the same inputs (mc: the same fixed draws)
+        f_mu, f_var = la._glm_predictive_distribution(idx)
+        assert rel(f_mu.numpy(), g[key + "_glm_fmu"]) < 1e-5 and rel(f_var.numpy(), g[key + "_glm_fvar"]) < 2e-4
+        assert np.abs(la(idx).numpy() - g[key + "_glm_probit"]).max() < 2e-5  # defaults: glm + probit
+        for link in ("bridge", "bridge_norm"):
+            assert np.abs(la(idx, pred_type="glm", link_approx=link).numpy() - g[f"{key}_glm_{link}"]).max() < 5e-5
+        mc = la(idx, pred_type="glm", link_approx="mc", n_samples=6, eps=torch.from_numpy(g["glm_eps"]))
+        assert np.abs(mc.numpy() - g[key + "_glm_mc"]).max() < 5e-5
+        with pytest.raises(ValueError):
+            la(idx, pred_type="nn", link_approx="probit")
+        with pytest.raises(ValueError):
+            la(idx, pred_type="gp")
 
 
 def test_kron_decomposed_bmm_matches_dense_power():
