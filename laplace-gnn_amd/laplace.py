@@ -315,6 +315,61 @@ class ParametricLaplace(BaseLaplace):
         return self.log_likelihood - 0.5 * (self.log_det_ratio + self.scatter)
 
 
+    # ---- post-hoc prior precision tuning (laplace/baselaplace.py:342-560) ------------------------------------------
+    def optimize_prior_precision(self, pred_type: str = "glm", method: str = "marglik", n_steps: int = 100,
+                                 lr: float = 1e-1, init_prior_prec=1.0, prior_structure: str = "scalar",
+                                 val_loader=None, loss=None, log_prior_prec_min: float = -4,
+                                 log_prior_prec_max: float = 4, grid_size: int = 100, link_approx: str = "probit",
+                                 n_samples: int = 100, verbose: bool = False, progress_bar: bool = False) -> None:
+        """``method="marglik"``: Adam on the log prior precision against ``-log_marginal_likelihood`` (the fitted
+        factors and their decomposition are constants, only ``logdet(P)``, ``logdet(P_0)`` and the scatter term move:
+        :444-463).  ``method="gridsearch"``: the value of a log-spaced grid with the lowest validation loss of the
+        chosen predictive (:464-560; default loss = mean negative log likelihood of the predictive, the
+        reference's RunningNLLMetric)."""
+        if method == "marglik":
+            pp = init_prior_prec if torch.is_tensor(init_prior_prec) else torch.tensor(float(init_prior_prec))
+            pp = pp.detach().to(self._device, torch.float32).reshape(-1)
+            if pp.numel() == 1 and prior_structure != "scalar":
+                n = {"layerwise": self.n_layers, "diag": self.n_params}.get(prior_structure)
+                if n is None:
+                    raise ValueError(f"Invalid prior structure {prior_structure}.")
+                pp = torch.full((n,), float(pp), device=self._device)
+            log_pp = pp.log().clone().requires_grad_(True)
+            opt = torch.optim.Adam([log_pp], lr=lr)
+            with torch.enable_grad():
+                for _ in range(n_steps):
+                    opt.zero_grad()
+                    neg = -self.log_marginal_likelihood(prior_precision=log_pp.exp())
+                    neg.backward()
+                    opt.step()
+            self.prior_precision = log_pp.detach().exp()
+        elif method == "gridsearch":
+            if val_loader is None:
+                raise ValueError("gridsearch requires a validation set DataLoader")
+            if loss is None:
+                def loss(probs, y):  # mean NLL of the predictive (laplace/utils/metrics.py RunningNLLMetric)
+                    return float(torch.nn.functional.nll_loss(probs.clamp_min(1e-30).log(), y, reduction="mean"))
+            best, best_pp = None, None
+            for pp in torch.logspace(log_prior_prec_min, log_prior_prec_max, grid_size):
+                self.prior_precision = pp
+                try:
+                    outs, ys = [], []
+                    for X, y in val_loader:
+                        outs.append(self(X.to(self._device), pred_type=pred_type, link_approx=link_approx,
+                                         n_samples=n_samples))
+                        ys.append(y.to(self._device))
+                    val = loss(torch.cat(outs), torch.cat(ys))
+                except RuntimeError:
+                    val = float("inf")
+                if best is None or val < best:
+                    best, best_pp = val, pp
+            self.prior_precision = best_pp
+        else:
+            raise ValueError("For now only marglik and gridsearch is implemented.")
+        if verbose:
+            print(f"Optimized prior precision is {self.prior_precision}.")
+
+
 class KronLaplace(ParametricLaplace):
     _key = ("all", "kron")
 

@@ -152,6 +152,20 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
         finally:
             _lu.torch.randn = real_randn
     _glm_all(la, "kron")
+    # post-hoc prior precision tuning on the marginal likelihood (laplace/baselaplace.py:444-463): 25 Adam steps
+    import warnings as _w
+    # (the fork's factors and loss carry the autograd graph of the fit (kfac.py:655-661 create_graph=True), which a
+    #  second backward cannot traverse: the tuning loop only works on detached copies of the fitted state)
+    la.loss = la.loss.detach() if torch.is_tensor(la.loss) else la.loss
+    la.H.eigenvalues = [[l_.detach() for l_ in ls] for ls in la.H.eigenvalues]
+    la.H.eigenvectors = [[q_.detach() for q_ in qs] for qs in la.H.eigenvectors]
+    with _w.catch_warnings():
+        _w.simplefilter("ignore")
+        la.optimize_prior_precision(pred_type="glm", method="marglik", n_steps=25, lr=0.1, prior_structure="scalar")
+        out["kron_opt_pp_scalar"] = la.prior_precision.detach().numpy().astype(np.float32)
+        la.optimize_prior_precision(pred_type="glm", method="marglik", n_steps=25, lr=0.1, prior_structure="layerwise")
+        out["kron_opt_pp_layerwise"] = la.prior_precision.detach().numpy().astype(np.float32)
+    la.prior_precision = 1.0
 
     ld = bl.DiagLaplace(model, "classification")
     ld.fit(loader)

@@ -158,6 +158,11 @@ def test_jacobians_and_glm_predictive(path):
             assert np.abs(got - g[f"{structure}_glm_{link}"]).max() < 2e-4, link
         mc = la(idx, pred_type="glm", link_approx="mc", n_samples=6, eps=torch.from_numpy(g["glm_eps"]).cuda())
         assert np.abs(mc.cpu().numpy() - g[structure + "_glm_mc"]).max() < 2e-4
+        if structure == "kron":  # post-hoc prior tuning on the marginal likelihood (reference's Adam loop, 25 steps)
+            la.optimize_prior_precision(method="marglik", n_steps=25, lr=0.1, prior_structure="scalar")
+            assert rel(la.prior_precision.cpu().numpy(), g["kron_opt_pp_scalar"]) < 2e-3
+            la.optimize_prior_precision(method="marglik", n_steps=25, lr=0.1, prior_structure="layerwise")
+            assert rel(la.prior_precision.cpu().numpy(), g["kron_opt_pp_layerwise"]) < 2e-3
     model.engine.check_async_errors()
 
 
