@@ -123,10 +123,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; LGNN_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 code path on a
+    # 1-GPU box: RCCL refuses two ranks on the same device)
+    backend = os.environ.get("LGNN_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import laplace_gnn_amd as lg
 
