@@ -258,3 +258,107 @@ def test_kfac_kernel_variants_vs_oracle(kind, H, C, L):
         assert rel(A.cpu().numpy(), oH[2 * l][1]) < RTOL, f"A_{l}"
     assert abs(loss - float(oloss)) < RTOL * abs(float(oloss))
     eng.close()
+
+
+def _random_config(seed):
+    r = np.random.default_rng(seed)
+    kind = "gcn" if r.random() < 0.6 else "sage"
+    L = int(r.choice([1, 2, 2, 2, 3]))
+    N = int(r.integers(40, 900))
+    F = int(r.integers(1, 70))
+    H = int(r.choice([4, 8, 20, 32, 33, 64, 100, 128, 160, 256]))
+    C = int(r.choice([1, 2, 3, 7, 10, 16, 17, 40, 47, 64, 65, 70]))
+    E = int(r.integers(0, 6 * N))
+    M = int(r.integers(1, min(N, 300) + 1))
+    bs = int(r.choice([M, max(1, M // 2), max(1, M // 3 + 1)]))
+    dup = r.random() < 0.3          # node ids repeated inside the batch
+    sym = r.random() < 0.7
+    ranges = r.random() < 0.4 and C > 1
+    return kind, L, N, F, H, C, E, M, bs, dup, sym, ranges
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_kfac_random_configurations_vs_oracle(seed):
+    """Randomised shapes through every dispatch of the KFAC path (C = 1 ... 70 incl. the > 64 fallback, widths that are
+    not multiples of 4 / 32, empty edge lists, single-sample batches, repeated node ids, directed graphs, class-range
+    shares): the HIP factors against the oracle's, fp32 <= 1e-4 relative per block."""
+    kind, L, N, F, H, C, E, M, bs, dup, sym, ranges = _random_config(seed)
+    g = torch.Generator().manual_seed(1000 + seed)
+    ei = torch.randint(0, N, (2, E), generator=g) if E > 0 else torch.zeros(2, 0, dtype=torch.int64)
+    X = torch.randn(N, F, generator=g)
+    mult = 2 if kind == "sage" else 1
+    dims = [F] + [H] * (L - 1) + [C]
+    Ws = [torch.randn(dims[l + 1], mult * dims[l], generator=g) / (mult * dims[l]) ** 0.5 for l in range(L)]
+    bs_ = [torch.randn(dims[l + 1], generator=g) * 0.1 for l in range(L)]
+    idx = torch.randperm(N, generator=g)[:M]
+    if dup and M > 2:
+        idx[M // 2:] = idx[: M - M // 2].clone()
+    y = torch.randint(0, C, (M,), generator=g)
+    eng = _engine(kind, N, ei, X, Ws, bs_, symmetric=sym)
+    if ranges:  # the fit as a sum of class-range shares
+        _, views, loss = eng.new_kfac_buffers()
+        cut = max(1, C // 3)
+        for s0 in range(0, M, bs):
+            for r in ((0, cut), (cut, C)):
+                eng.kfac_accumulate(idx[s0:s0 + bs].cuda(), y[s0:s0 + bs].cuda(), M, views, loss, classes=r)
+        torch.cuda.synchronize()
+        loss = float(loss)
+    else:
+        views, loss = kfac_fit_engine(eng, idx.cuda(), y.cuda(), bs)
+    om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs_], sym)
+    oloss, oH = O.fit_kron(om, idx.numpy(), y.numpy(), bs)
+    cfg = (kind, L, N, F, H, C, E, M, bs, dup, sym, ranges)
+
+    def close(a, b):  # relative in the Frobenius norm; C = 1 has exactly zero B factors (softmax of one class)
+        return np.linalg.norm(a - b) <= RTOL * np.linalg.norm(b) + 1e-9
+
+    for l, (A, B) in enumerate(views):
+        assert close(B.cpu().numpy(), oH[2 * l][0]), (f"B_{l}", cfg)
+        assert close(A.cpu().numpy(), oH[2 * l][1]), (f"A_{l}", cfg)
+    assert abs(loss - float(oloss)) <= RTOL * max(abs(float(oloss)), 1e-6), cfg
+    eng.check_async_errors()
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_diag_lastlayer_jacobians_random_configurations_vs_oracle(seed):
+    """The other accumulators and the Jacobians on the same randomised shapes: diagonal GGN (closed form, <= 2
+    layers), last-layer full GGN, per-sample Jacobians."""
+    kind, L, N, F, H, C, E, M, bs, dup, sym, _ = _random_config(seed)
+    M = min(M, 60)
+    g = torch.Generator().manual_seed(2000 + seed)
+    ei = torch.randint(0, N, (2, E), generator=g) if E > 0 else torch.zeros(2, 0, dtype=torch.int64)
+    X = torch.randn(N, F, generator=g)
+    mult = 2 if kind == "sage" else 1
+    dims = [F] + [H] * (L - 1) + [C]
+    Ws = [torch.randn(dims[l + 1], mult * dims[l], generator=g) / (mult * dims[l]) ** 0.5 for l in range(L)]
+    bs_ = [torch.randn(dims[l + 1], generator=g) * 0.1 for l in range(L)]
+    idx = torch.randperm(N, generator=g)[:M]
+    if dup and M > 2:
+        idx[M // 2:] = idx[: M - M // 2].clone()
+    y = torch.randint(0, C, (M,), generator=g)
+    eng = _engine(kind, N, ei, X, Ws, bs_, symmetric=sym)
+    om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs_], sym)
+    cfg = (kind, L, N, F, H, C, E, M, dup, sym)
+
+    def close(a, b):
+        return np.linalg.norm(a - b) <= RTOL * np.linalg.norm(b) + 1e-9
+
+    Js, f = eng.jacobians(idx.cuda())
+    oJ, of = O.jacobians_batch(om, idx.numpy())
+    assert close(Js.cpu().numpy(), oJ) and close(f.cpu().numpy(), of), ("jacobians", cfg)
+    if L <= 2 and kind == "gcn":
+        Hd = torch.zeros(eng.n_params, device="cuda")
+        loss = torch.zeros(1, device="cuda")
+        eng.diag_accumulate(idx.cuda(), y.cuda(), Hd, loss)
+        ol, od = O.diag_batch(om, idx.numpy(), y.numpy())
+        assert close(Hd.cpu().numpy(), od) and abs(float(loss) - float(ol)) <= RTOL * max(abs(float(ol)), 1e-6), ("diag", cfg)
+    p_ll = eng.in_dims[-1] * C + C
+    if p_ll <= 6000:
+        Hl = torch.zeros(p_ll, p_ll, device="cuda")
+        loss = torch.zeros(1, device="cuda")
+        eng.lastlayer_full_accumulate(idx.cuda(), y.cuda(), Hl, loss)
+        ol, oh = O.lastlayer_full_batch(om, idx.numpy(), y.numpy())
+        assert close(Hl.cpu().numpy(), oh), ("last layer", cfg)
+    eng.check_async_errors()
+    eng.close()
