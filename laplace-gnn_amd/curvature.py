@@ -108,14 +108,32 @@ class HipCurvatureInterface:
     # ---- full (last layer) ---------------------------------------------------------------------
     def full(self, x: torch.Tensor, y: torch.Tensor, **kwargs: Any):
         if not self.last_layer:
-            raise NotImplementedError("full GGN over all weights needs backpack in the reference and is out of "
-                                      "scope; use last_layer=True (SURVEY.md 8(a-6))")
+            return self._full_from_jacobians(x, y)
         eng = self.engine
         p_ll = eng.in_dims[-1] * eng.dims[-1] + eng.dims[-1]
         H = torch.zeros(p_ll, p_ll, dtype=torch.float32, device=eng.device)
         loss = torch.zeros(1, dtype=torch.float32, device=eng.device)
         eng.lastlayer_full_accumulate(x, y, H, loss)
         return self.factor * loss[0], H
+
+    def _full_from_jacobians(self, x: torch.Tensor, y: torch.Tensor, chunk: int = 0):
+        """Full GGN over all weights, ``H = sum_n J_n^T Lambda_n J_n`` with ``Lambda_n = diag(p_n) - p_n p_n^T``:
+        GGNInterface.full (laplace/curvature/curvature.py:374-410; the reference's default backend routes this case
+        through un-vendored backpack, the einsum form is the same matrix).  The Jacobians come from the HIP engine
+        (csrc/jacobian.hip) in chunks of samples; the P x P contraction is one library GEMM per chunk."""
+        eng = self.engine
+        C, P = eng.dims[-1], eng.n_params
+        H = torch.zeros(P, P, dtype=torch.float32, device=eng.device)
+        loss = torch.zeros((), dtype=torch.float32, device=eng.device)
+        if chunk <= 0:  # keep a chunk's Jacobians around 1 GiB
+            chunk = max(1, min(len(x), (1 << 28) // max(C * P, 1)))
+        for s in range(0, len(x), chunk):
+            Js, f = eng.jacobians(x[s:s + chunk])
+            p = torch.softmax(f, dim=-1)
+            K = p.unsqueeze(-1) * Js - p.unsqueeze(-1) * torch.einsum("mc,mcp->mp", p, Js).unsqueeze(1)  # Lambda J
+            H += Js.reshape(-1, P).T @ K.reshape(-1, P)
+            loss = loss + self.lossfunc(f, y[s:s + chunk])
+        return self.factor * loss, self.factor * H
 
     def check_async_errors(self):
         self.engine.check_async_errors()

@@ -532,6 +532,48 @@ class FullLLLaplace(ParametricLaplace):
         return self.posterior_precision.logdet()
 
 
+class FullLaplace(ParametricLaplace):
+    """Full GGN over all weights (laplace/baselaplace.py:1380-1470): dense ``P x P`` precision, Cholesky-based scale,
+    log determinant, functional variance and samples.  For the small models it fits (P^2 floats)."""
+    _key = ("all", "full")
+    _sample_additive = True
+
+    def _init_H(self):
+        self.H = torch.zeros(self.n_params, self.n_params, device=self._device)
+        self._posterior_scale = None
+
+    def _curv_closure(self, X, y, N):
+        return self.backend.full(X, y, N=N)
+
+    def _reduce_tensors(self):
+        return [self.H]
+
+    @property
+    def posterior_precision(self) -> torch.Tensor:
+        return self._H_factor * self.H + torch.diag(self.prior_precision_diag)
+
+    @property
+    def posterior_scale(self) -> torch.Tensor:
+        """``P^-1/2`` as a lower-triangular factor (laplace/utils/utils.py:118-129)."""
+        from torch.distributions.multivariate_normal import _precision_to_scale_tril
+        return _precision_to_scale_tril(self.posterior_precision)
+
+    @property
+    def posterior_covariance(self) -> torch.Tensor:
+        scale = self.posterior_scale
+        return scale @ scale.T
+
+    @property
+    def log_det_posterior_precision(self) -> torch.Tensor:
+        return self.posterior_precision.logdet()
+
+    def functional_variance(self, Js):  # :1488-1489
+        return torch.einsum("ncp,pq,nkq->nck", Js, self.posterior_covariance, Js)
+
+    def _scale_samples(self, eps):  # :1497-1508: samples @ posterior_scale
+        return eps @ self.posterior_scale
+
+
 def _all_subclasses(cls) -> set:
     return set(cls.__subclasses__()).union([s for c in cls.__subclasses__() for s in _all_subclasses(c)])
 

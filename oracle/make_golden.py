@@ -194,6 +194,17 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
         Js, fb = be.jacobians(xb, enable_backprop=False)
         out["jac_first_batch"] = Js.numpy().astype(np.float32)
         out["f_first_batch"] = fb.numpy().astype(np.float32)
+        # FullLaplace over all weights with that backend: marginal likelihood, posterior samples, GLM predictive
+        lf = bl.FullLaplace(model, "classification", backend=ns.curvature.GGNInterface)
+        lf.fit(loader)
+        out["fullla_H"] = lf.H.detach().numpy().astype(np.float32)
+        out["fullla_marglik_pp1"] = np.float32(float(lf.log_marginal_likelihood()))
+        out["fullla_marglik_pp07"] = np.float32(float(lf.log_marginal_likelihood(prior_precision=torch.tensor(0.7))))
+        lf.prior_precision = 1.0
+        out["fullla_samples"] = (lf.mean.reshape(1, -1) + eps @ lf.posterior_scale).detach().numpy().astype(np.float32)
+        f_mu, f_var = lf._glm_predictive_distribution(eval_idx)
+        out["fullla_glm_fvar"] = f_var.detach().numpy().astype(np.float32)
+        out["fullla_glm_probit"] = lf(eval_idx, pred_type="glm", link_approx="probit").detach().numpy().astype(np.float32)
 
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")

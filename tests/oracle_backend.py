@@ -57,7 +57,8 @@ class OracleBackend:
 
     def full(self, x, y, **kw):
         self.calls.append(("full", tuple(x.tolist())))
-        loss, H = O.lastlayer_full_batch(self.model.oracle_model(), x.numpy(), y.numpy())
+        fn = O.lastlayer_full_batch if self.last_layer else O.full_batch
+        loss, H = fn(self.model.oracle_model(), x.numpy(), y.numpy())
         return torch.tensor(float(loss)), torch.from_numpy(H)
 
 

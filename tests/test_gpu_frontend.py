@@ -166,6 +166,34 @@ def test_jacobians_and_glm_predictive(path):
     model.engine.check_async_errors()
 
 
+@pytest.mark.parametrize("name", ["gcn_small_1batch_s0", "sage_small_1batch_s0"])
+def test_full_laplace_all_weights(name):
+    """hessian_structure="full" over all weights on the GPU: the GGN from the HIP Jacobians against the reference's
+    FullLaplace (GGNInterface backend) -- H, marginal likelihood, samples, GLM predictive; a three-batch fit adds up."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = model_from_golden(g)
+    idx_all, y_all = torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda()
+    loader = lg.TensorBatchLoader(idx_all, y_all, batch_size=int(g["batch_size"]))
+    la = lg.Laplace(model, "classification", "all", "full")
+    la.fit(loader)
+    assert rel(la.H.cpu().numpy(), g["fullla_H"]) < RTOL
+    assert abs(float(la.loss) - float(g["full_loss"])) < RTOL * abs(float(g["full_loss"]))
+    for pp, key in ((None, "fullla_marglik_pp1"), (torch.tensor(0.7), "fullla_marglik_pp07")):
+        got = float(la.log_marginal_likelihood(prior_precision=pp))
+        assert abs(got - float(g[key])) <= 3e-4 * abs(float(g[key])), key
+    la.prior_precision = 1.0
+    eps, idx = torch.from_numpy(g["pred_eps"]).cuda(), torch.from_numpy(g["pred_idx"]).cuda()
+    assert rel(la.sample(eps=eps).cpu().numpy(), g["fullla_samples"]) < 1e-3
+    _, f_var = la._glm_predictive_distribution(idx)
+    assert rel(f_var.cpu().numpy(), g["fullla_glm_fvar"]) < 1e-3
+    assert np.abs(la(idx).cpu().numpy() - g["fullla_glm_probit"]).max() < 1e-4
+    la3 = lg.FullLaplace(model, "classification")
+    la3.fit(lg.TensorBatchLoader(idx_all, y_all, batch_size=max(1, len(idx_all) // 3 + 1)))
+    assert rel(la3.H.cpu().numpy(), la.H.cpu().numpy()) < 1e-5
+
+
 def test_batched_symeig_matches_float64_eigh():
     """lgnn_symeig_batched behind Kron.decompose: factors of different sizes go through one padded batched solver
     call; eigenvalues against float64 LAPACK, eigenvectors through gauge-free properties (orthonormal,
@@ -221,8 +249,11 @@ def test_backend_kron_returns_fresh_tensors_and_reference_layout():
     _, k3 = be.kron(x, y, N=7 * len(x))
     assert rel(7 * k3.kfacs[0][1].cpu().numpy(), k2.kfacs[0][1].cpu().numpy()) < 1e-5
     assert rel(k3.kfacs[0][0].cpu().numpy(), k2.kfacs[0][0].cpu().numpy()) < 1e-5
+    loss_f, H_f = be.full(x, y)  # all weights: GGN from the HIP Jacobians (same matrix as GGNInterface.full)
+    assert H_f.shape == (be.engine.n_params,) * 2 and torch.allclose(H_f, H_f.T, atol=1e-5)
+    assert abs(float(loss_f) - float(loss2)) < 1e-5 * abs(float(loss2))
     with pytest.raises(NotImplementedError):
-        be.full(x, y)
+        be.jacobians(x, enable_backprop=True)
 
 
 def test_fit_override_false_accumulates_like_reference():

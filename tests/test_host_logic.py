@@ -309,6 +309,28 @@ def test_optimize_prior_precision_matches_reference(name):
         la.optimize_prior_precision(method="cv")
 
 
+def test_full_laplace_all_weights_matches_reference():
+    """hessian_structure="full" over all weights (laplace/baselaplace.py:1380-1510) against the reference's FullLaplace
+    run with its backend-free GGNInterface: H, marginal likelihood, samples, GLM predictive."""
+    g = np.load(os.path.join(GOLDEN, "gcn_small_1batch_s0.npz"))
+    model = _cpu_model(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"]),
+                                  int(g["batch_size"]))
+    la = lg.Laplace(model, "classification", "all", "full", backend=OracleBackend)
+    assert isinstance(la, lg.FullLaplace)
+    la.fit(loader)
+    assert rel(la.H.numpy(), g["fullla_H"]) < RTOL
+    assert abs(float(la.log_marginal_likelihood()) - float(g["fullla_marglik_pp1"])) < 2e-4 * abs(float(g["fullla_marglik_pp1"]))
+    got = float(la.log_marginal_likelihood(prior_precision=torch.tensor(0.7)))
+    assert abs(got - float(g["fullla_marglik_pp07"])) < 2e-4 * abs(float(g["fullla_marglik_pp07"]))
+    la.prior_precision = 1.0
+    eps, idx = torch.from_numpy(g["pred_eps"]), torch.from_numpy(g["pred_idx"])
+    assert rel(la.sample(eps=eps).numpy(), g["fullla_samples"]) < 5e-4
+    _, f_var = la._glm_predictive_distribution(idx)
+    assert rel(f_var.numpy(), g["fullla_glm_fvar"]) < 5e-4
+    assert np.abs(la(idx).numpy() - g["fullla_glm_probit"]).max() < 5e-5
+
+
 def test_kron_decomposed_bmm_matches_dense_power():
     """laplace tests/test_matrix.py bmm pattern: (Q diag(l + delta)^e Q^T) W against the dense matrix, for
     1-, 2- and 3-dimensional W and exponents -1, -1/2, 1."""
