@@ -26,7 +26,7 @@ for k, v in val.items():
         a = {c: v[c] / cnt[(k, c)] for c in v}
         j = {"kernel": "spmm_gram256_kernel",
              "command": "rocprofv3 --pmc <ctrs> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (one pass per counter group)",
-             "dispatches": max(cnt[(k, c)] for c in v), "planes_per_launch": 20.0}
+             "dispatches": max(cnt[(k, c)] for c in v), "planes_per_launch": float(__import__("os").environ.get("LGNN_PLANES_PER_LAUNCH", "40"))}
         j.update({c + "_avg": a[c] for c in a})
         if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
             j["note"] = ("gfx950: FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md HBM section) -> "
