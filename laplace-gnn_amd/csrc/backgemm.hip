@@ -196,6 +196,175 @@ __global__ __launch_bounds__(BG_THREADS, BG_OCC) void backgemm_kernel(BackGemmAr
   }
 }
 
+// ---- producer / consumer variant for the hot shape (K % 8 == 0, ReLU mask, Nout == 256) ---------------------------
+// In the streaming kernel above every wave loads, multiplies and stores, and hipcc's wait counts serialise a wave's
+// stores with its next loads (vmcnt counts both, in order).  Here the roles are split like in the fused SpMM kernel:
+//   * 4 loader waves fetch a stage of 128 rows (row list -> rows of G, mask words, output offsets) and put it into
+//     one of two LDS buffers; they issue no stores, so their waits only ever concern their own loads;
+//   * 8 compute waves (one per group of 32 output columns, W slice in registers) read the MFMA operands of the stage
+//     from LDS and issue 20 MFMAs + 16 unconditional stores per 32-row tile; they issue no global loads inside the
+//     loop, so nothing ever makes them wait for their stores.
+// One s_barrier per stage, written as "s_waitcnt lgkmcnt(0); s_barrier" (LDS hand-over only): __syncthreads() would
+// add a vmcnt(0) and drain the compute waves' stores.  Each row of G is read once per stage instead of once per column
+// group.  One 768-thread workgroup per CU, persistent.
+constexpr int PC_ROWS = 128, PC_LOADERS = 4, PC_COMPUTE = 8, PC_THREADS = 64 * (PC_LOADERS + PC_COMPUTE);
+
+template <int KH>
+__global__ __launch_bounds__(PC_THREADS) void backgemm_pc_kernel(BackGemmArgs g) {
+  extern __shared__ float pc_smem[];
+  constexpr int H = 4 * KH;
+  constexpr int KP = 2 * H + 4;  // row stride of the staged rows: 16-byte aligned, conflict-free ds_read_b128
+  constexpr int BUF_FLOATS = PC_ROWS * KP + PC_ROWS * META_LD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int64_t na = int64_t(*g.na_dev);
+  const uint32_t spp = uint32_t((na + PC_ROWS - 1) / PC_ROWS);  // stages per plane
+  const int64_t total = int64_t(spp) * g.planes;
+  if (int64_t(blockIdx.x) >= total) return;  // (uniform per workgroup, before any barrier)
+  const int64_t nit = (total - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  const auto stage_of = [&](int64_t j) {  // global stage of this workgroup's j-th; past the end: its last one
+    const int64_t jj = j < nit ? j : nit - 1;
+    return int64_t(blockIdx.x) + jj * gridDim.x;
+  };
+  const int32_t rowb = int32_t(g.Nout) * 4;
+  const auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  if (wave < PC_LOADERS) {
+    // ------------------------------------------------------------ loader waves
+    // (written without lambdas over the staged registers: captured by reference they stay address-taken, and the
+    //  "memory" clobber of the barrier then forces them through scratch memory)
+    const int r = wave * 32 + l31;  // row of the stage
+    const int mw = int(g.mask_words);
+    // named registers, not an array: an array that is live across the barrier's memory clobber is kept in scratch
+    float4 a0, a1, a2, a3, a4, a5, a6, a7;
+    a0 = a1 = a2 = a3 = a4 = a5 = a6 = a7 = make_float4(0.f, 0.f, 0.f, 0.f);
+    u4u m0, m1;
+    int32_t nd, off;
+    bool ok;
+#define PC_EACH(OP) { if constexpr (KH > 0) OP(0, a0) if constexpr (KH > 1) OP(1, a1) if constexpr (KH > 2) OP(2, a2) \
+    if constexpr (KH > 3) OP(3, a3) if constexpr (KH > 4) OP(4, a4) if constexpr (KH > 5) OP(5, a5) \
+    if constexpr (KH > 6) OP(6, a6) if constexpr (KH > 7) OP(7, a7) }
+#define PC_LD(Q, R) R = *reinterpret_cast<const float4*>(src_ + 4 * Q);
+#define PC_ST(Q, R) *reinterpret_cast<float4*>(A_ + r * KP + lhi * H + 4 * Q) = R;
+#define PC_ISSUE_ID(J)                                                            \
+  {                                                                               \
+    const uint32_t st_ = uint32_t(stage_of(J));                                   \
+    const uint32_t plane_ = st_ / spp;                                            \
+    const int64_t t_ = int64_t(st_ - plane_ * spp) * PC_ROWS + r;                 \
+    ok = t_ < na;                                                                 \
+    nd = g.rows[ok ? t_ : na - 1];                                                \
+  }
+#define PC_ISSUE_ROWS(J) /* uses nd / ok of stage J */                            \
+  {                                                                               \
+    const uint32_t plane_ = uint32_t(stage_of(J)) / spp;                          \
+    const float* __restrict__ src_ = g.G + (int64_t(plane_) * g.N + nd) * g.K + lhi * H; \
+    PC_EACH(PC_LD)                                                                \
+    const uint32_t* __restrict__ mp_ = g.mask_bits + int64_t(nd) * mw;            \
+    m0 = *reinterpret_cast<const u4u*>(mp_);                                      \
+    m1 = *reinterpret_cast<const u4u*>(mp_ + 4);                                  \
+    off = (ok ? nd : int32_t(g.N)) * rowb;                                        \
+  }
+#define PC_PARK(BUF)                                                              \
+  {                                                                               \
+    float* __restrict__ A_ = pc_smem + (BUF) * BUF_FLOATS;                        \
+    int32_t* __restrict__ meta_ = reinterpret_cast<int32_t*>(A_ + PC_ROWS * KP);  \
+    PC_EACH(PC_ST)                                                                \
+    if (lhi == 0) {                                                               \
+      meta_[r * META_LD] = off;                                                   \
+      *reinterpret_cast<uint4*>(meta_ + r * META_LD + 4) = make_uint4(m0.x, m0.y, m0.z, m0.w); \
+      *reinterpret_cast<uint4*>(meta_ + r * META_LD + 8) = make_uint4(m1.x, m1.y, m1.z, m1.w); \
+    }                                                                             \
+  }
+    PC_ISSUE_ID(0)
+    PC_ISSUE_ROWS(0)
+    PC_ISSUE_ID(1)
+    PC_PARK(0)        // stage 0 -> buffer 0
+    PC_ISSUE_ROWS(1)  // rows of stage 1 in flight, id of stage 2 next
+    PC_ISSUE_ID(2)
+    barrier();
+    for (int64_t i = 0; i < nit; ++i) {
+      // stage i + 1 -> the buffer the compute waves are not reading; then its registers take stage i + 2
+      PC_PARK(int((i + 1) & 1))
+      PC_ISSUE_ROWS(i + 2)
+      PC_ISSUE_ID(i + 3)
+      barrier();
+    }
+#undef PC_ISSUE_ID
+#undef PC_ISSUE_ROWS
+#undef PC_PARK
+#undef PC_EACH
+#undef PC_LD
+#undef PC_ST
+  } else {
+    // ------------------------------------------------------------ compute waves
+    const int ch = wave - PC_LOADERS;  // column group
+    const int col = ch * 32 + l31;
+    float bw[H];
+#pragma unroll
+    for (int kk = 0; kk < H; ++kk) bw[kk] = g.W[int64_t(lhi * H + kk) * g.ldw + col];
+    const int sh = 31 - l31;
+    barrier();
+    for (int64_t i = 0; i < nit; ++i) {
+      const uint32_t plane = uint32_t(stage_of(i)) / spp;
+      char* __restrict__ Up = reinterpret_cast<char*>(g.U + int64_t(plane) * g.u_plane_stride + col);
+      const float* __restrict__ A = pc_smem + int(i & 1) * BUF_FLOATS;
+      const int32_t* __restrict__ meta = reinterpret_cast<const int32_t*>(A + PC_ROWS * KP);
+#pragma unroll
+      for (int rt = 0; rt < PC_ROWS / 32; ++rt) {
+        float av[H];
+        const float* __restrict__ arow = A + (rt * 32 + l31) * KP + lhi * H;
+#pragma unroll
+        for (int q = 0; q < KH; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(arow + 4 * q);
+          av[4 * q + 0] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < H; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bw[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int rq = 0; rq < 2; ++rq) {
+          int32_t offs[8];
+          uint32_t wd[8];
+#pragma unroll
+          for (int ri = 0; ri < 8; ++ri) {
+            const int e = rq * 8 + ri;
+            const int lr = rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+            offs[ri] = meta[lr * META_LD];
+            wd[ri] = uint32_t(meta[lr * META_LD + 4 + ch]);
+          }
+#pragma unroll
+          for (int ri = 0; ri < 8; ++ri) {
+            const float v = int32_t(wd[ri] << sh) < 0 ? acc[rq * 8 + ri] : 0.f;
+            *reinterpret_cast<float*>(Up + uint32_t(offs[ri])) = v;
+          }
+        }
+      }
+      barrier();
+    }
+  }
+}
+
+template <int KH>
+int backgemm_pc_launch(const BackGemmArgs& g, hipStream_t s) {
+  constexpr int H = 4 * KH, KP = 2 * H + 4;
+  const size_t smem = size_t(2) * (PC_ROWS * KP + PC_ROWS * META_LD) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    LGNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&backgemm_pc_kernel<KH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    attr_set = true;
+  }
+  const int64_t worst = cdiv(g.N, PC_ROWS) * g.planes;
+  const unsigned grid = unsigned(std::max<int64_t>(1, std::min<int64_t>(worst, 256)));
+  hipLaunchKernelGGL(backgemm_pc_kernel<KH>, dim3(grid), dim3(PC_THREADS), smem, s, g);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 template <int KH>
 int backgemm_launch(const BackGemmArgs& g, hipStream_t s) {
   const size_t smem = size_t(2 * BG_WAVES * BGM * META_LD) * 4;
@@ -251,6 +420,20 @@ int launch_backgemm(const BackGemmArgs& g_in, hipStream_t s) {
   LGNN_REQUIRE(g.rows && g.na_dev, "backgemm needs the compacted row list");
   LGNN_REQUIRE(g.u_plane_stride >= (g.N + 1) * g.Nout, "backgemm: planes of U need a spare row");
   const int kh = int(cdiv(cdiv(g.K, 2), 4));  // 16-byte pieces per half row
+  if (g.mask_bits && g.mask_words == 8 && g.Nout == 256 && g.K == 8 * kh && (reinterpret_cast<uintptr_t>(g.G) & 15) == 0 &&
+      g.ldw >= 256 && getenv("LGNN_BACKGEMM_STREAM") == nullptr) {
+    LGNN_REQUIRE(cdiv(g.N, PC_ROWS) * g.planes < (int64_t(1) << 31), "backgemm: too many stages for 32-bit indices");
+    switch (kh) {
+      case 1: return backgemm_pc_launch<1>(g, s);
+      case 2: return backgemm_pc_launch<2>(g, s);
+      case 3: return backgemm_pc_launch<3>(g, s);
+      case 4: return backgemm_pc_launch<4>(g, s);
+      case 5: return backgemm_pc_launch<5>(g, s);
+      case 6: return backgemm_pc_launch<6>(g, s);
+      case 7: return backgemm_pc_launch<7>(g, s);
+      default: return backgemm_pc_launch<8>(g, s);
+    }
+  }
   switch (kh) {
     case 1: return backgemm_launch<1>(g, s);
     case 2: return backgemm_launch<2>(g, s);
