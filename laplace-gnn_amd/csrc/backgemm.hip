@@ -308,7 +308,8 @@ __global__ __launch_bounds__(PC_THREADS) void backgemm_pc_kernel(BackGemmArgs g)
     barrier();
     for (int64_t i = 0; i < nit; ++i) {
       const uint32_t plane = uint32_t(stage_of(i)) / spp;
-      char* __restrict__ Up = reinterpret_cast<char*>(g.U + int64_t(plane) * g.u_plane_stride + col);
+      // wave-uniform plane base + 32-bit lane offset: the stores take the scalar-base form (no 64-bit vector adds)
+      char* __restrict__ Up = reinterpret_cast<char*>(g.U + int64_t(plane) * g.u_plane_stride);
       const float* __restrict__ A = pc_smem + int(i & 1) * BUF_FLOATS;
       const int32_t* __restrict__ meta = reinterpret_cast<const int32_t*>(A + PC_ROWS * KP);
 #pragma unroll
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(PC_THREADS) void backgemm_pc_kernel(BackGemmArgs g)
 #pragma unroll
           for (int ri = 0; ri < 8; ++ri) {
             const float v = int32_t(wd[ri] << sh) < 0 ? acc[rq * 8 + ri] : 0.f;
-            *reinterpret_cast<float*>(Up + uint32_t(offs[ri])) = v;
+            *reinterpret_cast<float*>(Up + uint32_t(offs[ri] + col * 4)) = v;
           }
         }
       }
