@@ -195,12 +195,12 @@ def main():
             # (counters cannot be collected inside the timed run); the committed summary is quoted when
             # it matches this workload, otherwise null.
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_g_pmc_fused.json")
+            pmc = os.path.join(ROOT, "profiles", "r01_h_pmc_fused.json")
             if args.workload == "arxiv" and structure == "kron" and os.path.exists(pmc):
                 with open(pmc) as fh:
                     pj = json.load(fh)
                 traffic = pj["traffic_bytes_per_launch"] * (planes / launches) / pj["planes_per_launch"]
-                traffic_src = "profiles/r01_g_pmc_fused.json ((2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction)"
+                traffic_src = "profiles/r01_h_pmc_fused.json ((2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction)"
             roofline = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
