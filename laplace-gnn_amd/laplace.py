@@ -315,6 +315,31 @@ class ParametricLaplace(BaseLaplace):
         return self.log_likelihood - 0.5 * (self.log_det_ratio + self.scatter)
 
 
+    # ---- serialisation (laplace/baselaplace.py:1314-1368): plain dict of tensors and scalars, torch.save-able -----
+    def state_dict(self) -> dict:
+        if getattr(self, "H", None) is None:
+            raise AttributeError("Laplace not fit. Run fit() first.")
+        return {"mean": self.mean, "H": self.H, "loss": self.loss, "prior_mean": self.prior_mean,
+                "prior_precision": self.prior_precision, "sigma_noise": self.sigma_noise, "n_data": self.n_data,
+                "n_outputs": self.n_outputs, "likelihood": self.likelihood, "temperature": self.temperature,
+                "enable_backprop": self.enable_backprop, "cls_name": self.__class__.__name__}
+
+    def load_state_dict(self, state_dict: dict) -> None:
+        if self.__class__.__name__ != state_dict["cls_name"]:
+            raise ValueError("Loading a wrong Laplace type. Make sure `subset_of_weights` and `hessian_structure` "
+                             "are correct!")
+        if self.n_params is not None and len(state_dict["mean"]) != self.n_params:
+            raise ValueError("Attempting to load Laplace with different number of parameters than the model.")
+        if self.likelihood != state_dict["likelihood"]:
+            raise ValueError("Different likelihoods detected!")
+        import warnings
+        if self.temperature != state_dict["temperature"]:
+            warnings.warn("Different `temperature` parameters detected. Some calculation might be off!")
+        for k in ("mean", "H", "loss", "prior_mean", "prior_precision", "sigma_noise", "n_data", "n_outputs",
+                  "likelihood", "temperature", "enable_backprop"):
+            setattr(self, k, state_dict[k])
+        setattr(self.model, "output_size", self.n_outputs)
+
     # ---- post-hoc prior precision tuning (laplace/baselaplace.py:342-560) ------------------------------------------
     def optimize_prior_precision(self, pred_type: str = "glm", method: str = "marglik", n_steps: int = 100,
                                  lr: float = 1e-1, init_prior_prec=1.0, prior_structure: str = "scalar",
@@ -381,6 +406,18 @@ class KronLaplace(ParametricLaplace):
     def _init_H(self):
         self.H = Kron.init_from_model(self.params, self._device)
         self._flat = None
+
+    def state_dict(self) -> dict:  # laplace/baselaplace.py:1664-1677: the factors, not their decomposition
+        sd = super().state_dict()
+        sd["H"] = self.H_facs.kfacs
+        return sd
+
+    def load_state_dict(self, state_dict: dict) -> None:
+        super().load_state_dict(state_dict)
+        self._init_H()
+        self.H_facs = self.H
+        self.H_facs.kfacs = state_dict["H"]
+        self.H = self.H_facs.decompose(damping=self.damping)
 
     def _curv_closure(self, X, y, N, classes=None):
         be = self.backend

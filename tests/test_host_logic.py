@@ -331,6 +331,31 @@ def test_full_laplace_all_weights_matches_reference():
     assert np.abs(la(idx).numpy() - g["fullla_glm_probit"]).max() < 5e-5
 
 
+def test_state_dict_round_trip(tmp_path):
+    """laplace/baselaplace.py:1314-1368, 1664-1677: a fitted Laplace saved with torch.save and loaded into a fresh
+    object (safe loader) predicts and scores identically; wrong class / size / likelihood are refused."""
+    g = np.load(os.path.join(GOLDEN, "gcn_small_3batch_s1.npz"))
+    model = _cpu_model(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"]),
+                                  int(g["batch_size"]))
+    idx = torch.from_numpy(g["pred_idx"])
+    for structure in ("kron", "diag", "full"):
+        la = lg.Laplace(model, "classification", "all", structure, backend=OracleBackend, prior_precision=0.8)
+        la.fit(loader)
+        path = tmp_path / f"{structure}.pt"
+        torch.save(la.state_dict(), path)
+        lb = lg.Laplace(model, "classification", "all", structure, backend=OracleBackend)
+        lb.load_state_dict(torch.load(path, weights_only=True))
+        assert float(lb.prior_precision) == pytest.approx(0.8) and lb.n_data == la.n_data
+        assert abs(float(lb.log_marginal_likelihood()) - float(la.log_marginal_likelihood())) < 1e-4
+        assert torch.allclose(lb(idx), la(idx), atol=1e-6)
+        other = lg.Laplace(model, "classification", "all", "diag" if structure != "diag" else "kron", backend=OracleBackend)
+        with pytest.raises(ValueError):
+            other.load_state_dict(la.state_dict())
+    with pytest.raises(AttributeError):
+        lg.Laplace(model, "classification", "all", "diag", backend=OracleBackend).state_dict()
+
+
 def test_kron_decomposed_bmm_matches_dense_power():
     """laplace tests/test_matrix.py bmm pattern: (Q diag(l + delta)^e Q^T) W against the dense matrix, for
     1-, 2- and 3-dimensional W and exponents -1, -1/2, 1."""
