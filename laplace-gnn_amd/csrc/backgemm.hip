@@ -421,8 +421,12 @@ int launch_backgemm(const BackGemmArgs& g_in, hipStream_t s) {
   LGNN_REQUIRE(g.rows && g.na_dev, "backgemm needs the compacted row list");
   LGNN_REQUIRE(g.u_plane_stride >= (g.N + 1) * g.Nout, "backgemm: planes of U need a spare row");
   const int kh = int(cdiv(cdiv(g.K, 2), 4));  // 16-byte pieces per half row
-  if (g.mask_bits && g.mask_words == 8 && g.Nout == 256 && g.K == 8 * kh && (reinterpret_cast<uintptr_t>(g.G) & 15) == 0 &&
-      g.ldw >= 256 && getenv("LGNN_BACKGEMM_STREAM") == nullptr) {
+  bool hot = g.mask_bits && g.mask_words == 8 && g.Nout == 256 && g.K == 8 * kh &&
+             (reinterpret_cast<uintptr_t>(g.G) & 15) == 0 && g.ldw >= 256;
+#ifdef LGNN_DEV  // make DEV=1: LGNN_BACKGEMM_STREAM=1 forces the streaming kernel for A/B timing
+  if (getenv("LGNN_BACKGEMM_STREAM")) hot = false;
+#endif
+  if (hot) {
     LGNN_REQUIRE(cdiv(g.N, PC_ROWS) * g.planes < (int64_t(1) << 31), "backgemm: too many stages for 32-bit indices");
     switch (kh) {
       case 1: return backgemm_pc_launch<1>(g, s);

@@ -230,6 +230,7 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
   LGNN_REQUIRE(M > 0 && idx && y && diag_out && loss_out, "empty batch or null pointers");
   LGNN_REQUIRE(h->L >= 1 && h->L <= 2,
                "diag: closed form implemented for 1- and 2-layer models (the reference cannot build deeper ones)");
+  LGNN_REQUIRE(h->lik == LGNN_LIK_CLASSIFICATION, "diag kernels: classification likelihood (regression goes through the Jacobians)");
   LGNN_CALL(forward_ensure_aux(h, s));
   const int L = h->L;
   const int64_t C = h->dims[L];
@@ -274,6 +275,7 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
 int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out,
                               float* loss_out, hipStream_t s) {
   LGNN_REQUIRE(M > 0 && idx && y && H_out && loss_out, "empty batch or null pointers");
+  LGNN_REQUIRE(h->lik == LGNN_LIK_CLASSIFICATION, "last-layer full GGN kernels: classification likelihood");
   LGNN_CALL(forward_ensure_aux(h, s));
   const int L = h->L;
   const int64_t C = h->dims[L];

@@ -50,7 +50,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // written as seeds[first][c][k] (+=: duplicated node ids accumulate like x[x_indices]' backward).
 // loss += logsumexp(f) - f[y]   (CrossEntropyLoss(reduction='sum'))
 __global__ __launch_bounds__(256) void seed_kernel(const float* __restrict__ logits, int64_t C,
-                                                   const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
+                                                   const int64_t* __restrict__ idx, const void* __restrict__ y_,
                                                    int64_t M, int64_t N, const int32_t* __restrict__ pos, int fork_exact,
                                                    float* __restrict__ seeds, float* __restrict__ probs,
                                                    float* __restrict__ loss, int* __restrict__ bad,
@@ -91,8 +91,18 @@ __global__ __launch_bounds__(256) void seed_kernel(const float* __restrict__ log
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane == 0 && loss) {
-      const int64_t yy = y[m];
+    if (fork_exact == 2) {
+      // regression: sum_k (f_k - y_k)^2 with float targets [M, C] (MSELoss(reduction='sum'); the factor 0.5 of the
+      // interface is applied by the caller)
+      if (loss) {
+        const float* __restrict__ yr = static_cast<const float*>(y_) + m * C;
+        float sq = 0.f;
+        for (int64_t k = lane; k < C; k += 64) { const float dlt = f_s[k] - yr[k]; sq += dlt * dlt; }
+        sq = wave_sum(sq);
+        if (lane == 0) loss_acc += sq;
+      }
+    } else if (lane == 0 && loss) {
+      const int64_t yy = static_cast<const int64_t*>(y_)[m];
       if (yy < 0 || yy >= C) *bad = 2;
       else loss_acc += logf(se) + mx - f_s[yy];
     }
@@ -106,7 +116,8 @@ __global__ __launch_bounds__(256) void seed_kernel(const float* __restrict__ log
         const float pc = p_s[c], pk = p_s[k];
         const float d = (k == c) ? 1.f : 0.f;
         float v;
-        if (fork_exact) v = sqrtf(pc) * (d - pk * (1.f + f_s[k] - mb) + 0.5f * (d - pk) * (f_s[c] - mb));
+        if (fork_exact == 2) v = d * 1.41421356237309515f;  // regression: Hessian square root sqrt(2) I (kfac_utils.py:116-120)
+        else if (fork_exact) v = sqrtf(pc) * (d - pk * (1.f + f_s[k] - mb) + 0.5f * (d - pk) * (f_s[c] - mb));
         else v = sqrtf(pc) * (d - pk);
         atomicAdd(&dst[q], v);
       }
@@ -297,15 +308,16 @@ __global__ __launch_bounds__(1024) void seed_spmm_gram_kernel(
           const int64_t mm = __shfl(mp, b);
           const int64_t u = __shfl(cu, b);
           float pk = 0.f, fk = 0.f;
-          if (lane < C) { pk = probs[mm * C + lane]; fk = logits[u * C + lane]; }
+          if (lane < C && fork_exact != 2) { pk = probs[mm * C + lane]; fk = logits[u * C + lane]; }
           // a node listed t times in the batch counts t times (the dense reference's x[x_indices] backward)
           const float vv = __shfl(v, b) * float(mult[mm]);
           const float mb = wave_sum(pk * fk);  // same summation order as seed_kernel
           const float sp = sqrtf(pk), t = fk - mb;
-          const float alpha = fork_exact ? sp * (1.f + 0.5f * t) : sp;
-          const float nbeta = -sp, ngamma = fork_exact ? -0.5f * sp * t : 0.f;
-          int uvi = __float_as_int(vv * (fork_exact ? pk * (1.f + t) : pk));
-          int pvi = __float_as_int(fork_exact ? vv * pk : 0.f);
+          // fork_exact: 0 upstream, 1 fork-exact classification seeds; 2 regression: V = sqrt(2) I (only the diagonal term)
+          const float alpha = fork_exact == 2 ? 1.41421356237309515f : (fork_exact ? sp * (1.f + 0.5f * t) : sp);
+          const float nbeta = -sp, ngamma = fork_exact == 1 ? -0.5f * sp * t : 0.f;
+          int uvi = __float_as_int(vv * (fork_exact == 1 ? pk * (1.f + t) : pk));
+          int pvi = __float_as_int(fork_exact == 1 ? vv * pk : 0.f);
           // Both are read with v_readlane (which ignores EXEC) inside the rowok region below, from lanes that are not
           // part of it: pin their computation here, for all lanes, so that it is not sunk into that region.
           asm volatile("" : "+v"(uvi), "+v"(pvi));
@@ -448,7 +460,8 @@ int seed_spmm_gram_launch(lgnn_ctx* h, bool fork_exact, float* g, int64_t cb, in
 #endif
   hipLaunchKernelGGL(seed_spmm_gram_kernel<NBLK>, dim3(unsigned(256 * per_cu)), dim3(64 * waves), smem, s, h->PT.rowptr,
                      h->PT.col, h->PT.val, h->N, C, h->ws.pos.as<int32_t>(), h->ws.probs.as<float>(),
-                     h->fc.out.as<float>(), h->ws.mult.as<int32_t>(), fork_exact ? 1 : 0, g,
+                     h->fc.out.as<float>(), h->ws.mult.as<int32_t>(),
+                     h->lik == LGNN_LIK_REGRESSION ? 2 : (fork_exact ? 1 : 0), g,
                      h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(), int(cb), int(ce), scratch, ldb, debug);
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
@@ -496,8 +509,8 @@ int record_event(lgnn_ctx* h, hipStream_t s) {
 // shared by kfac / diag / last layer: mark the batch, compute seeds/probs/loss.
 int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bool want_seeds, bool fork_exact,
                    float* loss_out, hipStream_t s) {
-  LGNN_REQUIRE(h->lik == LGNN_LIK_CLASSIFICATION, "only the classification likelihood is implemented on the GPU path");
   const int64_t N = h->N, C = h->dims[h->L];
+  const int seed_mode = h->lik == LGNN_LIK_REGRESSION ? 2 : (fork_exact ? 1 : 0);
   LGNN_REQUIRE(2 * C * 4 <= 64 * 1024, "too many classes for the seed kernel");
   int* bad = h->ws.flags.as<int>();  // allocated and zeroed by lgnn_create; sticky until lgnn_check_async_errors
   hipLaunchKernelGGL(mark_batch_kernel, dim3(unsigned(cdiv(M, 256))), dim3(256), 0, s, idx, M, N,
@@ -514,7 +527,7 @@ int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bo
   LGNN_REQUIRE(8 * C * 4 <= 60 * 1024, "too many classes for the seed kernel");
   hipLaunchKernelGGL(seed_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M, 4), 2048))), dim3(256), size_t(8 * C) * 4, s,
                      h->fc.out.as<float>(), C, idx,
-                     static_cast<const int64_t*>(y), M, N, h->ws.pos.as<int32_t>(), fork_exact ? 1 : 0, seeds,
+                     y, M, N, h->ws.pos.as<int32_t>(), seed_mode, seeds,
                      h->ws.probs.as<float>(), loss_out, bad, h->ws.mult.as<int32_t>());
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;

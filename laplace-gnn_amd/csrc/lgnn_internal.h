@@ -179,7 +179,6 @@ struct BackGemmArgs {
   const int32_t* na_dev;    // device count of `rows`
   const uint32_t* mask_bits; int64_t mask_words;  // ReLU mask bits of h (or null)
   const float* hact; int64_t hact_ld; int act;    // float activations otherwise
-  int debug;
 };
 bool backgemm_supported(int64_t K, int64_t Nout, bool with_mask);
 int launch_backgemm(const BackGemmArgs& g, hipStream_t s);

@@ -36,8 +36,6 @@ class HipCurvatureInterface:
             raise NotImplementedError("subnetwork Laplace is out of scope for the HIP backend")
         if stochastic:
             raise NotImplementedError("MC Fisher (stochastic=True) is not implemented on the HIP backend")
-        if likelihood != "classification":
-            raise NotImplementedError("the HIP backend implements the classification likelihood")
         self.likelihood = likelihood
         self.model = model
         self.last_layer = last_layer
@@ -59,6 +57,8 @@ class HipCurvatureInterface:
         if not hasattr(model, "engine"):
             raise TypeError("HipGGN needs a model that exposes a HIP `engine` (laplace_gnn_amd.models.GCN / "
                             "GraphSAGE); there is no generic autograd fallback")
+        if likelihood == "regression" and last_layer:
+            raise NotImplementedError("last-layer full GGN: classification likelihood only")
 
     @property
     def _model(self) -> nn.Module:
@@ -77,6 +77,7 @@ class HipCurvatureInterface:
                          classes: tuple[int, int] | None = None):
         """Add this batch's RAW factors (A_l/N_train, B_l) and loss into caller-owned buffers; ``classes``
         restricts the call to a range of class columns (exact additive share, see the C ABI)."""
+        self.engine.set_likelihood(self.likelihood)  # regression: sqrt(2) I seeds and the MSE loss on the device
         self.engine.kfac_accumulate(x, y, N, views, loss_buf, fork_exact=self.fork_exact_seed, fuse=fuse,
                                     classes=classes)
 
@@ -99,6 +100,9 @@ class HipCurvatureInterface:
 
     # ---- diag ----------------------------------------------------------------------------------
     def diag(self, x: torch.Tensor, y: torch.Tensor, **kwargs: Any):
+        if self.likelihood == "regression":
+            return self._regression_from_jacobians(x, y, full=False)
+        self.engine.set_likelihood("classification")
         eng = self.engine
         H = torch.zeros(eng.n_params, dtype=torch.float32, device=eng.device)
         loss = torch.zeros(1, dtype=torch.float32, device=eng.device)
@@ -116,11 +120,28 @@ class HipCurvatureInterface:
         eng.lastlayer_full_accumulate(x, y, H, loss)
         return self.factor * loss[0], H
 
+    def _regression_from_jacobians(self, x: torch.Tensor, y: torch.Tensor, full: bool, chunk: int = 0):
+        """Regression GGN (H_lik = None, laplace/curvature/curvature.py:406-407, 429-430): ``H = sum J^T J`` resp.
+        its diagonal -- no factor on H -- and ``loss = 0.5 * MSE_sum``; Jacobians from the HIP engine."""
+        eng = self.engine
+        C, P = eng.dims[-1], eng.n_params
+        H = torch.zeros((P, P) if full else (P,), dtype=torch.float32, device=eng.device)
+        loss = torch.zeros((), dtype=torch.float32, device=eng.device)
+        if chunk <= 0:
+            chunk = max(1, min(len(x), (1 << 28) // max(C * P, 1)))
+        for s in range(0, len(x), chunk):
+            Js, f = eng.jacobians(x[s:s + chunk])
+            H += Js.reshape(-1, P).T @ Js.reshape(-1, P) if full else (Js * Js).sum(dim=(0, 1))
+            loss = loss + self.lossfunc(f, y[s:s + chunk].to(f.dtype).reshape(f.shape))
+        return self.factor * loss, H
+
     def _full_from_jacobians(self, x: torch.Tensor, y: torch.Tensor, chunk: int = 0):
         """Full GGN over all weights, ``H = sum_n J_n^T Lambda_n J_n`` with ``Lambda_n = diag(p_n) - p_n p_n^T``:
         GGNInterface.full (laplace/curvature/curvature.py:374-410; the reference's default backend routes this case
         through un-vendored backpack, the einsum form is the same matrix).  The Jacobians come from the HIP engine
         (csrc/jacobian.hip) in chunks of samples; the P x P contraction is one library GEMM per chunk."""
+        if self.likelihood == "regression":
+            return self._regression_from_jacobians(x, y, full=True, chunk=chunk)
         eng = self.engine
         C, P = eng.dims[-1], eng.n_params
         H = torch.zeros(P, P, dtype=torch.float32, device=eng.device)

@@ -131,6 +131,29 @@ class GraphEngine:
         self.in_dims = [mult * d for d in dims[:-1]]
         self._versions = self._param_versions()
 
+    def set_likelihood(self, likelihood: str):
+        """Switch the bound model between the classification and the regression likelihood (re-binds the same tensors)."""
+        if self._bound is None:
+            raise _lib.HipLibraryError("no model bound")
+        if self._bind_opts[1] != likelihood:
+            X, ws, bs = self._bound
+            self.bind(X, ws, bs, self._bind_opts[0], likelihood)
+
+    @property
+    def likelihood(self) -> str:
+        return self._bind_opts[1]
+
+    def _labels(self, y: torch.Tensor, M: int):
+        """int64 class ids [M] (classification) or fp32 targets [M, C] (regression) as a device pointer."""
+        if self.likelihood == "regression":
+            if y.numel() != M * self.dims[-1]:
+                raise ValueError(f"regression targets must have shape [{M}, {self.dims[-1]}]")
+            y = y.to(torch.float32).contiguous()
+            self._keep = y
+            return _dev_ptr(y, torch.float32, "y")
+        y = y.contiguous()
+        return _dev_ptr(y, torch.int64, "y")
+
     def _param_versions(self):
         _, ws, bs = self._bound
         return [(t.data_ptr(), t._version) for t in (*ws, *bs)]
@@ -202,13 +225,14 @@ class GraphEngine:
         that range of class columns (an exact additive share of the batch; the share with class 0 also adds
         the loss and the A increment)."""
         self._sync_versions()
-        idx, y = idx.contiguous(), y.contiguous()
+        idx = idx.contiguous()
+        yp = self._labels(y, idx.shape[0])
         flags = (_lib.FLAG_FORK_EXACT_SEED if fork_exact else 0) | (0 if fuse else _lib.FLAG_NO_FUSE)
         A = _lib.ptr_array([a.data_ptr() for a, _ in views])
         B = _lib.ptr_array([b.data_ptr() for _, b in views])
         cb, ce = (0, self.dims[-1]) if classes is None else (int(classes[0]), int(classes[1]))
         rc = self.lib.lgnn_kfac_accumulate_classes(
-            self._h, _dev_ptr(idx, torch.int64, "idx"), _dev_ptr(y, torch.int64, "y"), idx.shape[0], int(n_train),
+            self._h, _dev_ptr(idx, torch.int64, "idx"), yp, idx.shape[0], int(n_train),
             flags, cb, ce, A, B, loss.data_ptr(), _stream(self.device))
         _lib.check(rc, "lgnn_kfac_accumulate_classes")
 

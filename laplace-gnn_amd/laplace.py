@@ -209,8 +209,6 @@ class ParametricLaplace(BaseLaplace):
         ``f ~ N(f_mu, J P^-1 J^T)`` from explicit Jacobians (:1123-1158, :570-665).  ``pred_type="nn"`` with
         ``link_approx="mc"``: parameter samples, one forward each (:1183-1199).  ``eps`` replaces the random draws
         (standard normal, [n_samples, n_params] for "nn", [n_outputs, n_samples] for "glm"/"mc")."""
-        if self.likelihood != "classification":
-            raise NotImplementedError("classification only")
         if pred_type not in ("glm", "nn"):
             raise ValueError("Only glm and nn supported as prediction types.")
         if link_approx not in ("mc", "probit", "bridge", "bridge_norm"):
@@ -218,18 +216,26 @@ class ParametricLaplace(BaseLaplace):
         if pred_type == "nn" and link_approx != "mc":
             raise ValueError("Only mc link approximation is supported for nn prediction type.")
         x = x.to(self._device)
+        regression = self.likelihood == "regression"
         if pred_type == "glm":
+            if regression:  # (f_mu [M, C], f_var [M, C, C]) of the linearised model (:620-624)
+                f_mu, f_var = self._glm_predictive_distribution(x)
+                return f_mu, (torch.diagonal(f_var, dim1=-2, dim2=-1) if diagonal_output else f_var)
             return self._glm_forward_call(x, link_approx, n_samples, diagonal_output, generator, eps)
         from torch.nn.utils import vector_to_parameters
-        py = 0.0
+        outs = []
         samples = self.sample(n_samples, generator=generator, eps=eps)
         try:
             for theta in samples:
                 vector_to_parameters(theta, self.params)
-                py = py + torch.softmax(self.model(x), dim=-1) / len(samples)
+                f = self.model(x)
+                outs.append(f if regression else torch.softmax(f, dim=-1))
         finally:
             vector_to_parameters(self.mean.clone(), self.params)  # the parameters must not alias self.mean afterwards
-        return py
+        outs = torch.stack(outs)
+        if regression:  # mean and variance over the parameter samples (:1060-1066)
+            return outs.mean(dim=0), outs.var(dim=0)
+        return outs.mean(dim=0)
 
     # ---- GLM predictive ("next" row 8(f)-3) ---------------------------------------------------------------------
     def functional_variance(self, Js: torch.Tensor) -> torch.Tensor:

@@ -180,6 +180,27 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
     out["diag_H"] = ld.H.detach().numpy().astype(np.float32)
     out["n_data"], out["n_outputs"], out["n_params"] = ld.n_data, ld.n_outputs, ld.n_params
 
+    if with_full:
+        # regression likelihood on the same model (MSELoss, Hessian sqrt = sqrt(2) I, factor 0.5): float targets
+        reg_y = torch.randn(n_train, c, generator=g)
+        out["reg_y"] = reg_y.numpy()
+        rloader = DataLoader(TensorDataset(train_idx, reg_y), batch_size=batch_size, shuffle=False)
+        lr_ = bl.KronLaplace(model, "regression", sigma_noise=0.7)
+        lr_.fit(rloader)
+        out["reg_kron_loss"] = np.float32(float(lr_.loss))
+        for i, Fs in enumerate(lr_.H_facs.kfacs):
+            for j, Hm in enumerate(Fs):
+                out[f"reg_kron_{i}_{j}"] = Hm.detach().numpy().astype(np.float32)
+        out["reg_kron_marglik"] = np.float32(float(lr_.log_marginal_likelihood()))
+        f_mu_r, f_var_r = lr_(eval_idx, pred_type="glm")
+        out["reg_kron_glm_fmu"] = f_mu_r.detach().numpy().astype(np.float32)
+        out["reg_kron_glm_fvar"] = f_var_r.detach().numpy().astype(np.float32)
+        ldr = bl.DiagLaplace(model, "regression", sigma_noise=0.7)
+        ldr.fit(rloader)
+        out["reg_diag_H"] = ldr.H.detach().numpy().astype(np.float32)
+        out["reg_diag_loss"] = np.float32(float(ldr.loss))
+        out["reg_diag_marglik"] = np.float32(float(ldr.log_marginal_likelihood()))
+
     if with_full:  # backend-free pin for "full" (SURVEY.md 8(c)): GGNInterface.full einsum
         be = ns.curvature.GGNInterface(model, "classification")
         loss, H = 0.0, 0.0

@@ -32,9 +32,11 @@ class CpuForwardGCN(torch.nn.Module):
 class OracleBackend:
     def __init__(self, model, likelihood, last_layer=False, subnetwork_indices=None, dict_key_x="input_ids",
                  dict_key_y="labels", stochastic=False):
-        assert likelihood == "classification"
         self.model, self.likelihood, self.last_layer = model, likelihood, last_layer
         self.lossfunc, self.factor = CrossEntropyLoss(reduction="sum"), 1.0
+        if likelihood == "regression":
+            from torch.nn import MSELoss
+            self.lossfunc, self.factor = MSELoss(reduction="sum"), 0.5
         self.params = [p for k, p in model.named_parameters() if p.requires_grad and "adj" not in k]
         self.params_dict = dict(model.named_parameters())
         self.buffers_dict = dict(model.named_buffers())
@@ -42,7 +44,7 @@ class OracleBackend:
 
     def kron(self, x, y, N, **kw):
         self.calls.append(("kron", tuple(x.tolist())))
-        loss, kfacs = O.kfac_batch(self.model.oracle_model(), x.numpy(), y.numpy(), N)
+        loss, kfacs = O.kfac_batch(self.model.oracle_model(), x.numpy(), y.numpy(), N, likelihood=self.likelihood)
         return torch.tensor(float(loss)), Kron([[torch.from_numpy(np.ascontiguousarray(h)) for h in F] for F in kfacs])
 
     def jacobians(self, x, enable_backprop=False):
@@ -52,7 +54,7 @@ class OracleBackend:
 
     def diag(self, x, y, **kw):
         self.calls.append(("diag", tuple(x.tolist())))
-        loss, H = O.diag_batch(self.model.oracle_model(), x.numpy(), y.numpy())
+        loss, H = O.diag_batch(self.model.oracle_model(), x.numpy(), y.numpy(), self.likelihood)
         return torch.tensor(float(loss)), torch.from_numpy(H)
 
     def full(self, x, y, **kw):

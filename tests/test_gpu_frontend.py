@@ -194,6 +194,53 @@ def test_full_laplace_all_weights(name):
     assert rel(la3.H.cpu().numpy(), la.H.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["gcn_small_1batch_s0", "sage_small_1batch_s0"])
+def test_regression_likelihood(name):
+    """likelihood="regression" on the GPU: KFAC with sqrt(2) I seeds and the MSE loss on the device (fused and unfused,
+    whole batch and three batches), diagonal / full GGN through the HIP Jacobians, marginal likelihood with sigma_noise
+    and the GLM predictive -- against the reference's regression goldens."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = model_from_golden(g)
+    idx_all, y_all = torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["reg_y"]).cuda()
+    loader = lg.TensorBatchLoader(idx_all, y_all, batch_size=int(g["batch_size"]))
+    la = lg.Laplace(model, "regression", "all", "kron", sigma_noise=0.7)
+    la.fit(loader)
+    for i, Fs in enumerate(la.H_facs.kfacs):
+        for j, Hm in enumerate(Fs):
+            assert rel(Hm.cpu().numpy(), g[f"reg_kron_{i}_{j}"]) < RTOL, (i, j)
+    assert abs(float(la.loss) - float(g["reg_kron_loss"])) < RTOL * float(g["reg_kron_loss"])
+    assert abs(float(la.log_marginal_likelihood()) - float(g["reg_kron_marglik"])) < 3e-4 * abs(float(g["reg_kron_marglik"]))
+    f_mu, f_var = la(torch.from_numpy(g["pred_idx"]).cuda(), pred_type="glm")
+    assert rel(f_mu.cpu().numpy(), g["reg_kron_glm_fmu"]) < RTOL and rel(f_var.cpu().numpy(), g["reg_kron_glm_fvar"]) < 5e-4
+    # unfused kernels and a three-batch fit give the same factors
+    be = lg.HipGGN(model, "regression")
+    _, views, loss = be.engine.new_kfac_buffers()
+    third = max(1, len(idx_all) // 3 + 1)
+    for s0 in range(0, len(idx_all), third):
+        be.kron_accumulate_(views, loss, idx_all[s0:s0 + third], y_all[s0:s0 + third], len(idx_all), fuse=False)
+    k3 = be.pack_kron(views)
+    la3 = lg.KronLaplace(model, "regression")
+    la3.fit(lg.TensorBatchLoader(idx_all, y_all, batch_size=third))
+    for Fa, Fb in zip(k3.kfacs, la3.H_facs.kfacs):
+        for a, b in zip(Fa, Fb):
+            assert rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    ld = lg.Laplace(model, "regression", "all", "diag", sigma_noise=0.7)
+    ld.fit(loader)
+    assert rel(ld.H.cpu().numpy(), g["reg_diag_H"]) < RTOL
+    assert abs(float(ld.loss) - float(g["reg_diag_loss"])) < RTOL * float(g["reg_diag_loss"])
+    assert abs(float(ld.log_marginal_likelihood()) - float(g["reg_diag_marglik"])) < 3e-4 * abs(float(g["reg_diag_marglik"]))
+    lf = lg.Laplace(model, "regression", "all", "full")
+    lf.fit(loader)
+    assert rel(torch.diagonal(lf.H).cpu().numpy(), g["reg_diag_H"]) < RTOL  # diag(J^T J) == sum J^2
+    # classification afterwards still works on the same engine (the likelihood is re-bound)
+    lc = lg.Laplace(model, "classification", "all", "kron")
+    lc.fit(lg.TensorBatchLoader(idx_all, torch.from_numpy(g["train_y"]).cuda(), batch_size=int(g["batch_size"])))
+    assert rel(lc.H_facs.kfacs[0][0].cpu().numpy(), g["kron_0_0"]) < RTOL
+    model.engine.check_async_errors()
+
+
 def test_batched_symeig_matches_float64_eigh():
     """lgnn_symeig_batched behind Kron.decompose: factors of different sizes go through one padded batched solver
     call; eigenvalues against float64 LAPACK, eigenvectors through gauge-free properties (orthonormal,

@@ -356,6 +356,32 @@ def test_state_dict_round_trip(tmp_path):
         lg.Laplace(model, "classification", "all", "diag", backend=OracleBackend).state_dict()
 
 
+@pytest.mark.parametrize("name", ["gcn_small_1batch_s0", "sage_small_1batch_s0"])
+def test_regression_likelihood_matches_reference(name):
+    """likelihood="regression" (MSE, Hessian square root sqrt(2) I, interface factor 0.5): KFAC factors, diagonal
+    GGN, marginal likelihood with sigma_noise and the GLM predictive against the reference's KronLaplace /
+    DiagLaplace run on float targets."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = _cpu_model(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["reg_y"]), int(g["batch_size"]))
+    la = lg.Laplace(model, "regression", "all", "kron", backend=OracleBackend, sigma_noise=0.7)
+    la.fit(loader)
+    for i, Fs in enumerate(la.H_facs.kfacs):
+        for j, Hm in enumerate(Fs):
+            assert rel(Hm.numpy(), g[f"reg_kron_{i}_{j}"]) < RTOL
+    assert abs(float(la.loss) - float(g["reg_kron_loss"])) < RTOL * float(g["reg_kron_loss"])
+    assert abs(float(la.log_marginal_likelihood()) - float(g["reg_kron_marglik"])) < 2e-4 * abs(float(g["reg_kron_marglik"]))
+    f_mu, f_var = la(torch.from_numpy(g["pred_idx"]), pred_type="glm")
+    assert rel(f_mu.numpy(), g["reg_kron_glm_fmu"]) < 1e-5 and rel(f_var.numpy(), g["reg_kron_glm_fvar"]) < 3e-4
+    m_nn, v_nn = la(torch.from_numpy(g["pred_idx"]), pred_type="nn", link_approx="mc", n_samples=8,
+                    generator=torch.Generator().manual_seed(0))
+    assert m_nn.shape == f_mu.shape and v_nn.shape == f_mu.shape and (v_nn >= 0).all()
+    ld = lg.Laplace(model, "regression", "all", "diag", backend=OracleBackend, sigma_noise=0.7)
+    ld.fit(loader)
+    assert rel(ld.H.numpy(), g["reg_diag_H"]) < RTOL
+    assert abs(float(ld.log_marginal_likelihood()) - float(g["reg_diag_marglik"])) < 2e-4 * abs(float(g["reg_diag_marglik"]))
+
+
 def test_kron_decomposed_bmm_matches_dense_power():
     """laplace tests/test_matrix.py bmm pattern: (Q diag(l + delta)^e Q^T) W against the dense matrix, for
     1-, 2- and 3-dimensional W and exponents -1, -1/2, 1."""
