@@ -241,6 +241,37 @@ def test_regression_likelihood(name):
     model.engine.check_async_errors()
 
 
+def test_config1_regression_mlp_on_the_gpu():
+    """BASELINE configs[0] (examples/regression_example.py: 1-50-1 tanh MLP, 150 points, regression) through the HIP
+    path: an MLP is a GCN on a graph without edges (self loops only, propagation = identity).  diag and kron fits against
+    the golden the reference's CPU curvlinops backend produced."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, "c1_regression_mlp.npz"))
+    X, y = torch.from_numpy(g["X"]), torch.from_numpy(g["y"])
+    n = X.shape[0]
+    model = lg.GCN(1, 50, 1, 2, X, torch.zeros(2, 0, dtype=torch.int64), act="tanh")
+    with torch.no_grad():
+        for l, conv in enumerate(model.convs):
+            conv.lin.weight.copy_(torch.from_numpy(g[f"W{l}"]))
+            conv.lin.bias.copy_(torch.from_numpy(g[f"b{l}"]))
+    model = model.eval().cuda()
+    loader = lg.TensorBatchLoader(torch.arange(n).cuda(), y.cuda(), batch_size=n)
+    ld = lg.Laplace(model, "regression", "all", "diag")
+    ld.fit(loader)
+    assert rel(ld.H.cpu().numpy(), g["diag_H"]) < RTOL
+    assert abs(float(ld.loss) - float(g["diag_loss"])) < RTOL * float(g["diag_loss"])
+    lk = lg.Laplace(model, "regression", "all", "kron")
+    lk.fit(loader)
+    assert abs(float(lk.loss) - float(g["kron_loss"])) < RTOL * float(g["kron_loss"])
+    assert len(lk.H_facs.kfacs) == int(g["kron_n_blocks"])
+    for i, Fs in enumerate(lk.H_facs.kfacs):
+        for j, Hm in enumerate(Fs):
+            assert rel(Hm.cpu().numpy(), g[f"kron_{i}_{j}"]) < RTOL, (i, j)
+    f_mu, f_var = lk(torch.arange(5).cuda())  # regression predictive: mean and variance of the linearised model
+    assert f_mu.shape == (5, 1) and f_var.shape == (5, 1, 1) and (f_var > 0).all()
+
+
 def test_batched_symeig_matches_float64_eigh():
     """lgnn_symeig_batched behind Kron.decompose: factors of different sizes go through one padded batched solver
     call; eigenvalues against float64 LAPACK, eigenvectors through gauge-free properties (orthonormal,
