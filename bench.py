@@ -40,6 +40,8 @@ WORKLOADS = {
     "cora": dict(N=2_708, E=5_278, F=1_433, H=64, C=7, n_train=1_299, batch=10_000),
     # same graph and widths as "arxiv" with the other model family of the path (GraphSAGE, mean aggregation)
     "arxiv_sage": dict(N=169_343, E=1_166_243, F=128, H=256, C=40, n_train=90_941, batch=10_000, kind="sage"),
+    # the same sizes with power-law degrees (hubs of ~1e4 neighbours like the real ogbn-arxiv citation graph)
+    "arxiv_powerlaw": dict(N=169_343, E=1_166_243, F=128, H=256, C=40, n_train=90_941, batch=10_000, powerlaw=0.5),
     # BASELINE configs[4]: 3-layer GraphSAGE, last-layer full GGN (P_LL = 47 * 513 = 24 111), power-law degrees
     "products": dict(N=2_449_029, E=61_859_140, F=100, H=256, C=47, n_train=196_615, batch=10_000, layers=3,
                      kind="sage", powerlaw=0.5),
@@ -142,7 +144,7 @@ def main():
     cls = lg.GraphSAGE if w.get("kind") == "sage" else lg.GCN
     model = cls(w["F"], w["H"], w["C"], w.get("layers", 2), X, ei, symmetric=True).to(dev)
     loader = lg.TensorBatchLoader(train_idx.to(dev), train_y.to(dev), batch_size=w["batch"])
-    structure = args.structure or {"arxiv": "kron", "arxiv_sage": "kron", "cora": "diag",
+    structure = args.structure or {"arxiv": "kron", "arxiv_sage": "kron", "arxiv_powerlaw": "kron", "cora": "diag",
                                    "products": "lastlayer"}[args.workload]
     if structure == "lastlayer":
         la = lg.Laplace(model, "classification", subset_of_weights="last_layer", hessian_structure="full")

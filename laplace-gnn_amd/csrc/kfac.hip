@@ -551,7 +551,10 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   const bool first = cb == 0;
   LGNN_REQUIRE(n_train > 0, "n_train must be positive");
   LGNN_REQUIRE(A_out && B_out && loss_out, "null output pointers");
-  LGNN_CALL(forward_ensure_grams(h, s));
+  // the input Grams feed the A increment, which only the share with class 0 adds (ranks of a multi-GPU job that
+  // hold no such share never compute them)
+  if (first) LGNN_CALL(forward_ensure_grams(h, s));
+  else LGNN_CALL(forward_ensure(h, s));
   const int64_t N = h->N;
   const int L = h->L;
   const int64_t C = h->dims[L];
