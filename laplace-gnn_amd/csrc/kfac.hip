@@ -708,7 +708,9 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           const bool fuse_here = !no_fuse && fused_supported(d, d, N * d, ping);
           if (top_level && fuse_here) ep.row_active = row_active;  // inactive rows are never read below
           int64_t ping_stride = N * d;
-          if (top_level && fuse_here && row_active && backgemm_supported(dout, d, h->act == LGNN_ACT_RELU)) {
+          // (32-bit row offsets inside a plane: beyond 2 GiB per plane the generic GEMM takes over)
+          if (top_level && fuse_here && row_active && backgemm_supported(dout, d, h->act == LGNN_ACT_RELU) &&
+              (N + 1) * d * 4 < (int64_t(1) << 31)) {
             ping_stride = (N + 1) * d;  // row N of every plane takes the stores of rows past the end of the list
             BackGemmArgs bg{};
             bg.u_plane_stride = ping_stride;
