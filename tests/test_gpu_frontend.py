@@ -272,6 +272,23 @@ def test_config1_regression_mlp_on_the_gpu():
     assert f_mu.shape == (5, 1) and f_var.shape == (5, 1, 1) and (f_var > 0).all()
 
 
+def test_two_ranks_share_one_gpu():
+    """The N > 1 path with the real HIP backend: two ranks (gloo, CUDA tensors, one device) shard a kron fit into
+    (batch, class) units and a diag fit into sample slices, all-reduce one flat buffer and must reproduce the
+    reference goldens on every rank (tests/dist_gpu_worker.py)."""
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(os.path.dirname(__file__), "dist_gpu_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "DIST_GPU_OK world=2" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
 def test_batched_symeig_matches_float64_eigh():
     """lgnn_symeig_batched behind Kron.decompose: factors of different sizes go through one padded batched solver
     call; eigenvalues against float64 LAPACK, eigenvectors through gauge-free properties (orthonormal,
