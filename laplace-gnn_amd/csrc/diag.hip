@@ -201,7 +201,7 @@ __global__ void ll_place_block_kernel(const float* __restrict__ S, int64_t D, in
     const float v = S[lo * D1 + hi];
     const int64_t ra = a < D ? c * D + a : C * D + c;
     const int64_t rb = b < D ? c * D + b : C * D + c;
-    Hout[ra * P + rb] += v;
+    if (ra <= rb) Hout[ra * P + rb] += v;  // upper triangle only: the lower one is mirrored once per call
   }
 }
 
@@ -286,16 +286,13 @@ int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, in
   const int64_t D = Phi.width, D1 = D + 1, P = C * D + C;
   const int64_t ldz = cdiv(P, 4) * 4, ldy = cdiv(D1, 4) * 4;
 
-  // - Z^T Z
+  // - Z^T Z, accumulated straight into the upper triangle of H (one writer per element: no scratch matrix, no atomics)
   LGNN_CALL(h->ws.planes_a.reserve(std::max(size_t(M) * ldz, size_t(C) * M * ldy) * 4));  // Z, then Y
-  LGNN_CALL(h->ws.planes_b.reserve(size_t(P) * P * 4));
+  h->ws.planes_a_zero_ptr = nullptr;
   float* Z = h->ws.planes_a.as<float>();
-  float* scratch = h->ws.planes_b.as<float>();
   hipLaunchKernelGGL(ll_build_z_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M * ldz, 256), 8192))), dim3(256), 0, s,
                      probs, idx, M, C, Phi, ldz, Z);
-  LGNN_HIP_CHECK(hipMemsetAsync(scratch, 0, size_t(P) * P * 4, s));
-  LGNN_CALL(launch_gram(Z, ldz, M, P, scratch, s));
-  LGNN_CALL(launch_sym_accumulate(scratch, P, -1.0f, H_out, s));
+  LGNN_CALL(launch_gram_scaled(Z, ldz, M, P, H_out, -1.0f, s));
 
   // + blockdiag_c sum_n p_nc phi~ phi~^T
   float* Y = h->ws.planes_a.as<float>();
@@ -310,6 +307,8 @@ int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, in
                        0, s, s2, D, C, c, H_out);
   }
   LGNN_HIP_CHECK(hipGetLastError());
+  // everything above touched the upper triangle (and the diagonal 32 x 32 blocks); mirror it
+  LGNN_CALL(launch_symmetrize_upper(H_out, P, s));
   LGNN_CALL(batch_epilogue(h, idx, M, s));
   return 0;
 }

@@ -487,7 +487,7 @@ __device__ __forceinline__ void gram_mfma_block(const float* __restrict__ ta, co
 template <int NSLOT>
 __device__ __forceinline__ void gram_flush(float* __restrict__ scratch, int64_t D, int64_t i0, int64_t j0,
                                            const int (&si)[NSLOT], const int (&sj)[NSLOT], int nmine, int lane,
-                                           const f32x16 (&acc)[NSLOT]) {
+                                           const f32x16 (&acc)[NSLOT], float scale = 1.f, bool direct = false) {
   const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
@@ -496,7 +496,12 @@ __device__ __forceinline__ void gram_flush(float* __restrict__ scratch, int64_t 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t i = i0 + si[s] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (i < D && j < D) atomicAdd(&scratch[i * D + j], acc[s][r]);
+        if (i < D && j < D) {
+          // direct: this workgroup is the only writer of the element (rows not split): plain read-modify-write
+          // instead of a device-scope atomic -- 2.9e8 of them per products-shaped last-layer batch
+          if (direct) scratch[i * D + j] += scale * acc[s][r];
+          else atomicAdd(&scratch[i * D + j], scale * acc[s][r]);
+        }
       }
     }
   }
@@ -504,7 +509,8 @@ __device__ __forceinline__ void gram_flush(float* __restrict__ scratch, int64_t 
 
 template <int DT, int VEC>
 __global__ __launch_bounds__(256) void gram_mem_kernel(const float* __restrict__ X, int64_t ld, int64_t R, int64_t D,
-                                                       float* __restrict__ scratch, int64_t rows_per_wg, int ntile) {
+                                                       float* __restrict__ scratch, int64_t rows_per_wg, int ntile,
+                                                       float scale, int direct) {
   using Cfg = GramCfg<DT>;
   constexpr int NSLOT = Cfg::NSLOT;
   constexpr int PANELS = Cfg::HAS_OFF ? 2 : 1;
@@ -591,11 +597,13 @@ __global__ __launch_bounds__(256) void gram_mem_kernel(const float* __restrict__
       gram_mfma_block<NSLOT>(ta, tb, DT, si, sj, nmine, lane, acc);
       __syncthreads();
     }
-    gram_flush<NSLOT>(scratch, D, cA, cB, si, sj, nmine, lane, acc);
+    gram_flush<NSLOT>(scratch, D, cA, cB, si, sj, nmine, lane, acc, scale, direct != 0);
   }
 }
 
-int launch_gram(const float* X, int64_t ld, int64_t R, int64_t D, float* scratch, hipStream_t s) {
+// out[i, j] += scale * (X^T X)[i, j] for the upper 32x32 sub-tiles (i-tile <= j-tile; diagonal sub-tiles whole).
+// When the rows are not split over workgroups every element has one writer and is updated without atomics.
+int launch_gram_scaled(const float* X, int64_t ld, int64_t R, int64_t D, float* out, float scale, hipStream_t s) {
   if (R <= 0 || D <= 0) return 0;
   const bool vec = (ld % 4 == 0) && aligned16(X);
   int dt = D <= 64 ? 64 : (D <= 128 ? 128 : (D <= 256 ? 256 : 128));
@@ -606,14 +614,43 @@ int launch_gram(const float* X, int64_t ld, int64_t R, int64_t D, float* scratch
   int64_t rows_per_wg = std::max<int64_t>(KT, cdiv(cdiv(R, want_wg), KT) * KT);
   const int64_t ksplit = cdiv(R, rows_per_wg);
   LGNN_REQUIRE(ksplit < 65536, "gram split too large");
+  const int direct = ksplit == 1 ? 1 : 0;
   const dim3 grid{unsigned(npairs), unsigned(ksplit), 1u};
 #define LGNN_GRAM_LAUNCH(DTV)                                                                                   \
-  if (vec) hipLaunchKernelGGL((gram_mem_kernel<DTV, 4>), grid, dim3(256), 0, s, X, ld, R, D, scratch, rows_per_wg, ntile); \
-  else hipLaunchKernelGGL((gram_mem_kernel<DTV, 1>), grid, dim3(256), 0, s, X, ld, R, D, scratch, rows_per_wg, ntile);
+  if (vec) hipLaunchKernelGGL((gram_mem_kernel<DTV, 4>), grid, dim3(256), 0, s, X, ld, R, D, out, rows_per_wg, ntile, scale, direct); \
+  else hipLaunchKernelGGL((gram_mem_kernel<DTV, 1>), grid, dim3(256), 0, s, X, ld, R, D, out, rows_per_wg, ntile, scale, direct);
   if (dt == 64) { LGNN_GRAM_LAUNCH(64) }
   else if (dt == 128) { LGNN_GRAM_LAUNCH(128) }
   else { LGNN_GRAM_LAUNCH(256) }
 #undef LGNN_GRAM_LAUNCH
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_gram(const float* X, int64_t ld, int64_t R, int64_t D, float* scratch, hipStream_t s) {
+  return launch_gram_scaled(X, ld, R, D, scratch, 1.0f, s);
+}
+
+// lower triangle <- upper triangle of a D x D matrix, 32 x 32 tiles through LDS (coalesced on both sides)
+__global__ __launch_bounds__(256) void symmetrize_upper_kernel(float* __restrict__ H, int64_t D) {
+  __shared__ float t[32][33];
+  const int64_t bi = blockIdx.y, bj = blockIdx.x;  // tile row / column, bi <= bj handled
+  if (bi > bj) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = bi * 32 + r, j = bj * 32 + tx;
+    t[r][tx] = (i < D && j < D) ? H[i * D + j] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = bj * 32 + r, j = bi * 32 + tx;  // element (i, j) of the lower part = (j, i) of the upper
+    if (i < D && j < D && i > j) H[i * D + j] = t[tx][r];
+  }
+}
+int launch_symmetrize_upper(float* H, int64_t D, hipStream_t s) {
+  if (D <= 1) return 0;
+  const unsigned nt = unsigned(cdiv(D, 32));
+  hipLaunchKernelGGL(symmetrize_upper_kernel, dim3(nt, nt), dim3(256), 0, s, H, D);
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }

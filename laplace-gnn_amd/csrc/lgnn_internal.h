@@ -212,6 +212,10 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float*
 
 // scratch[D, D] (upper sub-tiles) += X[0:R, col0:col0+D)^T X[...]; X row-major with ld
 int launch_gram(const float* X, int64_t ld, int64_t R, int64_t D, float* scratch, hipStream_t s);
+// out[i,j] += scale * (X^T X)[i,j] on the upper sub-tiles, without atomics when the rows are not split
+int launch_gram_scaled(const float* X, int64_t ld, int64_t R, int64_t D, float* out, float scale, hipStream_t s);
+// lower triangle <- upper triangle
+int launch_symmetrize_upper(float* H, int64_t D, hipStream_t s);
 // out[i,j] += scale * scratch[min(i,j), max(i,j)]
 int launch_sym_accumulate(const float* scratch, int64_t D, float scale, float* out, hipStream_t s);
 // fused: rows r=(plane, n): y = sum_j val*in_plane[col[j]]; scratch += y^T y; optional store of y

@@ -120,6 +120,14 @@ class HipCurvatureInterface:
         eng.lastlayer_full_accumulate(x, y, H, loss)
         return self.factor * loss[0], H
 
+    def full_accumulate_(self, H: torch.Tensor, loss_buf: torch.Tensor, x: torch.Tensor, y: torch.Tensor):
+        """Last-layer full GGN of one batch added IN PLACE to the caller's ``H`` (and the raw loss to ``loss_buf``): no
+        ``P x P`` temporary per batch -- 2.3 GB each at the products shape."""
+        if not self.last_layer or self.likelihood != "classification" or self.factor != 1.0:
+            raise NotImplementedError("in-place accumulation exists for the last-layer classification GGN")
+        self.engine.set_likelihood("classification")
+        self.engine.lastlayer_full_accumulate(x, y, H, loss_buf)
+
     def _regression_from_jacobians(self, x: torch.Tensor, y: torch.Tensor, full: bool, chunk: int = 0):
         """Regression GGN (H_lik = None, laplace/curvature/curvature.py:406-407, 429-430): ``H = sum J^T J`` resp.
         its diagonal -- no factor on H -- and ``loss = 0.5 * MSE_sum``; Jacobians from the HIP engine."""

@@ -559,12 +559,32 @@ class FullLLLaplace(ParametricLaplace):
 
     def _init_H(self):
         self.H = torch.zeros(self.n_params, self.n_params, device=self._device)
+        self._loss_buf = None
 
     def _curv_closure(self, X, y, N):
-        return self.backend.full(X, y, N=N)
+        be = self.backend
+        if hasattr(be, "full_accumulate_"):  # in-place fast path of the HIP backend: H is 2.3 GB at the products shape
+            if self._loss_buf is None:
+                self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self._device)
+            be.full_accumulate_(self.H, self._loss_buf, X, y)
+            return 0.0, None
+        return be.full(X, y, N=N)
+
+    def _accumulate(self, H_batch):
+        if H_batch is not None:
+            self.H += H_batch
+
+    def fit(self, train_loader, override: bool = True, progress_bar: bool = False, process_group=None) -> None:
+        super().fit(train_loader, override=override, progress_bar=progress_bar, process_group=process_group)
+        if self._loss_buf is not None:  # (all-reduced together with H, see _reduce_tensors)
+            self.loss = self.loss + self._loss_buf[0].clone()
+            self._loss_buf = None
 
     def _reduce_tensors(self):
-        return [self.H]
+        be = self.backend
+        if hasattr(be, "full_accumulate_") and self._loss_buf is None:  # a rank without local samples still reduces
+            self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self._device)
+        return [self.H] + ([self._loss_buf] if self._loss_buf is not None else [])
 
     @property
     def posterior_precision(self) -> torch.Tensor:
