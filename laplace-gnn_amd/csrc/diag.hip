@@ -159,49 +159,65 @@ __global__ void diag_last_layer_kernel(const float* __restrict__ probs, const in
   else atomicAdd(&diag_b[k], acc);
 }
 
-// ---- last-layer full GGN helpers ---------------------------------------------------------------
-// Z[m, c*D + d] = p[m,c] phi[m,d];  Z[m, C*D + c] = p[m,c] s_m        (row stride ldz, zero padded)
-__global__ void ll_build_z_kernel(const float* __restrict__ probs, const int64_t* __restrict__ idx, int64_t M,
-                                  int64_t C, FeatView Phi, int64_t ldz, float* __restrict__ Z) {
-  const int64_t D = Phi.width;
-  const int64_t total = M * ldz;
+// ---- last-layer full GGN as weighted Grams over class pairs -----------------------------------------------------
+// H = sum_n Lambda_n (x) phi~_n phi~_n^T: block (c, c') of H is the weighted Gram Phi~^T diag(Lambda[:, c, c']) Phi~ -- symmetric
+// in (c, c') AND inside the block.  Only the pairs c <= c' and the upper half of every block are computed (a quarter
+// of the P x P products; the formulation through Z^T Z, Z = [p_c phi~], computed half).
+// pair index q <-> (c, c'), c <= c', row major
+__device__ __forceinline__ void pair_of(int64_t q, int64_t C, int64_t& c, int64_t& c2) {
+  c = 0;
+  while (q >= C - c) { q -= C - c; ++c; }
+  c2 = c + q;
+}
+// Phi[m][j] = phi~ of batch row m (j < D features, j == D bias scale), zero padded to ldp
+__global__ void ll_build_phi_kernel(const int64_t* __restrict__ idx, int64_t M, FeatView Phi, int64_t ldp,
+                                    float* __restrict__ out) {
+  const int64_t total = M * ldp;
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
   for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t m = t / ldz, q = t - m * ldz;
-    float v = 0.f;
-    if (q < C * D) {
-      const int64_t c = q / D, d = q - c * D;
-      v = probs[m * C + c] * feat(Phi, idx[m], d);
-    } else if (q < C * D + C) {
-      v = probs[m * C + (q - C * D)] * feat(Phi, idx[m], D);
-    }
-    Z[t] = v;
+    const int64_t m = t / ldp, j = t - m * ldp;
+    out[t] = j <= Phi.width ? feat(Phi, idx[m], j) : 0.f;
   }
 }
-// Y[c][m][d~] = sqrt(p[m,c]) phi~[m,d~]   (d~ in 0..D, row stride ldy zero padded)
-__global__ void ll_build_y_kernel(const float* __restrict__ probs, const int64_t* __restrict__ idx, int64_t M,
-                                  int64_t C, FeatView Phi, int64_t ldy, float* __restrict__ Y) {
-  const int64_t total = C * M * ldy;
+// w = Lambda[m, c, c'] = [c == c'] p_c - p_c p_c'.  rs[q][m] = sqrt|w| (row scale of the Gram), ws[q][m] = w * s_m (signed,
+// times the bias scale of the row: the bias column of a block is sum_m w s_m phi~_m), zsign[q] = +1 (c == c') / -1
+__global__ void ll_pair_weights_kernel(const float* __restrict__ probs, const int64_t* __restrict__ idx, FeatView Phi,
+                                       int64_t M, int64_t C, int64_t Q, float* __restrict__ rs, float* __restrict__ ws,
+                                       float* __restrict__ zsign) {
+  const int64_t q = blockIdx.y;
+  int64_t c, c2;
+  pair_of(q, C, c, c2);
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t c = t / (M * ldy), r = t - c * M * ldy;
-    const int64_t m = r / ldy, d = r - m * ldy;
-    Y[t] = d <= Phi.width ? sqrtf(probs[m * C + c]) * feat(Phi, idx[m], d) : 0.f;
+  for (int64_t m = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; m < M; m += stride) {
+    const float pc = probs[m * C + c], pc2 = probs[m * C + c2];
+    const float w = (c == c2 ? pc : 0.f) - pc * pc2;
+    rs[q * M + m] = sqrtf(fabsf(w));
+    ws[q * M + m] = w * feat(Phi, idx[m], Phi.width);
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) zsign[q] = c == c2 ? 1.f : -1.f;
 }
-// H[(c,d),(c,d')] += S[d,d'] etc. for the block of class c; S is the symmetric upper scratch [(D+1)^2]
-__global__ void ll_place_block_kernel(const float* __restrict__ S, int64_t D, int64_t C, int64_t c,
-                                      float* __restrict__ Hout) {
+// S[q] [D x D] (upper sub-tiles valid) and Sb[q] [D + 1] (bias column) -> upper triangle of H.
+// H index of (class c, column a): a < D -> c * D + a, a == D (bias) -> C * D + c.
+__global__ void ll_place_pairs_kernel(const float* __restrict__ S, const float* __restrict__ Sb, int64_t D, int64_t C,
+                                      int64_t Q, float* __restrict__ Hout) {
   const int64_t D1 = D + 1, P = C * D + C;
+  const int64_t q = blockIdx.y;
+  int64_t c, c2;
+  pair_of(q, C, c, c2);
+  const float* __restrict__ Sq = S + q * D * D;
+  const float* __restrict__ Sbq = Sb + q * D1;
   const int64_t total = D1 * D1;
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
   for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
     const int64_t a = t / D1, b = t - a * D1;
-    const int64_t lo = a < b ? a : b, hi = a < b ? b : a;
-    const float v = S[lo * D1 + hi];
+    if (c == c2 && a > b) continue;  // diagonal pair: its own upper half only
+    float v;
+    if (a < D && b < D) v = Sq[(a < b ? a : b) * D + (a < b ? b : a)];
+    else v = Sbq[a == D ? b : a];  // (bias, j) or (j, bias); (bias, bias) = Sbq[D]
     const int64_t ra = a < D ? c * D + a : C * D + c;
-    const int64_t rb = b < D ? c * D + b : C * D + c;
-    if (ra <= rb) Hout[ra * P + rb] += v;  // upper triangle only: the lower one is mirrored once per call
+    const int64_t rb = b < D ? c2 * D + b : C * D + c2;
+    const int64_t lo = ra < rb ? ra : rb, hi = ra < rb ? rb : ra;
+    Hout[lo * P + hi] += v;
   }
 }
 
@@ -284,28 +300,30 @@ int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, in
   FeatView Phi;
   feat_views(h, L - 1, Phi);
   const int64_t D = Phi.width, D1 = D + 1, P = C * D + C;
-  const int64_t ldz = cdiv(P, 4) * 4, ldy = cdiv(D1, 4) * 4;
 
-  // - Z^T Z, accumulated straight into the upper triangle of H (one writer per element: no scratch matrix, no atomics)
-  LGNN_CALL(h->ws.planes_a.reserve(std::max(size_t(M) * ldz, size_t(C) * M * ldy) * 4));  // Z, then Y
+  // weighted Grams over the class pairs (see the kernels above)
+  const int64_t Q = C * (C + 1) / 2, ldp = cdiv(D1, 4) * 4;
+  LGNN_CALL(h->ws.planes_a.reserve(size_t(M) * ldp * 4 + size_t(Q) * (2 * M + D1 + 1) * 4));
   h->ws.planes_a_zero_ptr = nullptr;
-  float* Z = h->ws.planes_a.as<float>();
-  hipLaunchKernelGGL(ll_build_z_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M * ldz, 256), 8192))), dim3(256), 0, s,
-                     probs, idx, M, C, Phi, ldz, Z);
-  LGNN_CALL(launch_gram_scaled(Z, ldz, M, P, H_out, -1.0f, s));
-
-  // + blockdiag_c sum_n p_nc phi~ phi~^T
-  float* Y = h->ws.planes_a.as<float>();
-  LGNN_CALL(h->ws.misc.reserve(size_t(D1) * D1 * 4));
-  float* s2 = h->ws.misc.as<float>();
-  hipLaunchKernelGGL(ll_build_y_kernel, dim3(unsigned(std::min<int64_t>(cdiv(C * M * ldy, 256), 8192))), dim3(256), 0,
-                     s, probs, idx, M, C, Phi, ldy, Y);
-  for (int64_t c = 0; c < C; ++c) {
-    LGNN_HIP_CHECK(hipMemsetAsync(s2, 0, size_t(D1) * D1 * 4, s));
-    LGNN_CALL(launch_gram(Y + c * M * ldy, ldy, M, D1, s2, s));
-    hipLaunchKernelGGL(ll_place_block_kernel, dim3(unsigned(std::min<int64_t>(cdiv(D1 * D1, 256), 2048))), dim3(256),
-                       0, s, s2, D, C, c, H_out);
-  }
+  LGNN_CALL(h->ws.planes_b.reserve(size_t(Q) * D * D * 4));
+  float* PhiM = h->ws.planes_a.as<float>();
+  float* rs = PhiM + M * ldp;
+  float* wsg = rs + Q * M;
+  float* Sb = wsg + Q * M;
+  float* zsign = Sb + Q * D1;
+  float* S = h->ws.planes_b.as<float>();
+  hipLaunchKernelGGL(ll_build_phi_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M * ldp, 256), 8192))), dim3(256), 0, s,
+                     idx, M, Phi, ldp, PhiM);
+  hipLaunchKernelGGL(ll_pair_weights_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M, 256), 64)), unsigned(Q)), dim3(256),
+                     0, s, probs, idx, Phi, M, C, Q, rs, wsg, zsign);
+  LGNN_HIP_CHECK(hipGetLastError());
+  LGNN_HIP_CHECK(hipMemsetAsync(S, 0, size_t(Q) * D * D * 4, s));
+  // S[q] = sign_q * (diag(rs_q) Phi)^T (diag(rs_q) Phi) over the D feature columns
+  LGNN_CALL(launch_gram_batched(PhiM, ldp, M, D, S, D * D, Q, rs, zsign, 1.0f, s));
+  // bias column: Sb[q][j] = sum_m w_qm phi~[m][j], one library GEMM [Q x M] * [M x D1]
+  LGNN_CALL(ll_bias_gemm(wsg, PhiM, Sb, Q, M, D1, ldp, s));
+  hipLaunchKernelGGL(ll_place_pairs_kernel, dim3(unsigned(std::min<int64_t>(cdiv(D1 * D1, 256), 1024)), unsigned(Q)),
+                     dim3(256), 0, s, S, Sb, D, C, Q, H_out);
   LGNN_HIP_CHECK(hipGetLastError());
   // everything above touched the upper triangle (and the diagonal 32 x 32 blocks); mirror it
   LGNN_CALL(launch_symmetrize_upper(H_out, P, s));

@@ -63,6 +63,20 @@ __global__ __launch_bounds__(256) void plane_colsum_kernel(const float* __restri
 
 }  // namespace
 
+// row major C[Q, D1] = A[Q, M] * B[M, D1] (ld ldp): the bias column of the last-layer pair Grams (diag.hip)
+int ll_bias_gemm(const float* Wq, const float* Phi, float* Sb, int64_t Q, int64_t M, int64_t D1, int64_t ldp,
+                 hipStream_t s) {
+  rocblas_handle blas = static_cast<rocblas_handle>(blas_handle(s));
+  LGNN_REQUIRE(blas != nullptr, "rocBLAS handle");
+  const float one = 1.f, zero = 0.f;
+  // column-major view: C^T[D1, Q] = B^T[D1, M] * A^T[M, Q]
+  const rocblas_status st = rocblas_sgemm(blas, rocblas_operation_none, rocblas_operation_none, rocblas_int(D1),
+                                          rocblas_int(Q), rocblas_int(M), &one, Phi, rocblas_int(ldp), Wq, rocblas_int(M),
+                                          &zero, Sb, rocblas_int(D1));
+  if (st != rocblas_status_success) { set_error("rocblas_sgemm failed"); return 3; }
+  return 0;
+}
+
 int jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out, hipStream_t s) {
   LGNN_REQUIRE(h->L > 0, "no model bound");
   LGNN_CALL(forward_ensure(h, s));

@@ -510,7 +510,13 @@ __device__ __forceinline__ void gram_flush(float* __restrict__ scratch, int64_t 
 template <int DT, int VEC>
 __global__ __launch_bounds__(256) void gram_mem_kernel(const float* __restrict__ X, int64_t ld, int64_t R, int64_t D,
                                                        float* __restrict__ scratch, int64_t rows_per_wg, int ntile,
-                                                       float scale, int direct) {
+                                                       float scale, int direct, const float* __restrict__ row_scale,
+                                                       int64_t out_zstride, const float* __restrict__ zscale) {
+  // blockIdx.z: one Gram per z over the SAME rows X, each row r scaled by row_scale[z * R + r] (weighted Gram
+  // X^T diag(w_z) X with w_z = zscale[z] * row_scale[z]^2), written to scratch + z * out_zstride
+  const float* __restrict__ rsz = row_scale ? row_scale + int64_t(blockIdx.z) * R : nullptr;
+  scratch += int64_t(blockIdx.z) * out_zstride;
+  if (zscale) scale *= zscale[blockIdx.z];
   using Cfg = GramCfg<DT>;
   constexpr int NSLOT = Cfg::NSLOT;
   constexpr int PANELS = Cfg::HAS_OFF ? 2 : 1;
@@ -568,6 +574,7 @@ __global__ __launch_bounds__(256) void gram_mem_kernel(const float* __restrict__
             if (gcol + 2 < D) v.z = src[2];
             if (gcol + 3 < D) v.w = src[3];
           }
+          if (rsz) { const float w = rsz[grow]; v.x *= w; v.y *= w; v.z *= w; v.w *= w; }
         }
         stage[pn][it] = v;
       }
@@ -603,28 +610,34 @@ __global__ __launch_bounds__(256) void gram_mem_kernel(const float* __restrict__
 
 // out[i, j] += scale * (X^T X)[i, j] for the upper 32x32 sub-tiles (i-tile <= j-tile; diagonal sub-tiles whole).
 // When the rows are not split over workgroups every element has one writer and is updated without atomics.
-int launch_gram_scaled(const float* X, int64_t ld, int64_t R, int64_t D, float* out, float scale, hipStream_t s) {
-  if (R <= 0 || D <= 0) return 0;
+int launch_gram_batched(const float* X, int64_t ld, int64_t R, int64_t D, float* out, int64_t out_zstride, int64_t nz,
+                        const float* row_scale, const float* zscale, float scale, hipStream_t s) {
+  if (R <= 0 || D <= 0 || nz <= 0) return 0;
+  LGNN_REQUIRE(nz < 65536, "too many Grams in one batched launch");
   const bool vec = (ld % 4 == 0) && aligned16(X);
   int dt = D <= 64 ? 64 : (D <= 128 ? 128 : (D <= 256 ? 256 : 128));
   const int ntile = int(cdiv(D, dt));
   const int npairs = ntile * (ntile + 1) / 2;
   // split the rows so that about 4 workgroups per CU exist (256 CUs), at least one 32-row block each
-  int64_t want_wg = std::max<int64_t>(1, (1024 + npairs - 1) / npairs);
+  int64_t want_wg = std::max<int64_t>(1, (1024 + npairs * nz - 1) / (npairs * nz));
   int64_t rows_per_wg = std::max<int64_t>(KT, cdiv(cdiv(R, want_wg), KT) * KT);
   const int64_t ksplit = cdiv(R, rows_per_wg);
   LGNN_REQUIRE(ksplit < 65536, "gram split too large");
   const int direct = ksplit == 1 ? 1 : 0;
-  const dim3 grid{unsigned(npairs), unsigned(ksplit), 1u};
+  const dim3 grid{unsigned(npairs), unsigned(ksplit), unsigned(nz)};
 #define LGNN_GRAM_LAUNCH(DTV)                                                                                   \
-  if (vec) hipLaunchKernelGGL((gram_mem_kernel<DTV, 4>), grid, dim3(256), 0, s, X, ld, R, D, out, rows_per_wg, ntile, scale, direct); \
-  else hipLaunchKernelGGL((gram_mem_kernel<DTV, 1>), grid, dim3(256), 0, s, X, ld, R, D, out, rows_per_wg, ntile, scale, direct);
+  if (vec) hipLaunchKernelGGL((gram_mem_kernel<DTV, 4>), grid, dim3(256), 0, s, X, ld, R, D, out, rows_per_wg, ntile, scale, direct, row_scale, out_zstride, zscale); \
+  else hipLaunchKernelGGL((gram_mem_kernel<DTV, 1>), grid, dim3(256), 0, s, X, ld, R, D, out, rows_per_wg, ntile, scale, direct, row_scale, out_zstride, zscale);
   if (dt == 64) { LGNN_GRAM_LAUNCH(64) }
   else if (dt == 128) { LGNN_GRAM_LAUNCH(128) }
   else { LGNN_GRAM_LAUNCH(256) }
 #undef LGNN_GRAM_LAUNCH
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+int launch_gram_scaled(const float* X, int64_t ld, int64_t R, int64_t D, float* out, float scale, hipStream_t s) {
+  return launch_gram_batched(X, ld, R, D, out, 0, 1, nullptr, nullptr, scale, s);
 }
 
 int launch_gram(const float* X, int64_t ld, int64_t R, int64_t D, float* scratch, hipStream_t s) {

@@ -214,6 +214,11 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float*
 int launch_gram(const float* X, int64_t ld, int64_t R, int64_t D, float* scratch, hipStream_t s);
 // out[i,j] += scale * (X^T X)[i,j] on the upper sub-tiles, without atomics when the rows are not split
 int launch_gram_scaled(const float* X, int64_t ld, int64_t R, int64_t D, float* out, float scale, hipStream_t s);
+// nz weighted Grams over the same rows: out[z] += scale * zscale[z] * X^T diag(row_scale[z]^2) X (upper sub-tiles)
+int launch_gram_batched(const float* X, int64_t ld, int64_t R, int64_t D, float* out, int64_t out_zstride, int64_t nz,
+                        const float* row_scale, const float* zscale, float scale, hipStream_t s);
+// row major Sb[Q, D1] = Wq[Q, M] * Phi[M, D1] (rocBLAS; jacobian.hip)
+int ll_bias_gemm(const float* Wq, const float* Phi, float* Sb, int64_t Q, int64_t M, int64_t D1, int64_t ldp, hipStream_t s);
 // lower triangle <- upper triangle
 int launch_symmetrize_upper(float* H, int64_t D, hipStream_t s);
 // out[i,j] += scale * scratch[min(i,j), max(i,j)]
