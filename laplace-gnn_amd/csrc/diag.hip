@@ -182,11 +182,11 @@ __global__ void ll_build_phi_kernel(const int64_t* __restrict__ idx, int64_t M, 
 // w = Lambda[m, c, c'] = [c == c'] p_c - p_c p_c'.  rs[q][m] = sqrt|w| (row scale of the Gram), ws[q][m] = w * s_m (signed,
 // times the bias scale of the row: the bias column of a block is sum_m w s_m phi~_m), zsign[q] = +1 (c == c') / -1
 __global__ void ll_pair_weights_kernel(const float* __restrict__ probs, const int64_t* __restrict__ idx, FeatView Phi,
-                                       int64_t M, int64_t C, int64_t Q, float* __restrict__ rs, float* __restrict__ ws,
+                                       int64_t M, int64_t C, int64_t q0, float* __restrict__ rs, float* __restrict__ ws,
                                        float* __restrict__ zsign) {
-  const int64_t q = blockIdx.y;
+  const int64_t q = blockIdx.y;  // index inside the chunk of pairs that starts at q0
   int64_t c, c2;
-  pair_of(q, C, c, c2);
+  pair_of(q0 + q, C, c, c2);
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
   for (int64_t m = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; m < M; m += stride) {
     const float pc = probs[m * C + c], pc2 = probs[m * C + c2];
@@ -199,11 +199,11 @@ __global__ void ll_pair_weights_kernel(const float* __restrict__ probs, const in
 // S[q] [D x D] (upper sub-tiles valid) and Sb[q] [D + 1] (bias column) -> upper triangle of H.
 // H index of (class c, column a): a < D -> c * D + a, a == D (bias) -> C * D + c.
 __global__ void ll_place_pairs_kernel(const float* __restrict__ S, const float* __restrict__ Sb, int64_t D, int64_t C,
-                                      int64_t Q, float* __restrict__ Hout) {
+                                      int64_t q0, float* __restrict__ Hout) {
   const int64_t D1 = D + 1, P = C * D + C;
   const int64_t q = blockIdx.y;
   int64_t c, c2;
-  pair_of(q, C, c, c2);
+  pair_of(q0 + q, C, c, c2);
   const float* __restrict__ Sq = S + q * D * D;
   const float* __restrict__ Sbq = Sb + q * D1;
   const int64_t total = D1 * D1;
@@ -301,29 +301,35 @@ int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, in
   feat_views(h, L - 1, Phi);
   const int64_t D = Phi.width, D1 = D + 1, P = C * D + C;
 
-  // weighted Grams over the class pairs (see the kernels above)
+  // weighted Grams over the class pairs (see the kernels above), in chunks of pairs that fit the workspace cap
   const int64_t Q = C * (C + 1) / 2, ldp = cdiv(D1, 4) * 4;
-  LGNN_CALL(h->ws.planes_a.reserve(size_t(M) * ldp * 4 + size_t(Q) * (2 * M + D1 + 1) * 4));
+  const int64_t per_pair = (D * D + 2 * M + D1 + 1) * 4;
+  const int64_t qc_max = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(Q, 32768), h->ws_limit / per_pair));
+  LGNN_CALL(h->ws.planes_a.reserve(size_t(M) * ldp * 4 + size_t(qc_max) * (2 * M + D1 + 1) * 4));
   h->ws.planes_a_zero_ptr = nullptr;
-  LGNN_CALL(h->ws.planes_b.reserve(size_t(Q) * D * D * 4));
+  LGNN_CALL(h->ws.planes_b.reserve(size_t(qc_max) * D * D * 4));
   float* PhiM = h->ws.planes_a.as<float>();
   float* rs = PhiM + M * ldp;
-  float* wsg = rs + Q * M;
-  float* Sb = wsg + Q * M;
-  float* zsign = Sb + Q * D1;
+  float* wsg = rs + qc_max * M;
+  float* Sb = wsg + qc_max * M;
+  float* zsign = Sb + qc_max * D1;
   float* S = h->ws.planes_b.as<float>();
   hipLaunchKernelGGL(ll_build_phi_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M * ldp, 256), 8192))), dim3(256), 0, s,
                      idx, M, Phi, ldp, PhiM);
-  hipLaunchKernelGGL(ll_pair_weights_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M, 256), 64)), unsigned(Q)), dim3(256),
-                     0, s, probs, idx, Phi, M, C, Q, rs, wsg, zsign);
   LGNN_HIP_CHECK(hipGetLastError());
-  LGNN_HIP_CHECK(hipMemsetAsync(S, 0, size_t(Q) * D * D * 4, s));
-  // S[q] = sign_q * (diag(rs_q) Phi)^T (diag(rs_q) Phi) over the D feature columns
-  LGNN_CALL(launch_gram_batched(PhiM, ldp, M, D, S, D * D, Q, rs, zsign, 1.0f, s));
-  // bias column: Sb[q][j] = sum_m w_qm phi~[m][j], one library GEMM [Q x M] * [M x D1]
-  LGNN_CALL(ll_bias_gemm(wsg, PhiM, Sb, Q, M, D1, ldp, s));
-  hipLaunchKernelGGL(ll_place_pairs_kernel, dim3(unsigned(std::min<int64_t>(cdiv(D1 * D1, 256), 1024)), unsigned(Q)),
-                     dim3(256), 0, s, S, Sb, D, C, Q, H_out);
+  for (int64_t q0 = 0; q0 < Q; q0 += qc_max) {
+    const int64_t qc = std::min(qc_max, Q - q0);
+    hipLaunchKernelGGL(ll_pair_weights_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M, 256), 64)), unsigned(qc)),
+                       dim3(256), 0, s, probs, idx, Phi, M, C, q0, rs, wsg, zsign);
+    LGNN_HIP_CHECK(hipGetLastError());
+    LGNN_HIP_CHECK(hipMemsetAsync(S, 0, size_t(qc) * D * D * 4, s));
+    // S[q] = sign_q * (diag(rs_q) Phi)^T (diag(rs_q) Phi) over the D feature columns
+    LGNN_CALL(launch_gram_batched(PhiM, ldp, M, D, S, D * D, qc, rs, zsign, 1.0f, s));
+    // bias column: Sb[q][j] = sum_m w_qm s_m phi~[m][j], one library GEMM [qc x M] * [M x D1]
+    LGNN_CALL(ll_bias_gemm(wsg, PhiM, Sb, qc, M, D1, ldp, s));
+    hipLaunchKernelGGL(ll_place_pairs_kernel, dim3(unsigned(std::min<int64_t>(cdiv(D1 * D1, 256), 1024)), unsigned(qc)),
+                       dim3(256), 0, s, S, Sb, D, C, q0, H_out);
+  }
   LGNN_HIP_CHECK(hipGetLastError());
   // everything above touched the upper triangle (and the diagonal 32 x 32 blocks); mirror it
   LGNN_CALL(launch_symmetrize_upper(H_out, P, s));

@@ -357,6 +357,8 @@ def test_diag_lastlayer_jacobians_random_configurations_vs_oracle(seed):
     if p_ll <= 6000:
         Hl = torch.zeros(p_ll, p_ll, device="cuda")
         loss = torch.zeros(1, device="cuda")
+        if seed % 3 == 0:
+            eng.set_workspace_limit(1 << 20)  # the minimum: several chunks of class pairs for the larger heads
         eng.lastlayer_full_accumulate(idx.cuda(), y.cuda(), Hl, loss)
         ol, oh = O.lastlayer_full_batch(om, idx.numpy(), y.numpy())
         assert close(Hl.cpu().numpy(), oh), ("last layer", cfg)
