@@ -552,6 +552,11 @@ __global__ __launch_bounds__(256) void gram_mem_kernel(const float* __restrict__
   const int64_t cA = int64_t(ti) * DT, cB = int64_t(tj) * DT;
   constexpr int PER_THREAD = KT * DT / 4 / 256;  // float4 slots per thread per panel
   float4 stage[PANELS][PER_THREAD];
+  float wstage[PANELS][PER_THREAD];  // row scales of the staged rows (weighted Gram)
+#pragma unroll
+  for (int pn = 0; pn < PANELS; ++pn)
+#pragma unroll
+    for (int it = 0; it < PER_THREAD; ++it) wstage[pn][it] = 1.f;
 
   auto load_block = [&](int64_t rb) {
 #pragma unroll
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(256) void gram_mem_kernel(const float* __restrict__
             if (gcol + 2 < D) v.z = src[2];
             if (gcol + 3 < D) v.w = src[3];
           }
-          if (rsz) { const float w = rsz[grow]; v.x *= w; v.y *= w; v.z *= w; v.w *= w; }
+          if (rsz) wstage[pn][it] = rsz[grow];  // applied in store_block: using it here would wait for the loads
         }
         stage[pn][it] = v;
       }
@@ -588,7 +593,9 @@ __global__ __launch_bounds__(256) void gram_mem_kernel(const float* __restrict__
       for (int it = 0; it < PER_THREAD; ++it) {
         const int flat = it * 256 + tid;
         const int r = flat / (DT / 4), c4 = (flat % (DT / 4)) * 4;
-        *reinterpret_cast<float4*>(&tile[pn][r][c4]) = stage[pn][it];
+        float4 v = stage[pn][it];
+        if (rsz) { const float w = wstage[pn][it]; v.x *= w; v.y *= w; v.z *= w; v.w *= w; }
+        *reinterpret_cast<float4*>(&tile[pn][r][c4]) = v;
       }
     }
   };
