@@ -268,6 +268,13 @@ def main():
 
     torch.set_num_threads(8)
     ns = ref_loader.load()
+    only = set(sys.argv[1:])  # optional: fixture names to (re)generate; default all
+    real_make_case, real_mlp = make_case, make_regression_mlp
+
+    def make_case_(ns_, torch_, name, *a, **k):
+        if not only or name in only:
+            real_make_case(ns_, torch_, name, *a, **k)
+    globals()["make_case"] = make_case_
     small = dict(n=64, f=12, h=8, c=3, layers=2, n_edges=150)
     mid = dict(n=512, f=64, h=32, c=7, layers=2, n_edges=1800)
     for seed in (0, 1, 2):
@@ -285,7 +292,18 @@ def main():
     make_case(ns, torch, "sage_small_3batch_s1", "sage", **small, n_train=33, batch_size=12,
               seed=1, isolated=4)
     make_case(ns, torch, "sage_mid_2batch_s2", "sage", **mid, n_train=150, batch_size=100, seed=2)
-    make_regression_mlp(ns, torch)
+    # three layers: the reference only builds them once the live breakpoint at gnn/models/base_gnn.py:109 is a no-op
+    # (ref_loader installs one); kron / diag / full GGN / Jacobians all come from the reference's own code
+    small3 = dict(n=64, f=12, h=8, c=3, layers=3, n_edges=150)
+    mid3 = dict(n=384, f=40, h=24, c=5, layers=3, n_edges=1300)
+    make_case(ns, torch, "gcn3_small_1batch_s0", "gcn", **small3, n_train=33, batch_size=10000, seed=20, with_full=True)
+    make_case(ns, torch, "gcn3_small_3batch_sym_s1", "gcn", **small3, n_train=33, batch_size=12, seed=21, symmetric=True)
+    make_case(ns, torch, "sage3_small_1batch_s0", "sage", **small3, n_train=33, batch_size=10000, seed=22, with_full=True)
+    make_case(ns, torch, "sage3_small_3batch_s1", "sage", **small3, n_train=33, batch_size=12, seed=23, isolated=3)
+    make_case(ns, torch, "gcn3_mid_2batch_s0", "gcn", **mid3, n_train=120, batch_size=70, seed=24)
+    make_case(ns, torch, "sage3_mid_2batch_s1", "sage", **mid3, n_train=120, batch_size=70, seed=25, symmetric=True)
+    if not only or "c1_regression_mlp" in only:
+        make_regression_mlp(ns, torch)
 
 
 if __name__ == "__main__":
