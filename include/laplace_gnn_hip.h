@@ -134,11 +134,20 @@ LGNN_API int lgnn_kfac_accumulate_classes(lgnn_ctx* h, const int64_t* idx, const
                                  uint32_t flags, int64_t class_begin, int64_t class_end,
                                  float* const* A_out, float* const* B_out, float* loss_out, void* stream);
 
+/* Host-only query (no context, no device work): which kernels lgnn_kfac_accumulate would run for a model of this
+ * shape -- the per-layer choice between the fused SpMM^T -> Gram kernel and the SpMM + Gram pair through HBM, the
+ * compacted backward GEMM, and the workspace layout (curvlinops/kfac.py:653-661 has one autograd backward per class
+ * instead; nothing to choose there).  out: int64 [4 + num_layers] = {seeds_on_the_fly, sage_compact, need_pong,
+ * classes_per_chunk, step_0 .. step_{L-1}} with step_l = 1 (fused) | 2 (compacted backward GEMM); step_0 is unused. */
+LGNN_API int lgnn_kfac_plan(int kind, int num_layers, const int64_t* dims /* host [L+1] */, int64_t num_nodes, int64_t nnz,
+                   int activation, uint32_t flags, int64_t workspace_limit, int64_t* out /* host */);
+
 /* ---- diagonal GGN of one mini-batch ----------------------------------------------------------
  * Replaces GGNInterface.diag (laplace/curvature/curvature.py:412-432 with jacobians :89-130 and
  * _get_functional_hessian :365-372):  diag_out[P] += einsum('bcp,bck,bkp->p', J, Lambda, J),
- * parameter order = named_parameters() (W0 row-major, b0, W1, b1, ...).  2-layer GCN and
- * L-layer models are both handled without materialising J.                                     */
+ * parameter order = named_parameters() (W0 row-major, b0, W1, b1, ...).  1- and 2-layer models: closed form, no
+ * Jacobians; deeper models and the regression likelihood (y = fp32 targets [M, C], H_lik = None: sum J^T J): chunks
+ * of per-sample Jacobians contracted on the device.                                              */
 LGNN_API int lgnn_diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags,
                          float* diag_out /* [P] */, float* loss_out, void* stream);
 

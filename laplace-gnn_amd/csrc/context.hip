@@ -192,7 +192,7 @@ extern "C" void lgnn_destroy(lgnn_ctx* h) {
   (void)hipDeviceSynchronize();
   DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
                     &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult, &h->ws.planes_a,
-                    &h->ws.planes_b, &h->ws.misc, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
+                    &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (DevBuf* b : bufs) b->release();
   for (int l = 0; l < kMaxLayers; ++l) {
     h->Wt[l].release(); h->fc.lin_in[l].release(); h->fc.act_out[l].release(); h->fc.gram_raw[l].release();
@@ -229,6 +229,10 @@ extern "C" int lgnn_bind_model(lgnn_ctx* h, int num_layers, const int64_t* dims,
   h->X = X;
   h->act = activation;
   h->lik = likelihood;
+  // the compact GraphSAGE top level keeps planes_a all zero outside the batch rows for ONE plane layout; a new
+  // binding (other widths) must not inherit that claim: the old layout's spare rows hold stale backward-GEMM stores
+  h->ws.planes_a_zero_ptr = nullptr;
+  h->ws.planes_a_zero_bytes = 0;
   return lgnn_invalidate(h);
 }
 
@@ -252,7 +256,7 @@ extern "C" int64_t lgnn_device_bytes(const lgnn_ctx* h) {
   size_t t = 0;
   const DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
                           &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult,
-                          &h->ws.planes_a, &h->ws.planes_b, &h->ws.misc, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
+                          &h->ws.planes_a, &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (const DevBuf* b : bufs) t += b->bytes;
   for (int l = 0; l < kMaxLayers; ++l)
     t += h->Wt[l].bytes + h->fc.lin_in[l].bytes + h->fc.act_out[l].bytes + h->fc.gram_raw[l].bytes +

@@ -221,6 +221,47 @@ __global__ void ll_place_pairs_kernel(const float* __restrict__ S, const float* 
   }
 }
 
+// Generic depth: diag[p] += sum_m sum_{c,k} J[m,c,p] Lambda_m[c,k] J[m,k,p] from a chunk of explicit Jacobians
+// J [mc, C, P] (jacobian.hip); Lambda_m = diag(p_m) - p_m p_m^T (laplace/curvature/curvature.py:365-372, 428), so
+// per sample: sum_c p_c t_c^2 - (sum_c p_c t_c)^2 with t_c = J[m,c,p].  regression (H_lik = None, :429-430): sum_c t_c^2.
+__global__ __launch_bounds__(256) void diag_from_jac_kernel(const float* __restrict__ J, const float* __restrict__ probs,
+                                                            int64_t mc, int64_t C, int64_t P, int regression,
+                                                            float* __restrict__ diag) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int64_t m_begin = int64_t(blockIdx.y) * 8, m_end = min(mc, m_begin + 8);
+  float acc = 0.f;
+  for (int64_t m = m_begin; m < m_end; ++m) {
+    const float* __restrict__ Jm = J + m * C * P + p;
+    float s2 = 0.f, s1 = 0.f;
+    for (int64_t c = 0; c < C; ++c) {
+      const float t = Jm[c * P];
+      const float pc = regression ? 1.f : probs[m * C + c];
+      s2 += pc * t * t;
+      s1 += pc * t;
+    }
+    acc += regression ? s2 : s2 - s1 * s1;
+  }
+  atomicAdd(&diag[p], acc);
+}
+
+int diag_from_jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* diag_out, hipStream_t s) {
+  const int64_t C = h->dims[h->L], P = h->n_params;
+  // chunk of samples whose Jacobians [mc, C, P] take at most a quarter of the workspace cap (the planes of
+  // jacobian.hip are chunked against the cap by themselves)
+  const int64_t mc_max = std::max<int64_t>(1, std::min<int64_t>(M, (h->ws_limit / 4) / std::max<int64_t>(C * P * 4, 1)));
+  LGNN_CALL(h->ws.jac.reserve(size_t(mc_max) * C * P * 4));
+  float* J = h->ws.jac.as<float>();
+  for (int64_t m0 = 0; m0 < M; m0 += mc_max) {
+    const int64_t mc = std::min(mc_max, M - m0);
+    LGNN_CALL(jacobians(h, idx + m0, mc, J, nullptr, s));
+    hipLaunchKernelGGL(diag_from_jac_kernel, dim3(unsigned(cdiv(P, 256)), unsigned(cdiv(mc, 8))), dim3(256), 0, s, J,
+                       h->ws.probs.as<float>() + m0 * C, mc, C, P, h->lik == LGNN_LIK_REGRESSION ? 1 : 0, diag_out);
+    LGNN_HIP_CHECK(hipGetLastError());
+  }
+  return 0;
+}
+
 int feat_views(lgnn_ctx* h, int layer, FeatView& f) {
   f.nrows = h->N;
   // what Linear `layer` multiplies, seen from an output node: propagated input (GCN) or cat (GraphSAGE)
@@ -244,12 +285,19 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
                     float* loss_out, hipStream_t s) {
   (void)flags;
   LGNN_REQUIRE(M > 0 && idx && y && diag_out && loss_out, "empty batch or null pointers");
-  LGNN_REQUIRE(h->L >= 1 && h->L <= 2,
-               "diag: closed form implemented for 1- and 2-layer models (the reference cannot build deeper ones)");
-  LGNN_REQUIRE(h->lik == LGNN_LIK_CLASSIFICATION, "diag kernels: classification likelihood (regression goes through the Jacobians)");
-  LGNN_CALL(forward_ensure_aux(h, s));
+  LGNN_REQUIRE(h->L >= 1, "no model bound");
   const int L = h->L;
   const int64_t C = h->dims[L];
+  if (L > 2 || h->lik == LGNN_LIK_REGRESSION) {
+    // deeper models (the reference builds them once the breakpoint at gnn/models/base_gnn.py:109 is removed) and the
+    // regression likelihood: per-sample Jacobians in chunks + the contraction with Lambda; no closed form
+    LGNN_CALL(forward_ensure(h, s));
+    LGNN_CALL(batch_prologue(h, idx, y, M, false, false, loss_out, s));
+    LGNN_CALL(diag_from_jacobians(h, idx, M, diag_out, s));
+    LGNN_CALL(batch_epilogue(h, idx, M, s));
+    return 0;
+  }
+  LGNN_CALL(forward_ensure_aux(h, s));
   LGNN_CALL(batch_prologue(h, idx, y, M, false, false, loss_out, s));
   const float* probs = h->ws.probs.as<float>();
   // Samples per workgroup slab.  A thread walks its slab's samples and their neighbours one after the other (dependent

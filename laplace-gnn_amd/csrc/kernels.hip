@@ -809,8 +809,11 @@ int launch_spmm_gram_ex(const FusedArgs& a, hipStream_t s) {
   return 0;
 }
 
-bool fused_supported(int64_t width, int64_t in_ld, int64_t in_plane_stride, const void* in) {
-  return width <= 256 && width % 4 == 0 && in_ld % 4 == 0 && in_plane_stride % 4 == 0 && aligned16(in);
+bool fused_supported(int64_t width, int64_t in_ld, int64_t in_plane_stride, const void* in, int64_t rows) {
+  if (!(width <= 256 && width % 4 == 0 && in_ld % 4 == 0 && in_plane_stride % 4 == 0 && aligned16(in))) return false;
+  // the 256-wide kernel addresses a plane (and its self plane) through 32-bit buffer offsets
+  if (width > 128 && rows * in_ld * 4 >= (int64_t(1) << 32) - 4096) return false;
+  return true;
 }
 
 int launch_spmm_gram(const Csr& m, int64_t nrows, int64_t nplanes, const float* in, float* store_or_null,

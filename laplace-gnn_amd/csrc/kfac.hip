@@ -506,6 +506,43 @@ int record_event(lgnn_ctx* h, hipStream_t s) {
 
 }  // namespace
 
+// Every path decision of kfac_accumulate as a pure function of the shapes (base pointers come from hipMalloc and
+// are 256-byte aligned, so alignment follows from the widths).  One helper serves the launch loop, the workspace
+// sizing (need_pong, cc_max) and lgnn_kfac_plan, so that the prediction cannot drift from what the loop does.
+KfacPlan plan_kfac(int kind, int L, int64_t N, int64_t nnz, const int64_t* dims, int act, bool no_fuse,
+                   int64_t ws_limit) {
+  KfacPlan p{};
+  const int64_t C = dims[L];
+  const bool gcn = kind == LGNN_KIND_GCN;
+  p.seeds_on_the_fly = gcn && !no_fuse && C <= 64;
+  const int64_t d_top = L > 1 ? dims[L - 1] : 0;
+  auto hact_ld = [&](int l) { return gcn ? dims[l + 1] : 2 * dims[l + 1]; };  // row stride of h_{l+1} (context.hip)
+  p.sage_compact = !gcn && L > 1 && !no_fuse && nnz > 0 && backgemm_supported(C, 2 * d_top, false) &&
+                   (N + 1) * 2 * d_top * 4 < (int64_t(1) << 31) &&
+                   fused_supported(d_top, 2 * d_top, (N + 1) * 2 * d_top, nullptr, N + 1) && hact_ld(L - 2) % 4 == 0;
+  const bool row_active = gcn && !no_fuse && nnz > 0;  // flags of the non-zero top-layer gradient rows exist
+  p.need_pong = L > 2 || no_fuse;
+  for (int l = L - 1; l >= 1; --l) {
+    const int64_t d = dims[l], dout = dims[l + 1];
+    const bool top = l == L - 1;
+    if (gcn) {
+      p.fuse[l] = !no_fuse && fused_supported(d, d, N * d, nullptr, N + 1);
+      p.backgemm[l] = top && p.fuse[l] && row_active && backgemm_supported(dout, d, act == LGNN_ACT_RELU) &&
+                      (N + 1) * d * 4 < (int64_t(1) << 31);
+    } else {
+      const bool compact = p.sage_compact && top;
+      const int64_t stride = (compact ? N + 1 : N) * 2 * d;
+      p.fuse[l] = !no_fuse && fused_supported(d, 2 * d, stride, nullptr, N + 1) && hact_ld(l - 1) % 4 == 0;
+      p.backgemm[l] = compact;
+    }
+    if (!p.fuse[l]) p.need_pong = true;  // the unfused path writes its SpMM output there
+    p.maxw = std::max(p.maxw, gcn ? d : 2 * d);  // GEMM output width of layer l
+  }
+  const int64_t per_class = (N + 1) * p.maxw * 4 * (p.need_pong ? 2 : 1);
+  p.cc_max = std::max<int64_t>(1, std::min<int64_t>(C, ws_limit / std::max<int64_t>(per_class, 1)));
+  return p;
+}
+
 // shared by kfac / diag / last layer: mark the batch, compute seeds/probs/loss.
 int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bool want_seeds, bool fork_exact,
                    float* loss_out, hipStream_t s) {
@@ -563,9 +600,10 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   LGNN_REQUIRE(M < INT32_MAX, "batch too large");
 
   const bool fork_exact = (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0;
+  const KfacPlan plan = plan_kfac(h->kind, L, N, h->nnz, h->dims, h->act, no_fuse, h->ws_limit);
   // GCN, fused path: the top-layer kernel rebuilds each sample's C x C seed block from its probabilities and logits,
   // so the blocks are never written (64 MB per arxiv-shaped batch); every other path reads them from ws.seeds
-  const bool seeds_on_the_fly = h->kind == LGNN_KIND_GCN && !no_fuse && C <= 64;
+  const bool seeds_on_the_fly = plan.seeds_on_the_fly;
   LGNN_CALL(batch_prologue(h, idx, y, M, !seeds_on_the_fly, fork_exact, first ? loss_out : nullptr, s));
 
   // A_l += in_l^T in_l / n_train   (kfac.py:870 divides by M, curvlinops.py:46-53 multiplies by M/N)
@@ -588,11 +626,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   bool have_act_list = false;
   // GraphSAGE, fused path: the top-level GEMM g W_l runs over the (distinct) batch nodes only -- 6 % of the rows at
   // the arxiv shape -- through the compacted-row backward GEMM; the other rows of its output stay zero (see below)
-  const int64_t d_top = L > 1 ? h->dims[L - 1] : 0;
-  const bool sage_compact = h->kind == LGNN_KIND_SAGE && L > 1 && !no_fuse && h->nnz > 0 &&
-                            backgemm_supported(C, 2 * d_top, false) && (N + 1) * 2 * d_top * 4 < (int64_t(1) << 31) &&
-                            fused_supported(d_top, 2 * d_top, (N + 1) * 2 * d_top, h->ws.top.p) &&
-                            h->fc.hact_ld[L - 2] % 4 == 0;
+  const bool sage_compact = plan.sage_compact;
   if (h->kind == LGNN_KIND_GCN) {
     const int64_t nq = (ce - cb) * C;
     if (seeds_on_the_fly) {
@@ -607,7 +641,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
                               h->ws.act_count.as<int32_t>(), h->ws.select_tmp, s));
       have_act_list = true;
       float* gplanes = L > 1 ? gtop : nullptr;  // a single-layer model needs the Gram only
-      if (L > 1 && !fused_supported(h->dims[L - 1], h->dims[L - 1], N * h->dims[L - 1], gtop))
+      if (L > 1 && !plan.fuse[L - 1])
         // the unfused lower path reads every row of the planes: the rows this kernel skips must be zero
         LGNN_HIP_CHECK(hipMemsetAsync(gtop + cb * N * C, 0, size_t(N) * nq * 4, s));
       float* sc = h->ws.gram_scratch[L - 1].as<float>();
@@ -673,20 +707,14 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
         }
       }
     }
-    int64_t maxw = 0;
-    for (int l = 0; l < L - 1; ++l) maxw = std::max(maxw, h->in_dim[l + 1]);  // GEMM output width of layer l+1
     // The pong buffer holds g_{l-1} when a lower layer needs it (L > 2) and the SpMM output of the unfused path;
-    // the fused two-layer path never touches it.
-    bool need_pong = L > 2 || no_fuse;
-    for (int l = 1; l < L && !need_pong; ++l) {
-      const int64_t d = h->dims[l];
-      const bool fusable = h->kind == LGNN_KIND_GCN
-                               ? fused_supported(d, d, N * d, h->ws.top.p)
-                               : fused_supported(d, 2 * d, N * 2 * d, h->ws.top.p) && h->fc.hact_ld[l - 1] % 4 == 0;
-      need_pong = !fusable;
-    }
-    const int64_t per_class = (N + 1) * maxw * 4 * (need_pong ? 2 : 1);
-    int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(C, h->ws_limit / std::max<int64_t>(per_class, 1)));
+    // the fused two-layer path never touches it (plan_kfac decides, from the same per-layer flags the loop uses).
+    const int64_t maxw = plan.maxw;
+    const bool need_pong = plan.need_pong;
+    const int64_t cc_max = plan.cc_max;
+    for (int l = 1; l < L; ++l)
+      LGNN_REQUIRE(h->fc.hact_ld[l - 1] == (h->kind == LGNN_KIND_GCN ? h->dims[l] : 2 * h->dims[l]),
+                   "internal: activation row stride differs from the plan's");
     LGNN_CALL(h->ws.planes_a.reserve(size_t(cc_max) * (N + 1) * maxw * 4));  // + 1: the backward GEMM's spare row per plane
     if (need_pong) LGNN_CALL(h->ws.planes_b.reserve(size_t(cc_max) * N * maxw * 4));
     for (int64_t c0 = cb; c0 < ce; c0 += cc_max) {
@@ -705,12 +733,12 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           GemmEpilogue ep;
           ep.hact = h->fc.hact_p[l - 1]; ep.hact_ld = h->fc.hact_ld[l - 1]; ep.act = h->act; ep.hact_row_mod = N;
           const bool top_level = l == L - 1;
-          const bool fuse_here = !no_fuse && fused_supported(d, d, N * d, ping);
+          const bool fuse_here = plan.fuse[l];
           if (top_level && fuse_here) ep.row_active = row_active;  // inactive rows are never read below
           int64_t ping_stride = N * d;
           // (32-bit row offsets inside a plane: beyond 2 GiB per plane the generic GEMM takes over)
-          if (top_level && fuse_here && row_active && backgemm_supported(dout, d, h->act == LGNN_ACT_RELU) &&
-              (N + 1) * d * 4 < (int64_t(1) << 31)) {
+          if (plan.backgemm[l]) {
+            LGNN_REQUIRE(row_active != nullptr, "internal: compacted backward GEMM without its row list");
             ping_stride = (N + 1) * d;  // row N of every plane takes the stores of rows past the end of the list
             BackGemmArgs bg{};
             bg.u_plane_stride = ping_stride;
@@ -782,7 +810,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           LGNN_REQUIRE(!store || pong != nullptr, "internal: stored planes without a buffer");
           a.store = store ? pong : nullptr; a.store_ld = d; a.store_plane_stride = N * d;
           a.width = d; a.scratch = scratch;
-          if (!no_fuse && fused_supported(d, a.in_ld, a.in_plane_stride, a.in) && h->fc.hact_ld[l - 1] % 4 == 0) {
+          if (plan.fuse[l]) {
             if (h->timing && dominant) LGNN_CALL(record_event(h, s));
             LGNN_CALL(launch_spmm_gram_ex(a, s));
             if (h->timing && dominant) { LGNN_CALL(record_event(h, s)); h->ev_planes += cc; }
@@ -818,3 +846,19 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
 }
 
 }  // namespace lgnn
+
+// Host-only: which kernels a KFAC accumulate of this shape would run (no context, no device work) -- lets the path
+// decisions be tested per branch without allocating the planes (products-shaped GraphSAGE: 5 GB per plane).
+extern "C" int lgnn_kfac_plan(int kind, int num_layers, const int64_t* dims, int64_t num_nodes, int64_t nnz, int activation,
+                              uint32_t flags, int64_t workspace_limit, int64_t* out) {
+  using namespace lgnn;
+  if (!dims || !out) { set_error("null argument"); return 2; }
+  LGNN_REQUIRE(num_layers >= 1 && num_layers <= kMaxLayers, "num_layers out of range");
+  LGNN_REQUIRE(kind == LGNN_KIND_GCN || kind == LGNN_KIND_SAGE, "unknown graph kind");
+  LGNN_REQUIRE(workspace_limit > 0 && num_nodes > 0, "workspace limit and node count must be positive");
+  const KfacPlan p = plan_kfac(kind, num_layers, num_nodes, nnz, dims, activation, (flags & LGNN_FLAG_NO_FUSE) != 0,
+                               workspace_limit);
+  out[0] = p.seeds_on_the_fly; out[1] = p.sage_compact; out[2] = p.need_pong; out[3] = p.cc_max;
+  for (int l = 0; l < num_layers; ++l) out[4 + l] = (p.fuse[l] ? 1 : 0) | (p.backgemm[l] ? 2 : 0);
+  return 0;
+}

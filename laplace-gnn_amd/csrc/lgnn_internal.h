@@ -87,6 +87,7 @@ struct Workspace {
   DevBuf planes_b;  // backward planes, pong
   DevBuf gram_scratch[kMaxLayers];  // [out_l, out_l] per-call partial B (upper sub-tiles)
   DevBuf misc;
+  DevBuf jac;      // fp32 [chunk, C, P]: Jacobians of a chunk of samples (generic-depth diagonal GGN)
   DevBuf top;    // top-layer gradient planes [C][N][C]
   DevBuf active;   // uint8 [N]: node has a non-zero top-layer gradient row
   DevBuf val_act;  // fp32 [nnz]: P^T values with inactive source columns zeroed
@@ -227,7 +228,9 @@ int launch_sym_accumulate(const float* scratch, int64_t D, float scale, float* o
 int launch_spmm_ex(const SpmmArgs& a, int64_t nplanes, hipStream_t s);
 int launch_spmm_gram_ex(const FusedArgs& a, hipStream_t s);
 int launch_spmm_gram256(const FusedArgs& a, hipStream_t s);  // fused256.hip
-bool fused_supported(int64_t width, int64_t in_ld, int64_t in_plane_stride, const void* in);
+// `rows`: rows per plane incl. a spare row where one exists; planes wider than 128 columns go through 32-bit buffer
+// offsets (fused256.hip), so rows * in_ld * 4 must stay below 4 GiB there -- otherwise the unfused path takes over
+bool fused_supported(int64_t width, int64_t in_ld, int64_t in_plane_stride, const void* in, int64_t rows);
 int launch_spmm_gram(const Csr& m, int64_t nrows, int64_t nplanes, const float* in, float* store_or_null,
                      int64_t width, float* scratch, hipStream_t s);
 
@@ -237,6 +240,15 @@ int launch_gather_rows(const float* in, int64_t ld, int64_t nrows_in, const int6
                        float* out, int* bad_flag, hipStream_t s);
 
 // ---- kfac.hip ---------------------------------------------------------------------------
+struct KfacPlan {
+  bool seeds_on_the_fly;       // GCN top layer rebuilds the seed blocks from probabilities + logits
+  bool sage_compact;           // GraphSAGE top level over the batch nodes only (compacted backward GEMM + fused MODE 1)
+  bool need_pong;              // the second plane buffer is written by some step
+  bool fuse[kMaxLayers];       // step l (l = L-1 .. 1): fused SpMM^T -> Gram kernel (else SpMM + Gram through HBM)
+  bool backgemm[kMaxLayers];   // step l: compacted producer / consumer backward GEMM (else the generic GEMM)
+  int64_t maxw, cc_max;        // widest GEMM output of the lower layers; class planes per chunk under the workspace cap
+};
+KfacPlan plan_kfac(int kind, int L, int64_t N, int64_t nnz, const int64_t* dims, int act, bool no_fuse, int64_t ws_limit);
 int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train, uint32_t flags,
                     int64_t class_begin, int64_t class_end, float* const* A_out, float* const* B_out, float* loss_out, hipStream_t s);
 int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bool want_seeds, bool fork_exact,
@@ -251,5 +263,7 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
                     float* loss_out, hipStream_t s);
 int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out,
                               float* loss_out, hipStream_t s);
+// ---- jacobian.hip -----------------------------------------------------------------------
+int jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out, hipStream_t s);
 
 }  // namespace lgnn

@@ -100,9 +100,7 @@ class HipCurvatureInterface:
 
     # ---- diag ----------------------------------------------------------------------------------
     def diag(self, x: torch.Tensor, y: torch.Tensor, **kwargs: Any):
-        if self.likelihood == "regression":
-            return self._regression_from_jacobians(x, y, full=False)
-        self.engine.set_likelihood("classification")
+        self.engine.set_likelihood(self.likelihood)  # regression: H = sum J^T J on the device (no factor on H)
         eng = self.engine
         H = torch.zeros(eng.n_params, dtype=torch.float32, device=eng.device)
         loss = torch.zeros(1, dtype=torch.float32, device=eng.device)

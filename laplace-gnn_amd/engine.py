@@ -31,6 +31,22 @@ def _dev_ptr(t: torch.Tensor, dtype, what: str) -> C.c_void_p:
     return C.c_void_p(t.data_ptr())
 
 
+def kfac_plan(kind: str, dims: Sequence[int], num_nodes: int, nnz: int, act: str = "relu", fuse: bool = True,
+              workspace_limit: int = 32 << 30) -> dict:
+    """Which kernels ``lgnn_kfac_accumulate`` would run for a model of this shape (host-only query, no GPU work):
+    per backward step l = L-1 .. 1 whether the fused SpMM^T -> Gram kernel and the compacted backward GEMM are used,
+    whether the second plane buffer is needed and how many class planes fit one chunk of the workspace."""
+    lib = _lib.load()
+    L = len(dims) - 1
+    out = (C.c_int64 * (4 + L))()
+    rc = lib.lgnn_kfac_plan(KINDS[kind], L, (C.c_int64 * (L + 1))(*dims), int(num_nodes), int(nnz), ACTS[act],
+                            0 if fuse else _lib.FLAG_NO_FUSE, int(workspace_limit), out)
+    _lib.check(rc, "lgnn_kfac_plan")
+    return {"seeds_on_the_fly": bool(out[0]), "sage_compact": bool(out[1]), "need_pong": bool(out[2]),
+            "classes_per_chunk": int(out[3]), "fused": [bool(out[4 + l] & 1) for l in range(L)],
+            "backgemm": [bool(out[4 + l] & 2) for l in range(L)]}
+
+
 class GraphEngine:
     """Graph ingest + model binding + per-batch curvature accumulation on one GPU."""
 
@@ -187,6 +203,12 @@ class GraphEngine:
 
     def set_workspace_limit(self, nbytes: int):
         _lib.check(self.lib.lgnn_set_workspace_limit(self._h, int(nbytes)), "lgnn_set_workspace_limit")
+        self._ws_limit = int(nbytes)
+
+    def kfac_plan(self, fuse: bool = True) -> dict:
+        """The kernel choices a KFAC accumulate on the bound model makes (see ``kfac_plan``)."""
+        return kfac_plan(self.kind, self.dims, self.num_nodes, self.nnz, self._bind_opts[0], fuse,
+                         getattr(self, "_ws_limit", 32 << 30))
 
     # -- forward --------------------------------------------------------------------------------
     def forward(self, idx: torch.Tensor) -> torch.Tensor:
@@ -237,10 +259,11 @@ class GraphEngine:
         _lib.check(rc, "lgnn_kfac_accumulate_classes")
 
     def diag_accumulate(self, idx, y, diag: torch.Tensor, loss: torch.Tensor):
+        """diag += diagonal GGN of the batch, loss += raw loss sum (CE, or the MSE sum for a regression binding)."""
         self._sync_versions()
-        idx, y = idx.contiguous(), y.contiguous()
+        idx = idx.contiguous()
         rc = self.lib.lgnn_diag_accumulate(
-            self._h, _dev_ptr(idx, torch.int64, "idx"), _dev_ptr(y, torch.int64, "y"), idx.shape[0], 0,
+            self._h, _dev_ptr(idx, torch.int64, "idx"), self._labels(y, idx.shape[0]), idx.shape[0], 0,
             _dev_ptr(diag, torch.float32, "diag"), loss.data_ptr(), _stream(self.device))
         _lib.check(rc, "lgnn_diag_accumulate")
 

@@ -43,6 +43,17 @@ def all_reduce_flat_(tensors: list[torch.Tensor], process_group=None):
     rank, world = _dist_info(process_group)
     if world == 1:
         return
+    big = [t for t in tensors if t.numel() >= (1 << 24)]
+    if len(tensors) == 1 or big:
+        # a large contiguous tensor (the 2.3 GB last-layer H at the products shape) is reduced where it lives --
+        # no second buffer, no copy back; the small rest (loss scalars) still travels as one flat message
+        for t in big if big else tensors:
+            if not t.is_contiguous():
+                raise ValueError("all_reduce_flat_ needs contiguous tensors")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
+        tensors = [t for t in tensors if t.numel() < (1 << 24)] if big else []
+        if not tensors:
+            return
     flat = torch.cat([t.reshape(-1) for t in tensors])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
     off = 0
@@ -137,6 +148,11 @@ class ParametricLaplace(BaseLaplace):
         setattr(self.model, "output_size", self.n_outputs)
         N = len(train_loader.dataset)
         rank, world = _dist_info(process_group)
+        # override=False inside a distributed job: self.H already holds the previous fits' ALL-REDUCED curvature; it must
+        # not take part in this fit's all-reduce (it would be counted once per rank): accumulate into a fresh buffer
+        H_prev = None
+        if not override and world > 1 and torch.is_tensor(getattr(self, "H", None)):
+            H_prev, self.H = self.H, torch.zeros_like(self.H)
         loss = torch.zeros((), dtype=torch.float32, device=self._device)
         plan = self._shard_plan(train_loader, rank, world)
         for t, (X, y) in enumerate(train_loader):
@@ -159,6 +175,9 @@ class ParametricLaplace(BaseLaplace):
         if world > 1:
             all_reduce_flat_(self._reduce_tensors() + [loss], process_group)
             self._after_reduce()
+        if H_prev is not None:
+            H_prev += self.H
+            self.H = H_prev
         self.loss = self.loss + loss
         self.n_data += N
 

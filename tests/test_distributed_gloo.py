@@ -95,6 +95,72 @@ def test_multi_rank_fit_equals_single_process(tmp_path, world, class_units, stru
             assert err < RTOL, (r, i, err)
 
 
+def _worker_override(rank, world, port, name, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import laplace_gnn_amd as lg
+    from oracle_backend import OracleBackend
+    from test_host_logic import _cpu_model
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = _cpu_model(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"]),
+                                  int(g["batch_size"]))
+    out = {}
+    for key, (sub, struct) in {"diag": ("all", "diag"), "ll": ("last_layer", "full"), "full": ("all", "full"),
+                               "kron": ("all", "kron")}.items():
+        la = lg.Laplace(model, "classification", sub, struct, backend=OracleBackend)
+        la.fit(loader)
+        la.fit(loader, override=False)
+        la.fit(loader, override=False)
+        H = la.H_facs.to_matrix() if key == "kron" else la.H
+        out[key], out[key + "_loss"], out[key + "_n"] = H.numpy(), float(la.loss), la.n_data
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_override_false_in_a_distributed_job_counts_earlier_fits_once(tmp_path):
+    """fit; fit(override=False) x 2 at world 2: the earlier, already all-reduced curvature must not go through
+    the all-reduce again (it would be multiplied by the world size).  diag / last-layer full / full: H == 3 x the
+    single fit's H (tests/test_baselaplace.py:408-426 pattern); kron: equal to the single-process sequence."""
+    name = "sage_small_3batch_s1"
+    port = _free_port()
+    mp.spawn(_worker_override, args=(2, port, name, str(tmp_path)), nprocs=2, join=True)
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import laplace_gnn_amd as lg
+    from oracle_backend import OracleBackend
+    from test_host_logic import _cpu_model
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = _cpu_model(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"]),
+                                  int(g["batch_size"]))
+    for key, (sub, struct) in {"diag": ("all", "diag"), "ll": ("last_layer", "full"), "full": ("all", "full"),
+                               "kron": ("all", "kron")}.items():
+        la = lg.Laplace(model, "classification", sub, struct, backend=OracleBackend)
+        la.fit(loader)
+        H1, loss1 = (None if key == "kron" else la.H.clone()), float(la.loss)
+        la.fit(loader, override=False)
+        la.fit(loader, override=False)
+        ref = la.H_facs.to_matrix().numpy() if key == "kron" else la.H.numpy()
+        if key != "kron":
+            assert np.allclose(ref, 3 * H1.numpy(), rtol=1e-5, atol=1e-6 * np.abs(ref).max())
+        for r in range(2):
+            out = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+            err = np.linalg.norm(out[key].astype(np.float64) - ref) / np.linalg.norm(ref)
+            assert err < 1e-5, (key, r, err)
+            assert abs(float(out[key + "_loss"]) - 3 * loss1) < 1e-5 * abs(3 * loss1)
+            assert int(out[key + "_n"]) == 3 * len(loader.dataset)
+
+
 def test_all_reduce_flat_single_process_is_noop():
     import laplace_gnn_amd as lg
 

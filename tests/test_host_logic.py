@@ -53,6 +53,33 @@ def test_header_cites_reference_for_every_compute_entry_point():
         assert needle in text, needle
 
 
+def test_kfac_plan_decisions_without_a_gpu():
+    """lgnn_kfac_plan is a host-only query: the kernel choices of the KFAC path per shape, incl. the 4 GiB plane bound of
+    the 256-wide fused kernel (a products-shaped GraphSAGE plane is 5 GB: SpMM + Gram through HBM, pong planes needed)
+    -- decided without allocating anything."""
+    from laplace_gnn_amd.engine import kfac_plan
+
+    arxiv = kfac_plan("gcn", [128, 256, 40], 169_343, 2_500_000)
+    assert arxiv == {"seeds_on_the_fly": True, "sage_compact": False, "need_pong": False, "classes_per_chunk": 40,
+                     "fused": [False, True], "backgemm": [False, True]}
+    assert kfac_plan("gcn", [128, 256, 40], 169_343, 2_500_000, fuse=False)["need_pong"]
+    sage = kfac_plan("sage", [128, 256, 40], 169_343, 2_500_000)
+    assert sage["sage_compact"] and sage["fused"] == [False, True] and not sage["need_pong"]
+    prod = kfac_plan("sage", [100, 256, 256, 47], 2_449_029, 123_000_000)
+    assert prod["fused"] == [False, False, False] and prod["need_pong"] and not prod["sage_compact"]
+    assert 1 <= prod["classes_per_chunk"] < 47  # 2 x 5 GB per class plane pair under the 32 GiB default cap
+    # the same widths on a graph whose planes stay below 4 GiB are fused
+    mid = kfac_plan("sage", [100, 256, 256, 47], 1_000_000, 50_000_000)
+    assert mid["fused"] == [False, True, True] and mid["sage_compact"]
+    # 128-wide planes use 64-bit addressing: no size bound
+    assert kfac_plan("sage", [100, 128, 47], 9_000_000, 10_000_000)["fused"] == [False, True]
+    # width % 4 != 0 and C > 64 leave the fused / on-the-fly paths
+    odd = kfac_plan("gcn", [16, 30, 70], 1000, 5000)
+    assert odd["fused"] == [False, False] and odd["need_pong"] and not odd["seeds_on_the_fly"]
+    with pytest.raises(lg._lib.HipLibraryError):
+        kfac_plan("gcn", [4] * 11, 10, 10)  # more than 8 layers
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(lg._lib, "_lib", None)
     monkeypatch.setattr(lg._lib, "LIB_PATH", str(tmp_path / "nope.so"))
