@@ -26,6 +26,35 @@ from torch.nn import CrossEntropyLoss, MSELoss
 
 from .matrix import Kron
 
+_BRIDGED = {}
+
+
+def _kron_class():
+    """The container ``kron()`` returns.  Inside the reference's own front, ``ParametricLaplace.fit`` does
+    ``self.H += H_batch`` (laplace/baselaplace.py:852) and ``Kron.__add__`` insists on ITS class
+    (laplace/utils/matrix.py:85-86).  When that module is loaded in this process the returned object therefore is an
+    instance of both: this package's ``Kron`` (so this package's front keeps working) and the host application's --
+    ``backend=HipGGN`` is a drop-in without an adapter.  The host's ``__add__`` returns plain host ``Kron`` objects,
+    so everything downstream (``decompose``, ``logdet`` ...) is the host's own code."""
+    import sys
+
+    mod = sys.modules.get("laplace.utils.matrix")
+    host = getattr(mod, "Kron", None)
+    if host is None or host is Kron:
+        return Kron
+    if host not in _BRIDGED:
+        def _add(self, other):
+            # Python asks the subclass's reflected method first (``host_kron + bridged`` lands here with the host object
+            # as ``other``): sums that involve a host container are the host's (its own class comes back), sums with
+            # this package's plain container stay here.  Elementwise addition commutes, operand order is irrelevant.
+            if isinstance(other, host):
+                return host.__add__(other, self)
+            return Kron.__add__(self, other)
+
+        _BRIDGED[host] = type("Kron", (Kron, host), {
+            "__doc__": "laplace_gnn_amd.Kron that is also a laplace.utils.matrix.Kron", "__add__": _add, "__radd__": _add})
+    return _BRIDGED[host]
+
 
 class HipCurvatureInterface:
     def __init__(self, model: nn.Module, likelihood: str, last_layer: bool = False,
@@ -89,7 +118,7 @@ class HipCurvatureInterface:
         for A, B in views:
             kfacs.append([B * f2 if self.factor != 1.0 else B.clone(), A * f2 if self.factor != 1.0 else A.clone()])
             kfacs.append([B * self.factor if self.factor != 1.0 else B.clone()])
-        return Kron(kfacs)
+        return _kron_class()(kfacs)
 
     def kron(self, x: torch.Tensor, y: torch.Tensor, N: int, **kwargs: Any):
         if kwargs:

@@ -16,6 +16,15 @@ class CpuForwardGCN(torch.nn.Module):
         super().__init__()
         self.inner = model
         self.convs = model.convs
+        self._oracle_engine = None
+
+    @property
+    def engine(self):
+        """The CPU stand-in for the HIP engine (tests/oracle_engine.py): lets the real ``HipGGN`` class run here."""
+        if self._oracle_engine is None:
+            from oracle_engine import OracleEngine
+            self._oracle_engine = OracleEngine(self.inner)
+        return self._oracle_engine
 
     def oracle_model(self):
         m = self.inner

@@ -1,0 +1,92 @@
+"""TEST-ONLY stand-in for ``laplace_gnn_amd.engine.GraphEngine``: the same Python surface, CPU oracle arithmetic.
+
+It lets the REAL backend class (``laplace_gnn_amd.HipGGN``, unmodified) run without a GPU, so that its contract with a
+``Laplace`` front -- constructor kwargs, return types and conventions, fresh tensors -- can be exercised in the build
+container, including through the reference's own ``laplace.baselaplace`` classes (tests/test_reference_dropin.py).
+Never shipped, never the product path, never timed.
+"""
+import numpy as np
+import torch
+
+import gnn_laplace_oracle as O
+
+
+class OracleEngine:
+    def __init__(self, model):
+        """``model``: a laplace_gnn_amd.GCN / GraphSAGE living on the CPU."""
+        self.m = model
+        self.kind = model.kind
+        self.device = torch.device("cpu")
+        self.num_nodes = model.num_nodes
+        mult = 2 if self.kind == "sage" else 1
+        self.dims = [model.convs[0].lin.weight.shape[1] // mult] + [c.lin.weight.shape[0] for c in model.convs]
+        self.in_dims = [mult * d for d in self.dims[:-1]]
+        self.likelihood = "classification"
+        self.calls = []
+
+    @property
+    def n_params(self):
+        return sum(i * o + o for i, o in zip(self.in_dims, self.dims[1:]))
+
+    @property
+    def num_layers(self):
+        return len(self.dims) - 1
+
+    def set_likelihood(self, likelihood):
+        self.likelihood = likelihood
+
+    def _om(self):
+        m = self.m
+        rp, col = O.edge_index_to_adj_csr(m.edge_index.numpy(), m.num_nodes, m.kind, m.symmetric)
+        return O.GnnModel(m.kind, rp, col, m.X.numpy(), [c.lin.weight.detach().numpy() for c in m.convs],
+                          [c.lin.bias.detach().numpy() for c in m.convs])
+
+    def forward(self, idx):
+        out, _, _ = O.forward_all(self._om())
+        return torch.from_numpy(out[idx.numpy()])
+
+    def new_kfac_buffers(self):
+        sizes = []
+        for i, o in zip(self.in_dims, self.dims[1:]):
+            sizes += [i * i, o * o]
+        flat = torch.zeros(sum(sizes) + 1)
+        views, off = [], 0
+        for i, o in zip(self.in_dims, self.dims[1:]):
+            A = flat[off:off + i * i].view(i, i); off += i * i
+            B = flat[off:off + o * o].view(o, o); off += o * o
+            views.append((A, B))
+        return flat, views, flat[off:off + 1]
+
+    def kfac_accumulate(self, idx, y, n_train, views, loss, fork_exact=True, fuse=True, classes=None):
+        """RAW factors (A_l / n_train, B_l) and the raw loss sum, as lgnn_kfac_accumulate adds them."""
+        self.calls.append(("kfac", tuple(idx.tolist()), classes))
+        reg = self.likelihood == "regression"
+        l, kfacs = O.kfac_batch(self._om(), idx.numpy(), y.numpy(), n_train, fork_exact, classes, self.likelihood)
+        undo2, undo1 = (1.0 / np.sqrt(0.5), 2.0) if reg else (1.0, 1.0)  # the oracle applied the interface factor 0.5
+        for k, (A, B) in enumerate(views):
+            B += torch.from_numpy(np.ascontiguousarray(kfacs[2 * k][0])) * undo2
+            A += torch.from_numpy(np.ascontiguousarray(kfacs[2 * k][1])) * undo2
+        loss += float(l) * undo1
+
+    def diag_accumulate(self, idx, y, diag, loss):
+        self.calls.append(("diag", tuple(idx.tolist())))
+        l, H = O.diag_batch(self._om(), idx.numpy(), y.numpy(), self.likelihood)
+        diag += torch.from_numpy(H)
+        loss += float(l) * (2.0 if self.likelihood == "regression" else 1.0)
+
+    def lastlayer_full_accumulate(self, idx, y, H, loss):
+        self.calls.append(("ll_full", tuple(idx.tolist())))
+        l, Hb = O.lastlayer_full_batch(self._om(), idx.numpy(), y.numpy())
+        H += torch.from_numpy(Hb)
+        loss += float(l)
+
+    def jacobians(self, idx):
+        self.calls.append(("jacobians", tuple(idx.tolist())))
+        Js, f = O.jacobians_batch(self._om(), idx.numpy())
+        return torch.from_numpy(Js), torch.from_numpy(f)
+
+    def check_async_errors(self):
+        pass
+
+    def invalidate(self):
+        pass

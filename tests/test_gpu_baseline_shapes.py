@@ -234,11 +234,18 @@ def test_products_shape_lastlayer_full_properties(products):
         lam = (p[:, c] if c == c2 else 0) - p[:, c] * p[:, c2]
         blk = phi.T @ (lam[:, None] * phi)
         assert rel(H[c * D:(c + 1) * D, c2 * D:(c2 + 1) * D].cpu().numpy(), blk.cpu().numpy()) < RTOL, (c, c2)
-    # positive semi-definite: Cholesky of H + eps I in fp64 succeeds
+    # positive semi-definite up to fp32 rounding: lambda_min >= -1e-5 lambda_max, i.e. the Cholesky factorisation of
+    # H + 1e-5 lambda_max I succeeds in fp64 (H has an exact null space of dimension D + 1: Lambda_n 1 = 0, so the
+    # shift has to be relative to the spectrum's top, found by power iteration, not to the diagonal)
     Hd = H.double()
-    Hd.diagonal().add_(1e-6 * float(hd.double().mean()))
+    v = torch.ones(P, 1, device="cuda", dtype=torch.float64)
+    for _ in range(30):
+        v = Hd @ v
+        lam_max = float(torch.linalg.norm(v))
+        v /= lam_max
+    Hd.diagonal().add_(1e-5 * lam_max)
     _, info = torch.linalg.cholesky_ex(Hd)
-    assert int(info) == 0
+    assert int(info) == 0, (int(info), lam_max)
     del Hd
     # a second call adds the same again (accumulate semantics; the mirror pass must not double the lower triangle)
     Hs = H[:2000, :2000].clone()
