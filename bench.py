@@ -1,38 +1,41 @@
 #!/usr/bin/env python3
-"""la.fit() throughput of the KFAC curvature path on MI355X (BASELINE.json metric).
+"""la.fit() throughput of the curvature path on MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[2], SURVEY.md 8(d) "C3"): 2-layer GCN on a synthetic
-ogbn-arxiv-shaped graph -- N = 169 343 nodes, 1 166 243 undirected random edges (symmetrised,
-self loops added), F = 128, H = 256, C = 40, N_train = 90 941 in 10 mini-batches of 10 000
-(reference loader: batch_size=10000, shuffle=False), hessian_structure="kron".
-A *step* is one complete ``la.fit(loader)``: forward + A-factor Grams (recomputed every step: the
-engine's cache is invalidated first), the 10 per-batch KFAC accumulations, the factor all-reduce
-(N > 1) and the eigendecomposition ``fit`` ends with.  value = steps * N_train / wall.
+Default workload (BASELINE.json configs[2], SURVEY.md 8(d) "C3"): 2-layer GCN on a synthetic ogbn-arxiv-shaped
+graph -- N = 169 343 nodes, 1 166 243 undirected random edges (symmetrised, self loops added), F = 128, H = 256,
+C = 40, N_train = 90 941 in 10 mini-batches of 10 000 (reference loader: batch_size=10000, shuffle=False),
+hessian_structure="kron".  Other workloads: ``--workload cora`` (configs[1], diag), ``--workload products``
+(configs[4], last-layer full GGN), ``arxiv_sage`` / ``arxiv_powerlaw`` (not BASELINE configs).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+A *step* is one complete ``la.fit(loader)``: forward + A-factor Grams (recomputed every step: the engine's cache is
+invalidated first), the per-batch accumulations, the factor all-reduce (N > 1) and, for kron, the eigendecomposition
+``fit`` ends with.  value = steps * N_train / wall.  Besides the wall of the K steps the line carries per-step medians
+from device events: ``ms_per_step_median`` (fit total) and ``accumulate_ms`` (the batch loop only: no all-reduce, no
+decomposition), SURVEY.md 8(d).
+
+    python bench.py --gpus N --steps K --warmup W        # N > 1: launches its own ranks (torch.distributed.run)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, the graph / features / weights replicated.  A batch's SAMPLES are never
-split (B factors have cross-sample terms inside a batch), but B = sum over batches and class columns,
-so the 10 x 40 (batch, class) units are dealt in balanced runs of 400/N (laplace_gnn_amd.units_of_rank),
-one RCCL all-reduce sums the flat factor buffer, the eigendecomposition is dealt to the ranks and
-shared with a second all-reduce.  Total work is fixed => "strong" scaling; the forward pass and the
-per-batch seeds are replicated (Amdahl).
+N > 1: one process per GPU, the graph / features / weights replicated.  A batch's SAMPLES are never split for KFAC
+(B factors have cross-sample terms inside a batch), but B = sum over batches and class columns, so the 10 x 40
+(batch, class) units are dealt in balanced runs of 400/N (laplace_gnn_amd.units_of_rank) and one RCCL all-reduce sums
+the flat factor buffer; every rank then runs the one batched eigendecomposition on its bit-identical factors (no
+second collective).  diag / last-layer: every rank takes its slice of every batch's samples.  Total work is fixed =>
+"strong" scaling; the forward pass and the per-batch seeds are replicated (Amdahl).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 WORKLOADS = {
     # name: N, undirected edges, F, H, C, N_train, batch
@@ -46,6 +49,9 @@ WORKLOADS = {
     "products": dict(N=2_449_029, E=61_859_140, F=100, H=256, C=47, n_train=196_615, batch=10_000, layers=3,
                      kind="sage", powerlaw=0.5),
 }
+BASELINE_CONFIG = dict(arxiv=2, cora=1, products=4)
+DEFAULT_STRUCTURE = {"arxiv": "kron", "arxiv_sage": "kron", "arxiv_powerlaw": "kron", "cora": "diag",
+                     "products": "lastlayer"}
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
 
@@ -53,6 +59,8 @@ PEAK_HBM_GBS = 8000.0
 def make_workload(name: str, device, seed: int = 0):
     """Seeded synthetic inputs of the named shape; generated on the CPU generator so
     every rank (and the CPU baseline) sees identical data."""
+    import torch
+
     w = WORKLOADS[name]
     g = torch.Generator().manual_seed(seed)
     if "powerlaw" in w:
@@ -74,39 +82,92 @@ def make_workload(name: str, device, seed: int = 0):
     return w, ei, X, train_idx, train_y
 
 
-def cpu_baseline(name: str, ei, X, Ws, bs, train_idx, train_y, w, structure="kron"):
-    """Oracle (CPU restatement, numpy + scipy) timed on the host cores on a bounded sample:
-    the first mini-batch of the same workload, forward and A factors included (the reference
-    recomputes them per batch)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import gnn_laplace_oracle as O
-
+def _threads():
     try:
         from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        return max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
-        cores = os.cpu_count() or 1
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(name: str, ei, X, Ws, bs, train_idx, train_y, w, structure, model=None):
+    """Oracle (CPU restatement, numpy + scipy; oracle/gnn_laplace_oracle.py, kind "port") timed on the host cores on
+    a BOUNDED sample of the same workload.  Dense GEMMs run on all BLAS threads; scipy's CSR products are single
+    threaded (said in ``sample``).  The reference itself cannot execute the arxiv / products shapes (dense N x N
+    adjacency: 115 GB / 24 TB); for the Cora shape ``cpu_baseline_dense`` times the reference-faithful dense mode."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gnn_laplace_oracle as O
+    import numpy as np
+
+    cores = int(_threads())
     kind = w.get("kind", "gcn")
+    M = min(w["batch"], w["n_train"])
+    if structure == "lastlayer":
+        # the forward pass (3 sparse layers over 2.4 M nodes) is NOT part of the sample: features and logits of the
+        # sampled batch nodes come from the GPU forward; timed = the reference-style Jacobian einsum of 48 samples
+        ms = 48
+        eng = model.engine
+        idx = train_idx[:ms].to(eng.device)
+        f = eng.forward(idx).cpu().numpy()
+        d = eng.in_dims[-1]
+        rng = np.random.default_rng(0)
+        phi = rng.standard_normal((ms, d)).astype(np.float32)  # same shape / arithmetic; values do not change the cost
+        t0 = time.perf_counter()
+        O.lastlayer_full_from_features(phi, np.ones(ms, np.float32), f)
+        dt = time.perf_counter() - t0
+        return {"value": ms / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+                "sample": f"{ms} samples of the first mini-batch, last-layer Jacobian einsum only (P = {d * w['C'] + w['C']}; "
+                          f"the 3-layer forward over {w['N']} nodes excluded, which favours the CPU), "
+                          f"oracle.lastlayer_full_from_features, {dt:.1f} s"}
     rp, col = O.edge_index_to_adj_csr(ei.numpy(), w["N"], kind, True)
     om = O.GnnModel(kind, rp, col, X.numpy(), Ws, bs)
-    M = min(w["batch"], w["n_train"])
-    t0 = time.perf_counter()
     if structure == "kron":
+        t0 = time.perf_counter()
         O.kfac_batch(om, train_idx[:M].numpy(), train_y[:M].numpy(), w["n_train"])
+        dt = time.perf_counter() - t0
+        what, ms = "kfac_batch", M
     else:
-        O.diag_batch(om, train_idx[:M].numpy(), train_y[:M].numpy())
-    dt = time.perf_counter() - t0
+        ms = min(M, 256)  # 30 ms of python per sample: bounded to ~10 s
+        t0 = time.perf_counter()
+        O.diag_batch(om, train_idx[:ms].numpy(), train_y[:ms].numpy())
+        dt = time.perf_counter() - t0
+        what = "diag_batch"
     return {
-        "value": M / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
-        "sample": f"first mini-batch ({M} of {w['n_train']} samples) of the same {name}-shaped {structure} fit, "
-                  f"oracle/gnn_laplace_oracle.{'kfac' if structure == 'kron' else 'diag'}_batch, {dt:.1f} s",
+        "value": ms / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+        "sample": f"{ms} of the {w['n_train']} samples (first mini-batch) of the same {name}-shaped {structure} fit, forward "
+                  f"and A factors included (the reference recomputes them per batch), oracle/gnn_laplace_oracle.{what} "
+                  f"(sparse restatement: dense GEMMs on {cores} BLAS threads, scipy CSR products single threaded), {dt:.1f} s",
     }
 
 
-def main():
+def cpu_baseline_dense(ei, X, Ws, bs, train_idx, train_y, w, structure):
+    """Reference-faithful dense mode for the Cora shape: dense N x N adjacency, normalize_adj as two
+    dense N^3 products on every forward, three forwards per batch, dense backward passes -- comparable with the
+    reference's own 8-vCPU measurement in BASELINE.md (~0.5 k samples/s kron, ~30 samples/s diag)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gnn_laplace_oracle as O
+
+    rp, col = O.edge_index_to_adj_csr(ei.numpy(), w["N"], "gcn", True)
+    om = O.GnnModel("gcn", rp, col, X.numpy(), Ws, bs)
+    M = min(w["batch"], w["n_train"])
+    if structure == "kron":
+        ms = M
+        t0 = time.perf_counter()
+        O.dense_mode_kron_batch(om, train_idx[:ms].numpy(), train_y[:ms].numpy(), w["n_train"])
+    else:
+        ms = min(M, 128)
+        t0 = time.perf_counter()
+        O.dense_mode_diag_batch(om, train_idx[:ms].numpy(), train_y[:ms].numpy())
+    dt = time.perf_counter() - t0
+    return {"value": ms / dt, "unit": "samples/s", "cores": int(_threads()), "kind": "port",
+            "sample": f"{ms} of {w['n_train']} samples, reference-faithful DENSE mode (dense adjacency, per-forward "
+                      f"normalize_adj, 3 forwards, dense backward passes), oracle.dense_mode_{structure}_batch, {dt:.1f} s"}
+
+
+def _parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="arxiv", choices=sorted(WORKLOADS))
     ap.add_argument("--structure", default=None, choices=["kron", "diag", "lastlayer"],
@@ -116,14 +177,74 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="dev aid, 1 GPU: time only the share rank 0 of an N-rank job would execute (no all-reduce); "
                          "prints the per-rank time, not a valid bench line")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def _launch_ranks(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this same file under torch.distributed.run
+    as a CHILD process (this parent never touches the GPU), relay rank 0's JSON line, return the child's code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for line in proc.stdout:
+        if line.lstrip().startswith("{"):
+            lines.append(line.rstrip("\n"))
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc != 0:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank child exited with code {rc}\n")
+        return rc
+    if not lines:
+        sys.stderr.write("bench.py: the ranks produced no JSON line\n")
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return None if n == 0 else (xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2]))
+
+
+def _pmc_traffic(workload, structure, units_per_launch):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass of this same command
+    (counters cannot be collected inside the timed run); null when no summary for this workload is committed."""
+    names = ["r02_arxiv_pmc_fused.json", "r01_h_pmc_fused.json"] if (workload, structure) == ("arxiv", "kron") \
+        else [f"r02_{workload}_pmc_dominant.json"]
+    if structure != DEFAULT_STRUCTURE[workload]:
+        names = []
+    for name in names:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as fh:
+                pj = json.load(fh)
+            per = pj.get("planes_per_launch") or pj.get("units_per_launch") or units_per_launch
+            return pj["traffic_bytes_per_launch"] * units_per_launch / per, f"profiles/{name} ((2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction)"
+    return None, None
+
+
+def main():
+    args = _parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        sys.exit(_launch_ranks(args))  # before anything touches the GPU
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     # one rank per GPU; LGNN_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 code path on a
     # 1-GPU box: RCCL refuses two ranks on the same device)
@@ -144,22 +265,31 @@ def main():
     cls = lg.GraphSAGE if w.get("kind") == "sage" else lg.GCN
     model = cls(w["F"], w["H"], w["C"], w.get("layers", 2), X, ei, symmetric=True).to(dev)
     loader = lg.TensorBatchLoader(train_idx.to(dev), train_y.to(dev), batch_size=w["batch"])
-    structure = args.structure or {"arxiv": "kron", "arxiv_sage": "kron", "arxiv_powerlaw": "kron", "cora": "diag",
-                                   "products": "lastlayer"}[args.workload]
+    structure = args.structure or DEFAULT_STRUCTURE[args.workload]
     if structure == "lastlayer":
         la = lg.Laplace(model, "classification", subset_of_weights="last_layer", hessian_structure="full")
     else:
         la = lg.Laplace(model, "classification", subset_of_weights="all", hessian_structure=structure)
     eng = model.engine
-    nnz, N, H, C = eng.nnz, w["N"], w["H"], w["C"]
+    nnz, N, F, H, C = eng.nnz, w["N"], w["F"], w["H"], w["C"]
 
     if args.emulate_world > 1:
         plan = la._shard_plan
         la._shard_plan = lambda tl, r, w_: plan(tl, 0, args.emulate_world)  # rank 0's share of an N-rank job
 
-    def step():
+    ev = []  # (start, accumulated, end) device events per timed step, on torch's current stream = the launch stream
+
+    def step(timed=False):
         eng.invalidate()  # a fresh fit: forward + input Grams are recomputed, nothing carried over
+        if timed:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+            la._on_accumulated = e[1].record
         la.fit(loader)
+        if timed:
+            e[2].record()
+            la._on_accumulated = None
+            ev.append(e)
 
     def sync():
         if world > 1:
@@ -172,69 +302,105 @@ def main():
     eng.enable_kernel_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     sync()
     elapsed = time.perf_counter() - t0
-    launches, kern_ms, planes = eng.kernel_timing()
+    launches, kern_ms, units = eng.kernel_timing()
     eng.enable_kernel_timing(False)
+    step_ms = [e[0].elapsed_time(e[2]) for e in ev]
+    acc_ms = [e[0].elapsed_time(e[1]) for e in ev]
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, _median(step_ms), _median(acc_ms)], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, step_med, acc_med = (float(v) for v in t.tolist())
+    else:
+        step_med, acc_med = _median(step_ms), _median(acc_ms)
 
     if rank == 0:
         value = args.steps * w["n_train"] / elapsed
-        # dominant kernel: fused SpMM^T -> Gram of layer 0.  ALGORITHMIC flops per class plane:
-        # SpMM 2*nnz*H + Gram 2*N*H^2 (no credit for symmetry); bytes per plane (fused, nothing written):
-        # nnz*8 + (N+1)*4 + N*H*4.  The MFMA floor is the higher one => "mfma" bound.
-        flops_plane = 2.0 * nnz * H + 2.0 * N * H * H
-        bytes_plane = nnz * 8.0 + (N + 1) * 4.0 + N * H * 4.0
         roofline = None
         if launches > 0 and kern_ms > 0:
             avg_ms = kern_ms / launches
-            ach = flops_plane * planes / (kern_ms * 1e-3) / 1e12
-            # HBM-side bytes per launch come from a separate rocprofv3 --pmc pass of this same command
-            # (counters cannot be collected inside the timed run); the committed summary is quoted when
-            # it matches this workload, otherwise null.
-            traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_h_pmc_fused.json")
-            if args.workload == "arxiv" and structure == "kron" and os.path.exists(pmc):
-                with open(pmc) as fh:
-                    pj = json.load(fh)
-                traffic = pj["traffic_bytes_per_launch"] * (planes / launches) / pj["planes_per_launch"]
-                traffic_src = "profiles/r01_h_pmc_fused.json ((2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction)"
-            roofline = {
-                "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": bytes_plane * planes / launches,
-                "kernel": "spmm_gram256_kernel", "launches": launches, "avg_launch_ms": avg_ms,
-                "planes_per_launch": planes / launches,
-                "algorithmic_GBps": bytes_plane * planes / (kern_ms * 1e-3) / 1e9,
-                "kernel_share_of_wall": kern_ms * 1e-3 / elapsed,
-            }
+            upl = units / launches
+            traffic, traffic_src = _pmc_traffic(args.workload, structure, upl)
+            common = {"traffic": traffic, "traffic_source": traffic_src, "launches": launches, "avg_launch_ms": avg_ms,
+                      "kernel_share_of_wall": kern_ms * 1e-3 / elapsed}
+            if structure == "kron":
+                # dominant kernel: fused SpMM^T -> Gram of layer 0.  ALGORITHMIC flops per class plane:
+                # SpMM 2*nnz*H + Gram 2*N*H^2 (no credit for symmetry); bytes per plane (fused, nothing written):
+                # nnz*8 + (N+1)*4 + N*H*4.  The MFMA floor is the higher one => "mfma" bound.
+                flops = (2.0 * nnz * H + 2.0 * N * H * H) * units
+                bytes_ = (nnz * 8.0 + (N + 1) * 4.0 + N * H * 4.0) * units
+                ach = flops / (kern_ms * 1e-3) / 1e12
+                roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / PEAK_MFMA_F32_TFLOPS, **common,
+                            "kernel": "spmm_gram256_kernel" if H > 128 else "spmm_gram_kernel",
+                            "planes_per_launch": upl, "algorithmic_bytes_per_launch": bytes_ / launches,
+                            "algorithmic_GBps": bytes_ / (kern_ms * 1e-3) / 1e9,
+                            "executed_frac_of_peak": ach / PEAK_MFMA_F32_TFLOPS * 36.0 / 64.0 if H > 128 else None,
+                            "note": "the kernel executes the 36 of 64 symmetric 32x32 sub-tiles of the Gram; 'achieved' "
+                                    "credits the full 2*N*H^2 as SURVEY.md 8(d) prescribes"}
+            elif structure == "diag":
+                # dominant kernel: diag_first_layer_kernel, one launch per batch.  ALGORITHMIC bytes per launch
+                # (SURVEY.md 8(d) "Diag (C2)"): N*F*4 + nnz*8 + 2*P*4; flops 2*M*dbar*H*(F+1).  HBM bound by that count
+                # (in practice latency bound: ~16 MB per launch).
+                P = eng.n_params
+                bytes_l = N * F * 4.0 + nnz * 8.0 + 2.0 * P * 4.0
+                ach = bytes_l * launches / (kern_ms * 1e-3) / 1e9
+                roofline = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": ach / PEAK_HBM_GBS, **common, "kernel": "diag_first_layer_kernel",
+                            "samples_per_launch": upl, "algorithmic_bytes_per_launch": bytes_l,
+                            "algorithmic_TFLOPs": 2.0 * units * (nnz / N) * H * (F + 1) / (kern_ms * 1e-3) / 1e12}
+            else:
+                # dominant kernel: batched weighted Gram (gram_mem_kernel<128>, one launch per chunk of class pairs).
+                # ALGORITHMIC flops per batch (SURVEY.md 8(d) "LL full"): 2*M*C^2*(D+1)^2, no credit for symmetry;
+                # executed: C(C+1)/2 pair Grams on their upper 128x128 tile pairs, 2*M*D^2 * (ntile+1)/(2*ntile) each.
+                D = eng.in_dims[-1]
+                nb = len(loader)
+                samples = args.steps * w["n_train"] // max(world, 1) if world > 1 else args.steps * w["n_train"]
+                flops = 2.0 * samples * C * C * (D + 1.0) ** 2
+                nt = -(-D // 128)
+                executed = 2.0 * samples * D * D * (nt + 1) / (2.0 * nt) * (C * (C + 1) / 2)
+                ach = flops / (kern_ms * 1e-3) / 1e12
+                exe = executed / (kern_ms * 1e-3) / 1e12
+                roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / PEAK_MFMA_F32_TFLOPS, **common, "kernel": "gram_mem_kernel<128> (batched, weighted)",
+                            "class_pairs_per_launch": upl, "executed_TFLOPs": exe,
+                            "executed_frac_of_peak": exe / PEAK_MFMA_F32_TFLOPS,
+                            "algorithmic_bytes_per_launch": (w["batch"] * (D + 1 + C) * 4.0) + upl * D * D * 4.0,
+                            "note": "'achieved' credits 2*M*C^2*(D+1)^2 per batch as SURVEY.md 8(d) prescribes; the kernel "
+                                    "executes only the pairs c <= c' and the upper tiles of each block (about a quarter), "
+                                    "so frac can exceed 1 -- executed_frac_of_peak is the matrix-pipe utilisation"}
+        gname = "GraphSAGE" if w.get("kind") == "sage" else "GCN"
         out = {
-            "metric": {"kron": f"la.fit() samples/sec ({'GraphSAGE' if w.get('kind') == 'sage' else 'GCN'}, KFAC)",
-                       "diag": "la.fit() samples/sec (GCN, diag GGN)",
-                       "lastlayer": "la.fit() samples/sec (GraphSAGE, last-layer full GGN)"}[structure],
+            "metric": {"kron": f"la.fit() samples/sec ({gname}, KFAC)",
+                       "diag": f"la.fit() samples/sec ({gname}, diag GGN)",
+                       "lastlayer": f"la.fit() samples/sec ({gname}, last-layer full GGN)"}[structure],
             "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step_median": step_med, "accumulate_ms": acc_med,
             "config": {
                 "workload": f"{args.workload}-shaped {w.get('layers', 2)}-layer {w.get('kind', 'gcn').upper()}, "
                             f"hessian_structure={structure} "
-                            + (f"(BASELINE configs[{dict(arxiv=2, cora=1, products=4)[args.workload]}])"
-                               if args.workload in ("arxiv", "cora", "products") else "(not a BASELINE config)"),
-                "num_nodes": N, "nnz": nnz, "features": w["F"], "hidden": H, "classes": C,
+                            + (f"(BASELINE configs[{BASELINE_CONFIG[args.workload]}])"
+                               if args.workload in BASELINE_CONFIG and structure == DEFAULT_STRUCTURE[args.workload]
+                               else "(not a BASELINE config)"),
+                "num_nodes": N, "nnz": nnz, "features": F, "hidden": H, "classes": C,
                 "n_train": w["n_train"], "batch_size": w["batch"],
-                "batches": len(loader), "parallelism": f"dp{world} ((batch, class) units, contiguous balanced runs)",
+                "batches": len(loader),
+                "parallelism": f"dp{world} (" + ("(batch, class) units, contiguous balanced runs" if structure == "kron"
+                                                  else "sample slices of every batch") + ")",
             },
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline and structure != "lastlayer":
+        if world == 1 and not args.no_cpu_baseline and not args.emulate_world:
             Ws = [c.lin.weight.detach().cpu().numpy() for c in model.convs]
             bs = [c.lin.bias.detach().cpu().numpy() for c in model.convs]
-            out["cpu_baseline"] = cpu_baseline(args.workload, ei, X, Ws, bs, train_idx, train_y, w, structure)
+            out["cpu_baseline"] = cpu_baseline(args.workload, ei, X, Ws, bs, train_idx, train_y, w, structure, model)
+            if args.workload == "cora":
+                out["cpu_baseline_dense"] = cpu_baseline_dense(ei, X, Ws, bs, train_idx, train_y, w, structure)
         else:
             out["cpu_baseline"] = None
         if args.emulate_world > 1:

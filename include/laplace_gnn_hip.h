@@ -164,11 +164,12 @@ LGNN_API int lgnn_lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, con
 LGNN_API int lgnn_check_async_errors(lgnn_ctx* h, void* stream);
 
 /* ---- timing hook (bench.py roofline) -----------------------------------------------------------
- * While enabled, every launch of the dominant kernel of the KFAC path (the fused SpMM^T -> Gram
- * kernel of the lowest layer) is bracketed by HIP events recorded on `stream` itself
- * (torch.cuda.Event only sees torch's current stream).  lgnn_kernel_timing_read synchronises on
- * the recorded events and returns the number of launches, their summed duration in ms and the
- * summed number of class planes they processed; enabling resets the counters.                    */
+ * While enabled, every launch of the dominant kernel of the path in use -- KFAC: the fused SpMM^T -> Gram kernel of
+ * the lowest layer; diagonal GGN: the first-layer kernel; last-layer full GGN: the batched weighted Gram -- is
+ * bracketed by HIP events recorded on `stream` itself (torch.cuda.Event only sees torch's current stream).
+ * lgnn_kernel_timing_read synchronises on the recorded events and returns the number of launches, their summed
+ * duration in ms and the summed number of units they processed (KFAC: class planes; diagonal: samples; last layer:
+ * class pairs); enabling resets the counters.                                                     */
 LGNN_API int lgnn_enable_kernel_timing(lgnn_ctx* h, int enable);
 LGNN_API int lgnn_kernel_timing_read(lgnn_ctx* h, int64_t* launches, double* total_ms, int64_t* planes);
 

@@ -319,9 +319,11 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
     FeatView E;
     feat_views(h, 0, E);
     const dim3 grid{unsigned(cdiv(E.width + 1, 64)), unsigned(cdiv(H, 64)), nslab};
+    if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the diagonal path (bench.py roofline)
     hipLaunchKernelGGL(diag_first_layer_kernel, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab,
                        E, h->fc.hact_p[0], h->fc.hact_ld[0], h->act, H, q, has_self, diag_out, diag_out + H * in0);
     LGNN_HIP_CHECK(hipGetLastError());
+    if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += M; }
     off = H * in0 + H;
   }
   {
@@ -372,7 +374,9 @@ int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, in
     LGNN_HIP_CHECK(hipGetLastError());
     LGNN_HIP_CHECK(hipMemsetAsync(S, 0, size_t(qc) * D * D * 4, s));
     // S[q] = sign_q * (diag(rs_q) Phi)^T (diag(rs_q) Phi) over the D feature columns
+    if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the last-layer path (bench.py roofline)
     LGNN_CALL(launch_gram_batched(PhiM, ldp, M, D, S, D * D, qc, rs, zsign, 1.0f, s));
+    if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += qc; }
     // bias column: Sb[q][j] = sum_m w_qm s_m phi~[m][j], one library GEMM [qc x M] * [M x D1]
     LGNN_CALL(ll_bias_gemm(wsg, PhiM, Sb, qc, M, D1, ldp, s));
     hipLaunchKernelGGL(ll_place_pairs_kernel, dim3(unsigned(std::min<int64_t>(cdiv(D1 * D1, 256), 1024)), unsigned(qc)),

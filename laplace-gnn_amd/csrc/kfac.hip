@@ -494,6 +494,8 @@ __global__ void scatter_seed_planes_kernel(const int64_t* __restrict__ idx, int6
   }
 }
 
+}  // namespace
+
 int record_event(lgnn_ctx* h, hipStream_t s) {
   if (h->ev_used >= h->ev.size()) {
     hipEvent_t e;
@@ -503,8 +505,6 @@ int record_event(lgnn_ctx* h, hipStream_t s) {
   LGNN_HIP_CHECK(hipEventRecord(h->ev[h->ev_used++], s));
   return 0;
 }
-
-}  // namespace
 
 // Every path decision of kfac_accumulate as a pure function of the shapes (base pointers come from hipMalloc and
 // are 256-byte aligned, so alignment follows from the widths).  One helper serves the launch loop, the workspace

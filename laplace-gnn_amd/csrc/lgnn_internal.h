@@ -254,6 +254,8 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
 int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bool want_seeds, bool fork_exact,
                    float* loss_out, hipStream_t s);
 int batch_epilogue(lgnn_ctx* h, const int64_t* idx, int64_t M, hipStream_t s);
+// timing hook (lgnn_enable_kernel_timing): one HIP event on the launch stream; callers bracket the dominant kernel
+int record_event(lgnn_ctx* h, hipStream_t s);
 // ---- forward.hip ------------------------------------------------------------------------
 int forward_ensure(lgnn_ctx* h, hipStream_t s);
 int forward_ensure_grams(lgnn_ctx* h, hipStream_t s);

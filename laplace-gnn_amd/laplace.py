@@ -170,6 +170,8 @@ class ParametricLaplace(BaseLaplace):
             loss = loss + loss_batch
             self._accumulate(H_batch)
         self._finish_accumulate()
+        if getattr(self, "_on_accumulated", None) is not None:
+            self._on_accumulated()  # measurement hook (bench.py): end of the accumulate loop, before reduce / decompose
         if hasattr(self.backend, "check_async_errors"):
             self.backend.check_async_errors()  # invalid node ids / labels are flagged on the device; one sync per fit
         if world > 1:
