@@ -227,6 +227,31 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
         out["fullla_glm_fvar"] = f_var.detach().numpy().astype(np.float32)
         out["fullla_glm_probit"] = lf(eval_idx, pred_type="glm", link_approx="probit").detach().numpy().astype(np.float32)
 
+    if kind == "gcn" and layers == 2:
+        # 8(f)-4: what the GNN driver differentiates (gnn/marglik_training.py:197-216): -log marglik of a KronLaplace fit
+        # w.r.t. the dense adjacency parameter of the STE model (gnn/models/models.py:65-118), same weights (same seed,
+        # same construction order), prior precision 0.7.  Stored: the gradient on the stored entries of the 0/1
+        # adjacency (row-major = adj_nz_row / adj_nz_col order) and on 200 random non-edges.
+        torch.manual_seed(seed)
+        ste = ns.gnn_models.STEGCN(f, h, c, layers, X, adj0.clone(), dropout_p=0.5, threshold=0.5, symmetric=symmetric)
+        ste.eval()
+        for a, b in zip(ste.convs, model.convs):
+            assert torch.equal(a.lin.weight, b.lin.weight) and torch.equal(a.lin.bias, b.lin.bias)
+        ls = bl.KronLaplace(ste, "classification", prior_precision=0.7)
+        ls.fit(loader)
+        neg = -ls.log_marginal_likelihood()
+        neg.backward()
+        gr = ste.adj.grad.detach().numpy()
+        out["adjgrad_prior"] = np.float64(0.7)
+        out["adjgrad_neg_marglik"] = np.float64(float(neg))
+        out["adjgrad_vals"] = gr[out["adj_nz_row"], out["adj_nz_col"]].astype(np.float32)
+        dense01 = np.zeros((n, n), dtype=bool)
+        dense01[out["adj_nz_row"], out["adj_nz_col"]] = True
+        ner, nec = np.nonzero(~dense01)
+        pick = np.random.default_rng(seed + 7).choice(len(ner), size=min(200, len(ner)), replace=False)
+        out["adjgrad_ne_row"], out["adjgrad_ne_col"] = ner[pick], nec[pick]
+        out["adjgrad_ne_val"] = gr[ner[pick], nec[pick]].astype(np.float32)
+
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
