@@ -180,6 +180,25 @@ LGNN_API int lgnn_kernel_timing_read(lgnn_ctx* h, int64_t* launches, double* tot
  * reference; the samples are processed in chunks that fit the workspace cap.                              */
 LGNN_API int lgnn_jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out, void* stream);
 
+/* ---- gradient of the negative log marginal likelihood w.r.t. the adjacency ("next" row 8(f)-4) --------------
+ * Replaces what autograd does for ``neg_marglik.backward()`` into ``model.adj`` (gnn/marglik_training.py:197-216):
+ * back through KronDecomposed.logdet / log_marginal_likelihood (laplace/utils/matrix.py:371-394,
+ * laplace/baselaplace.py:938-973), the KFAC accumulation the fork keeps attached to the graph (curvlinops/kfac.py:
+ * 637-661 non-detached square root + create_graph, :789-790, :836-837), the forward passes, normalize_adj
+ * (gnn/models/utils.py:106-112) and the straight-through binarisation (gnn/models/utils.py:42-86).  2-layer GCN,
+ * ReLU, classification.  The caller supplies gamma_B[l] = d(neg marglik)/dB_l, gamma_A[l] = d/dA_l (from the
+ * eigenpairs of the fitted factors; fp32 [out_l, out_l] / [in_l, in_l], symmetric).
+ *   per batch :  grad_P [nnz] += the terms of this batch on the stored entries of the propagation matrix (order of
+ *                lgnn_export_propagation);  out_bar [N, C] += d/d(all-node logits) of loss_scale * CE and of the seeds
+ *   once      :  adds the forward-pass terms (a_scale = batches / N_train: A_1 = a_scale * H1^T H1) to grad_P, then
+ *                grad_adj [nnz] = gradient w.r.t. the stored entries of the 0/1 adjacency, order of lgnn_export_adj
+ *                (diagonal 0: fill_diagonal_(1) overwrites it; symmetric models: average of (i,j) and (j,i)).     */
+LGNN_API int lgnn_kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags,
+                            const float* const* gamma_B /* host array of L device ptrs */, float loss_scale,
+                            float* grad_P, float* out_bar, void* stream);
+LGNN_API int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* const* gamma_A /* host array of L device ptrs */,
+                        float a_scale, float* grad_P, float* grad_adj, void* stream);
+
 /* ---- decomposition of the fitted factors ("next" row: KronLaplace.fit -> Kron.decompose) ----------
  * Replaces the per-factor torch.linalg.eigh calls of laplace/utils/matrix.py:118-145 (symeig,
  * laplace/utils/utils.py:193-226) by ONE strided-batched rocSOLVER syevd over all factors.

@@ -1,0 +1,467 @@
+// Gradient of the negative log marginal likelihood of a KronLaplace fit w.r.t. the adjacency ("next" row 8(f)-4).
+//
+// Reference: gnn/marglik_training.py:197-216 calls ``neg_marglik.backward()`` and steps an optimiser on ``model.adj``:
+// autograd walks back through log_marginal_likelihood (laplace/baselaplace.py:938-973), the eigendecomposed factors
+// (laplace/utils/matrix.py:118-145, 371-394), the KFAC accumulation that the fork keeps attached to the graph
+// (curvlinops/kfac.py:637-661 non-detached Hessian square root + create_graph=True, :789-790 / :836-837 clone instead
+// of detach), three dense full-graph forwards, normalize_adj (gnn/models/utils.py:106-112) and the straight-through
+// binarisation (gnn/models/utils.py:42-86, gnn/models/models.py:103-118).
+//
+// Here the same chain runs in reverse as explicit kernels on the stored sparsity pattern (2-layer GCN, ReLU):
+//   host (python):   Gamma_B_l = d(neg marglik)/dB_l, Gamma_A_l = d/dA_l from the eigenpairs of the fitted factors
+//   per batch:       seeds V, g1 = P^T scatter(V), u = mask * (g1 W1), g0 = P^T u               (kfac.hip's chain)
+//                    g0bar = 2 g0 Gamma_B0            gradP[(a,b)] += <u[a], g0bar[b]>             SDDMM, 256 wide
+//                    ubar  = mask * (P g0bar)         g1bar = ubar W1^T + 2 g1 Gamma_B1
+//                    gradP[(a,b)] += <G[a], g1bar[b]> (a in batch)      Vbar = (P g1bar)[batch]  SDDMM + row gather
+//                    fbar = dV/df . Vbar (the fork's attached square root) + softmax - onehot      outbar[batch] += fbar
+//   once per fit:    gradP += <outbar[a], Z1[b]>;  H1bar = (P^T outbar) W1 + 2 (T/N) H1 Gamma_A1
+//                    gradP += <(mask * H1bar)[a], Z0[b]>
+//                    normalize_adj backward: P[a,b] = d_a A[b,a] d_b, d = rowsum(A)^-1/2; diagonal -> 0 (overwritten
+//                    by fill_diagonal_(1) after the STE); symmetric models average (i,j) and (j,i)
+// The dense GEMMs with the (small) Gamma / weight matrices are plain library calls (rocBLAS).
+#include <rocblas/rocblas.h>
+
+#include "device_utils.h"
+#include "lgnn_internal.h"
+
+namespace lgnn {
+
+void* blas_handle(hipStream_t s);  // eigh.hip
+
+namespace {
+
+// out[p] += sum_planes <L_c[a, :], R_c[b, :]> for every stored entry p = (a, b) of the CSR, rows a from an optional list.
+// LPR lanes (a power of two >= width / 4, at most 64) share an entry; 64 / LPR entries are in flight per wave.
+template <int LPR>
+__global__ __launch_bounds__(256) void sddmm_planes_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                           int64_t nrows, const int32_t* __restrict__ rows,
+                                                           const int32_t* __restrict__ nrows_dev,
+                                                           const float* __restrict__ Lp, int64_t l_ld, int64_t l_stride,
+                                                           const float* __restrict__ Rp, int64_t r_ld, int64_t r_stride,
+                                                           int64_t width, int64_t nplanes, float* __restrict__ out) {
+  constexpr int EPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPR, sl = lane % LPR;
+  const int64_t total = rows ? int64_t(*nrows_dev) : nrows;
+  for (int64_t w = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); w < total; w += int64_t(gridDim.x) * 4) {
+    const int64_t a = rows ? rows[w] : w;
+    const int32_t s = rowptr[a], e = rowptr[a + 1];
+    for (int32_t p0 = s; p0 < e; p0 += EPW) {
+      const int32_t p = p0 + sub;
+      const bool ok = p < e;
+      const int64_t b = ok ? col[p] : 0;
+      float acc = 0.f;
+      for (int64_t c = 0; c < nplanes; ++c) {
+        const float* __restrict__ lrow = Lp + c * l_stride + a * l_ld;
+        const float* __restrict__ rrow = Rp + c * r_stride + b * r_ld;
+        for (int64_t k = sl; k < width; k += LPR) acc += ok ? lrow[k] * rrow[k] : 0.f;
+      }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      if (ok && sl == 0) out[p] += acc;  // one wave owns row a: a single writer per entry inside a launch
+    }
+  }
+}
+
+int launch_sddmm(const Csr& m, int64_t nrows, const int32_t* rows, const int32_t* nrows_dev, const float* L, int64_t l_ld,
+                 int64_t l_stride, const float* R, int64_t r_ld, int64_t r_stride, int64_t width, int64_t nplanes,
+                 float* out, hipStream_t s) {
+  if (nrows <= 0 || width <= 0 || nplanes <= 0) return 0;
+  const unsigned grid = unsigned(std::min<int64_t>(cdiv(nrows, 4), 8192));
+#define LGNN_SDDMM(LPRV)                                                                                           \
+  hipLaunchKernelGGL(sddmm_planes_kernel<LPRV>, dim3(grid), dim3(256), 0, s, m.rowptr, m.col, nrows, rows, nrows_dev, \
+                     L, l_ld, l_stride, R, r_ld, r_stride, width, nplanes, out)
+  if (width <= 8) LGNN_SDDMM(8);
+  else if (width <= 16) LGNN_SDDMM(16);
+  else if (width <= 32) LGNN_SDDMM(32);
+  else LGNN_SDDMM(64);
+#undef LGNN_SDDMM
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// gradP[(a, b)] += sum_{c in [c0, c0+cc)} sum_k seeds[m][c][k] * g1bar[c - c0][b][k]  for the first occurrence m of every
+// batch node a = idx[m] (the scattered seed planes G_c are non-zero on those rows only and hold the accumulated seeds of
+// duplicated node ids).  One wave per sample; lanes over (c, k).
+__global__ __launch_bounds__(256) void sddmm_seed_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                         const int64_t* __restrict__ idx, int64_t M, int64_t N, int64_t C,
+                                                         const int32_t* __restrict__ pos, const float* __restrict__ seeds,
+                                                         const float* __restrict__ g1bar, int64_t c0, int64_t cc,
+                                                         float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int64_t a = idx[m];
+  if (a < 0 || a >= N || pos[a] != m) return;  // duplicates: the first occurrence owns the accumulated seed row
+  const float* __restrict__ sd = seeds + m * C * C + c0 * C;
+  const int64_t nq = cc * C;
+  for (int32_t p = rowptr[a]; p < rowptr[a + 1]; ++p) {
+    const int64_t b = col[p];
+    float acc = 0.f;
+    for (int64_t q = lane; q < nq; q += 64) {
+      const int64_t c = q / C, k = q - c * C;
+      acc += sd[q] * g1bar[(c * N + b) * C + k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[p] += acc;
+  }
+}
+
+// Vbar[m][c0 + c][k] = sum_b P[a, b] * g1bar[c][b][k], a = idx[m] (every sample, duplicates included)
+__global__ __launch_bounds__(256) void seed_adjoint_gather_kernel(const int32_t* __restrict__ rowptr,
+                                                                  const int32_t* __restrict__ col,
+                                                                  const float* __restrict__ val,
+                                                                  const int64_t* __restrict__ idx, int64_t M, int64_t N,
+                                                                  int64_t C, const float* __restrict__ g1bar, int64_t c0,
+                                                                  int64_t cc, float* __restrict__ vbar) {
+  const int64_t nq = cc * C;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= M * nq) return;
+  const int64_t m = t / nq, q = t - m * nq;
+  const int64_t c = q / C, k = q - c * C;
+  const int64_t a = idx[m];
+  if (a < 0 || a >= N) return;
+  float acc = 0.f;
+  for (int32_t p = rowptr[a]; p < rowptr[a + 1]; ++p) acc += val[p] * g1bar[(c * N + col[p]) * C + k];
+  vbar[m * C * C + (c0 + c) * C + k] = acc;
+}
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// fbar_m = d/df sum_{k,c} Vbar[k,c] V[k,c](f) + softmax(f) - onehot(y); outbar[idx[m]] += fbar_m.  One wave per sample.
+// V[k,c] = alpha_c d_kc - beta_c u_k - gamma_c p_k (alpha = s (1 + t/2), beta = s, gamma = s t / 2, s = sqrt(p),
+// t = f - mbar, u = p (1 + t)); closed form of the derivative: oracle/gnn_laplace_oracle.py seed_adjoint.
+__global__ __launch_bounds__(256) void seed_adjoint_kernel(const float* __restrict__ logits, const float* __restrict__ probs,
+                                                           const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
+                                                           int64_t M, int64_t N, int64_t C, const float* __restrict__ vbar,
+                                                           int fork_exact, float loss_scale, float* __restrict__ outbar) {
+  extern __shared__ float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t m = int64_t(blockIdx.x) * 4 + wave;
+  if (m >= M) return;
+  const int64_t n = idx[m];
+  if (n < 0 || n >= N) return;
+  float* __restrict__ p_s = sm + size_t(wave) * 8 * C;  // p, u, s, alpha, gamma, rho, sigma, diag
+  float* __restrict__ u_s = p_s + C;
+  float* __restrict__ s_s = u_s + C;
+  float* __restrict__ al_s = s_s + C;
+  float* __restrict__ ga_s = al_s + C;
+  float* __restrict__ rho_s = ga_s + C;
+  float* __restrict__ sig_s = rho_s + C;
+  float mb = 0.f;
+  for (int64_t k = lane; k < C; k += 64) mb += probs[m * C + k] * logits[n * C + k];
+  mb = wsum(mb);
+  for (int64_t k = lane; k < C; k += 64) {
+    const float p = probs[m * C + k], t = logits[n * C + k] - mb, s = sqrtf(p);
+    p_s[k] = p; u_s[k] = p * (1.f + t); s_s[k] = s; al_s[k] = s * (1.f + 0.5f * t); ga_s[k] = 0.5f * s * t;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float* __restrict__ vb = vbar + m * C * C;  // vb[c * C + k] = Psi[k, c]
+  const int64_t yy = y[m];
+  float se1 = 0.f, se2 = 0.f, sru = 0.f, srp = 0.f, ssp = 0.f;
+  if (fork_exact) {
+    // rho_k = sum_c beta_c Psi_kc, sigma_k = sum_c gamma_c Psi_kc  (lane = k)
+    for (int64_t k = lane; k < C; k += 64) {
+      float rho = 0.f, sig = 0.f;
+      for (int64_t c = 0; c < C; ++c) {
+        const float ps = vb[c * C + k];
+        rho += s_s[c] * ps;
+        sig += ga_s[c] * ps;
+      }
+      rho_s[k] = rho; sig_s[k] = sig;
+      sru += rho * u_s[k]; srp += rho * p_s[k]; ssp += sig * p_s[k];
+    }
+    sru = wsum(sru); srp = wsum(srp); ssp = wsum(ssp);
+  }
+  // e1_c, e2_c (lane = c): r_c = sum_k Psi_kc u_k, q_c = sum_k Psi_kc p_k
+  float e1_l[4], e2_l[4];  // C <= 256
+  int nl = 0;
+  for (int64_t c = lane; c < C; c += 64, ++nl) {
+    float e1 = 0.f, e2 = 0.f;
+    if (fork_exact) {
+      float r = 0.f, q = 0.f;
+      for (int64_t k = 0; k < C; ++k) {
+        const float ps = vb[c * C + k];
+        r += ps * u_s[k];
+        q += ps * p_s[k];
+      }
+      const float dg = vb[c * C + c];
+      e1 = 0.5f * (dg * al_s[c] - r * s_s[c] - q * ga_s[c]);
+      e2 = 0.5f * s_s[c] * (dg - q);
+    }
+    e1_l[nl] = e1; e2_l[nl] = e2;
+    se1 += e1; se2 += e2;
+  }
+  se1 = wsum(se1); se2 = wsum(se2);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  nl = 0;
+  for (int64_t k = lane; k < C; k += 64, ++nl) {
+    const float p = p_s[k], u = u_s[k];
+    float fb = loss_scale * (p - (k == yy ? 1.f : 0.f));  // d (H_factor * CE) / d f
+    if (fork_exact)
+      fb += e1_l[nl] + e2_l[nl] - p * se1 - u * se2 - rho_s[k] * (u + p) + p * sru + u * srp - sig_s[k] * p + p * ssp;
+    atomicAdd(&outbar[n * C + k], fb);
+  }
+}
+
+__global__ void relu_mask_inplace_kernel(float* __restrict__ x, const float* __restrict__ h, int64_t n) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < n; q += stride) x[q] = h[q] > 0.f ? x[q] : 0.f;
+}
+
+// rs[a] = sum_b gP[a,b] P[a,b], cs[b] += the same (column sums): d J / d d_i = (rs[i] + cs[i]) / d_i
+__global__ void gp_rowcol_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                 const float* __restrict__ val, const float* __restrict__ gP, int64_t N,
+                                 float* __restrict__ rs, float* __restrict__ cs) {
+  const int64_t a = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  float acc = 0.f;
+  for (int32_t p = rowptr[a]; p < rowptr[a + 1]; ++p) {
+    const float t = gP[p] * val[p];
+    acc += t;
+    atomicAdd(&cs[col[p]], t);
+  }
+  rs[a] = acc;
+}
+
+__device__ __forceinline__ int32_t find_col(const int32_t* __restrict__ col, int32_t s, int32_t e, int32_t want) {
+  while (s < e) {  // sorted columns inside a row
+    const int32_t mid = (s + e) >> 1;
+    if (col[mid] < want) s = mid + 1;
+    else e = mid;
+  }
+  return s;
+}
+
+// Entry p = (i, j) of the stored 0/1 adjacency A (row-major, lgnn_export_adj order):
+//   gA[p] = gP[(j, i)] d_i d_j - 1/2 d_i^2 (rs[i] + cs[i]),   d = rowsum(A)^-1/2,   P = D A^T D;   diagonal -> 0
+__global__ void adj_grad_kernel(const int32_t* __restrict__ a_rowptr, const int32_t* __restrict__ a_col,
+                                const int32_t* __restrict__ p_rowptr, const int32_t* __restrict__ p_col,
+                                const float* __restrict__ gP, const float* __restrict__ rs, const float* __restrict__ cs,
+                                int64_t N, float* __restrict__ gA) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int32_t s = a_rowptr[i], e = a_rowptr[i + 1];
+  if (s == e) return;
+  const float di = rsqrtf(float(e - s));
+  const float rowterm = -0.5f * di * di * (rs[i] + cs[i]);
+  for (int32_t p = s; p < e; ++p) {
+    const int32_t j = a_col[p];
+    if (j == i) { gA[p] = 0.f; continue; }
+    const int32_t js = p_rowptr[j], je = p_rowptr[j + 1];
+    const int32_t q = find_col(p_col, js, je, int32_t(i));  // P has the entry (j, i) exactly when A has (i, j)
+    const float dj = rsqrtf(float(a_rowptr[j + 1] - a_rowptr[j]));
+    gA[p] = gP[q] * di * dj + rowterm;
+  }
+}
+
+// symmetric models propagate with (adj + adj^T) / 2: the parameter's gradient is the average of (i, j) and (j, i)
+__global__ void adj_grad_symmetrize_kernel(const int32_t* __restrict__ a_rowptr, const int32_t* __restrict__ a_col,
+                                           const float* __restrict__ gA, int64_t N, float* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int32_t p = a_rowptr[i]; p < a_rowptr[i + 1]; ++p) {
+    const int32_t j = a_col[p];
+    const int32_t q = find_col(a_col, a_rowptr[j], a_rowptr[j + 1], int32_t(i));
+    out[p] = 0.5f * (gA[p] + gA[q]);
+  }
+}
+
+// GCN top layer, all N rows (kfac.hip's unfused seed SpMM restated here with the planes of a class chunk only)
+__global__ void seed_planes_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                   const float* __restrict__ val, int64_t N, int64_t C, const int32_t* __restrict__ pos,
+                                   const float* __restrict__ seeds, float* __restrict__ g, uint8_t* __restrict__ active) {
+  // g[c][n][k] = sum_{v in row n of P^T, v in batch} val * seeds[pos[v]][c][k]; one wave per node
+  const int lane = threadIdx.x & 63;
+  const int64_t n = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int64_t CC = C * C;
+  bool any = false;
+  for (int64_t q0 = 0; q0 < CC; q0 += 64) {
+    const int64_t q = q0 + lane;
+    float acc = 0.f;
+    for (int32_t p = rowptr[n]; p < rowptr[n + 1]; ++p) {
+      const int32_t mp = pos[col[p]];
+      if (mp != INT32_MAX) {
+        any = true;
+        if (q < CC) acc += val[p] * seeds[int64_t(mp) * CC + q];
+      }
+    }
+    if (q < CC) {
+      const int64_t c = q / C, k = q - c * C;
+      g[(c * N + n) * C + k] = acc;
+    }
+  }
+  if (lane == 0) active[n] = any ? 1 : 0;
+}
+
+// C_rm[R, Nout] = alpha * A_rm[R, K] * B_rm[K, Nout] + beta * C_rm   (row major through the column-major library call)
+int sgemm_rm(hipStream_t s, int64_t R, int64_t Nout, int64_t K, float alpha, const float* A, int64_t lda, const float* B,
+             int64_t ldb, float beta, float* Cm, int64_t ldc) {
+  rocblas_handle blas = static_cast<rocblas_handle>(blas_handle(s));
+  LGNN_REQUIRE(blas != nullptr, "rocBLAS handle");
+  LGNN_REQUIRE(R < (int64_t(1) << 31) && Nout < (int64_t(1) << 31) && K < (int64_t(1) << 31), "sgemm: dimension too large");
+  const rocblas_status st = rocblas_sgemm(blas, rocblas_operation_none, rocblas_operation_none, rocblas_int(Nout),
+                                          rocblas_int(R), rocblas_int(K), &alpha, B, rocblas_int(ldb), A, rocblas_int(lda),
+                                          &beta, Cm, rocblas_int(ldc));
+  if (st != rocblas_status_success) { set_error("rocblas_sgemm failed"); return 3; }
+  return 0;
+}
+
+int check_model(const lgnn_ctx* h) {
+  LGNN_REQUIRE(h->L == 2 && h->kind == LGNN_KIND_GCN, "adjacency gradient: 2-layer GCN models (first slice of SURVEY.md 8(f)-4)");
+  LGNN_REQUIRE(h->act == LGNN_ACT_RELU && h->lik == LGNN_LIK_CLASSIFICATION, "adjacency gradient: ReLU, classification");
+  LGNN_REQUIRE(h->dims[2] <= 256, "adjacency gradient: at most 256 classes");
+  return 0;
+}
+
+}  // namespace
+
+int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags, const float* gamma_B0,
+                       const float* gamma_B1, float loss_scale, float* grad_P, float* out_bar, hipStream_t s) {
+  LGNN_CALL(check_model(h));
+  LGNN_REQUIRE(M > 0 && idx && y && gamma_B0 && gamma_B1 && grad_P && out_bar, "empty batch or null pointers");
+  LGNN_CALL(forward_ensure(h, s));
+  const int64_t N = h->N, C = h->dims[2], H = h->dims[1], CC = C * C;
+  const bool fork_exact = (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0;
+  LGNN_CALL(batch_prologue(h, idx, y, M, true, fork_exact, nullptr, s));
+
+  // top layer: g1 planes [C][N][C] over all rows + flags of the rows that are not identically zero
+  LGNN_CALL(h->ws.top.reserve(size_t(N) * CC * 4 + 16));
+  LGNN_CALL(h->ws.active.reserve(size_t(N)));
+  float* g1 = h->ws.top.as<float>();
+  hipLaunchKernelGGL(seed_planes_kernel, dim3(unsigned(cdiv(N, 4))), dim3(256), 0, s, h->PT.rowptr, h->PT.col, h->PT.val, N,
+                     C, h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), g1, h->ws.active.as<uint8_t>());
+  LGNN_HIP_CHECK(hipGetLastError());
+  LGNN_CALL(h->ws.act_list.reserve(size_t(N) * 4));
+  LGNN_CALL(h->ws.act_count.reserve(64));
+  LGNN_CALL(compact_flags(h->ws.active.as<uint8_t>(), N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(),
+                          h->ws.select_tmp, s));
+  LGNN_CALL(h->ws.jac.reserve(size_t(M) * CC * 4));  // Vbar [M][C][C]
+  float* vbar = h->ws.jac.as<float>();
+
+  // class chunks: three [cc][N][H] plane buffers (u / ubar, g0, g0bar) + g1bar [cc][N][C] under the workspace cap
+  const int64_t per_class = N * (3 * H + C) * 4;
+  const int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(C, h->ws_limit / std::max<int64_t>(per_class, 1)));
+  LGNN_CALL(h->ws.planes_a.reserve(size_t(cc_max) * N * H * 4 * 2));
+  LGNN_CALL(h->ws.planes_b.reserve(size_t(cc_max) * N * (H + C) * 4));
+  h->ws.planes_a_zero_ptr = nullptr;
+  for (int64_t c0 = 0; c0 < C; c0 += cc_max) {
+    const int64_t cc = std::min(cc_max, C - c0);
+    float* U = h->ws.planes_a.as<float>();
+    float* G0 = U + cc_max * N * H;
+    float* G0B = h->ws.planes_b.as<float>();
+    float* G1B = G0B + cc_max * N * H;
+    const float* g1c = g1 + c0 * N * C;
+    // u = mask * (g1 W1)     [cc * N, H]
+    GemmEpilogue ep;
+    ep.hact = h->fc.hact_p[0]; ep.hact_ld = h->fc.hact_ld[0]; ep.act = h->act; ep.hact_row_mod = N;
+    LGNN_CALL(launch_gemm(g1c, C, h->W[1], H, U, H, cc * N, C, H, ep, s));
+    // g0 = P^T u
+    SpmmArgs sa{};
+    sa.rowptr = h->PT.rowptr; sa.col = h->PT.col; sa.val = h->PT.val; sa.nrows = N;
+    sa.in = U; sa.in_ld = H; sa.in_plane_stride = N * H; sa.out = G0; sa.out_ld = H; sa.out_plane_stride = N * H;
+    sa.width = H; sa.out_act = -1;
+    LGNN_CALL(launch_spmm_ex(sa, cc, s));
+    // g0bar = 2 g0 Gamma_B0
+    LGNN_CALL(sgemm_rm(s, cc * N, H, H, 2.f, G0, H, gamma_B0, H, 0.f, G0B, H));
+    // gradP[(a,b)] += sum_c <u_c[a], g0bar_c[b]>; u is zero outside the active rows
+    LGNN_CALL(launch_sddmm(h->P, N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(), U, H, N * H, G0B, H, N * H,
+                           H, cc, grad_P, s));
+    // ubar = mask * (P g0bar)  (overwrites u)
+    SpmmArgs sb{};
+    sb.rowptr = h->P.rowptr; sb.col = h->P.col; sb.val = h->P.val; sb.nrows = N;
+    sb.in = G0B; sb.in_ld = H; sb.in_plane_stride = N * H; sb.out = U; sb.out_ld = H; sb.out_plane_stride = N * H;
+    sb.width = H; sb.out_act = -1;
+    sb.hact = h->fc.hact_p[0]; sb.hact_ld = h->fc.hact_ld[0]; sb.act = h->act;
+    LGNN_CALL(launch_spmm_ex(sb, cc, s));
+    // g1bar = ubar W1^T + 2 g1 Gamma_B1     [cc * N, C]
+    LGNN_CALL(sgemm_rm(s, cc * N, C, H, 1.f, U, H, h->Wt[1].as<float>(), C, 0.f, G1B, C));
+    LGNN_CALL(sgemm_rm(s, cc * N, C, C, 2.f, g1c, C, gamma_B1, C, 1.f, G1B, C));
+    // gradP[(a,b)] += sum_c <G_c[a], g1bar_c[b]> for the batch rows a;  Vbar = (P g1bar)[batch rows]
+    hipLaunchKernelGGL(sddmm_seed_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, h->P.rowptr, h->P.col, idx, M, N, C,
+                       h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), G1B, c0, cc, grad_P);
+    LGNN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(seed_adjoint_gather_kernel, dim3(unsigned(cdiv(M * cc * C, 256))), dim3(256), 0, s, h->P.rowptr,
+                       h->P.col, h->P.val, idx, M, N, C, G1B, c0, cc, vbar);
+    LGNN_HIP_CHECK(hipGetLastError());
+  }
+  LGNN_REQUIRE(size_t(4) * 8 * C * 4 <= 64 * 1024, "too many classes for the seed adjoint kernel");
+  hipLaunchKernelGGL(seed_adjoint_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), size_t(4) * 8 * C * 4, s,
+                     h->fc.out.as<float>(), h->ws.probs.as<float>(), idx, static_cast<const int64_t*>(y), M, N, C, vbar,
+                     fork_exact ? 1 : 0, loss_scale, out_bar);
+  LGNN_HIP_CHECK(hipGetLastError());
+  LGNN_CALL(batch_epilogue(h, idx, M, s));
+  return 0;
+}
+
+int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A1, float a1_scale, float* grad_P, float* grad_adj,
+                   hipStream_t s) {
+  LGNN_CALL(check_model(h));
+  LGNN_REQUIRE(out_bar && gamma_A1 && grad_P && grad_adj, "null pointers");
+  LGNN_CALL(forward_ensure(h, s));
+  const int64_t N = h->N, C = h->dims[2], H = h->dims[1], F = h->dims[0];
+  // Z1 = H1 W1^T + b1 and Z0 = X W0^T + b0 (the forward keeps neither: one scratch serves both)
+  const int64_t zw = std::max(H, C);
+  LGNN_CALL(h->ws.planes_a.reserve(size_t(N) * (zw + H + C) * 4));
+  h->ws.planes_a_zero_ptr = nullptr;
+  float* Z = h->ws.planes_a.as<float>();  // Z1 [N, C], later Z0 [N, H]
+  float* Hb = Z + N * zw;                   // H1bar [N, H]
+  float* Zb = Hb + N * H;                   // Z1bar [N, C]
+  GemmEpilogue eb1;
+  eb1.bias = h->b[1];
+  LGNN_CALL(launch_gemm(h->fc.hact_p[0], h->fc.hact_ld[0], h->Wt[1].as<float>(), C, Z, C, N, H, C, eb1, s));
+  LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, out_bar, C, 0, Z, C, 0, C, 1, grad_P, s));
+  // Z1bar = P^T outbar;  H1bar = Z1bar W1 + 2 a1_scale H1 Gamma_A1;  P0bar = mask * H1bar
+  LGNN_CALL(launch_spmm(h->PT, N, out_bar, C, Zb, C, C, 0, s));
+  LGNN_CALL(sgemm_rm(s, N, H, C, 1.f, Zb, C, h->W[1], H, 0.f, Hb, H));
+  LGNN_CALL(sgemm_rm(s, N, H, H, 2.f * a1_scale, h->fc.hact_p[0], h->fc.hact_ld[0], gamma_A1, H, 1.f, Hb, H));
+  hipLaunchKernelGGL(relu_mask_inplace_kernel, dim3(unsigned(std::min<int64_t>(cdiv(N * H, 256), 4096))), dim3(256), 0, s,
+                     Hb, h->fc.hact_p[0], N * H);
+  LGNN_HIP_CHECK(hipGetLastError());
+  GemmEpilogue eb0;
+  eb0.bias = h->b[0];
+  LGNN_CALL(launch_gemm(h->X, F, h->Wt[0].as<float>(), H, Z, H, N, F, H, eb0, s));
+  LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, Hb, H, 0, Z, H, 0, H, 1, grad_P, s));
+  // normalize_adj backward + the straight-through binarisation
+  LGNN_CALL(h->ws.misc.reserve(size_t(2) * N * 4 + size_t(h->nnz) * 4));
+  float* rs = h->ws.misc.as<float>();
+  float* cs = rs + N;
+  float* tmp = cs + N;
+  LGNN_HIP_CHECK(hipMemsetAsync(cs, 0, size_t(N) * 4, s));
+  hipLaunchKernelGGL(gp_rowcol_kernel, dim3(unsigned(cdiv(N, 256))), dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, grad_P,
+                     N, rs, cs);
+  float* first = h->sym ? tmp : grad_adj;
+  hipLaunchKernelGGL(adj_grad_kernel, dim3(unsigned(cdiv(N, 256))), dim3(256), 0, s, h->A.rowptr, h->A.col, h->P.rowptr,
+                     h->P.col, grad_P, rs, cs, N, first);
+  if (h->sym)
+    hipLaunchKernelGGL(adj_grad_symmetrize_kernel, dim3(unsigned(cdiv(N, 256))), dim3(256), 0, s, h->A.rowptr, h->A.col, tmp,
+                       N, grad_adj);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace lgnn
+
+extern "C" int lgnn_kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags,
+                                       const float* const* gamma_B, float loss_scale, float* grad_P, float* out_bar,
+                                       void* stream) {
+  if (!h || !gamma_B) { lgnn::set_error("null argument"); return 2; }
+  return lgnn::kfac_adjgrad_batch(h, idx, y, M, flags, gamma_B[0], gamma_B[1], loss_scale, grad_P, out_bar,
+                                  static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* const* gamma_A, float a_scale,
+                                   float* grad_P, float* grad_adj, void* stream) {
+  if (!h || !gamma_A) { lgnn::set_error("null argument"); return 2; }
+  return lgnn::adjgrad_finish(h, out_bar, gamma_A[1], a_scale, grad_P, grad_adj, static_cast<hipStream_t>(stream));
+}

@@ -287,6 +287,32 @@ class GraphEngine:
                                            _stream(self.device)), "lgnn_jacobians")
         return J, f
 
+    # -- marginal-likelihood gradient w.r.t. the adjacency ("next" row 8(f)-4) ---------------------------------
+    def adjgrad_batch(self, idx, y, gammas_B, grad_P: torch.Tensor, out_bar: torch.Tensor, fork_exact: bool = True,
+                      loss_scale: float = 1.0):
+        """Add one batch's terms to ``grad_P`` [nnz] (stored entries of the propagation matrix) and ``out_bar`` [N, C]."""
+        self._sync_versions()
+        idx, y = idx.contiguous(), y.contiguous()
+        self._keep = [g.contiguous() for g in gammas_B]
+        gb = _lib.ptr_array([_dev_ptr(g, torch.float32, "gamma_B").value for g in self._keep])
+        rc = self.lib.lgnn_kfac_adjgrad_batch(
+            self._h, _dev_ptr(idx, torch.int64, "idx"), _dev_ptr(y, torch.int64, "y"), idx.shape[0],
+            _lib.FLAG_FORK_EXACT_SEED if fork_exact else 0, gb, float(loss_scale),
+            _dev_ptr(grad_P, torch.float32, "grad_P"), _dev_ptr(out_bar, torch.float32, "out_bar"), _stream(self.device))
+        _lib.check(rc, "lgnn_kfac_adjgrad_batch")
+
+    def adjgrad_finish(self, out_bar: torch.Tensor, gammas_A, a_scale: float, grad_P: torch.Tensor) -> torch.Tensor:
+        """Forward-pass terms + normalize_adj / STE backward: gradient w.r.t. the stored entries of the 0/1 adjacency
+        (``export_adj`` order)."""
+        self._sync_versions()
+        keep = [g.contiguous() for g in gammas_A]
+        ga = _lib.ptr_array([_dev_ptr(g, torch.float32, "gamma_A").value for g in keep])
+        out = torch.zeros(self.nnz, dtype=torch.float32, device=self.device)
+        rc = self.lib.lgnn_adjgrad_finish(self._h, _dev_ptr(out_bar, torch.float32, "out_bar"), ga, float(a_scale),
+                                          _dev_ptr(grad_P, torch.float32, "grad_P"), out.data_ptr(), _stream(self.device))
+        _lib.check(rc, "lgnn_adjgrad_finish")
+        return out
+
     def check_async_errors(self):
         """Synchronise and raise if any batch since the last check contained an invalid node id or label."""
         _lib.check(self.lib.lgnn_check_async_errors(self._h, _stream(self.device)), "lgnn_check_async_errors")

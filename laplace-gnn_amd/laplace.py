@@ -525,6 +525,61 @@ class KronLaplace(ParametricLaplace):
             raise ValueError("Prior precision for Kron either scalar or per-layer.")
         return self.H * self._H_factor + pp
 
+    # ---- 8(f)-4: what the GNN driver differentiates (gnn/marglik_training.py:197-216) ------------------------------
+    def _logdet_factor_gradients(self):
+        """``d logdet(P) / d B_l`` and ``/ d A_l`` per layer, from the eigenpairs of the fitted factors
+        (laplace/utils/matrix.py:371-394: ``sum log(f lB_i lA_j + delta)`` per weight block, ``sum log(f lB_i + delta)``
+        per bias block, f = H_factor): ``Q diag(.) Q^T`` in the factor's own eigenbasis."""
+        f = self._H_factor
+        pp = torch.as_tensor(self.prior_precision, dtype=torch.float32, device=self._device).reshape(-1)
+        deltas = pp.expand(self.n_layers) if pp.numel() == 1 else pp
+        gB, gA = [], []
+        ev, qs = self.H.eigenvalues, self.H.eigenvectors
+        for l in range(len(ev) // 2):
+            (lB, lA), (QB, QA) = ev[2 * l], qs[2 * l]
+            (lBb,), (QBb,) = ev[2 * l + 1], qs[2 * l + 1]
+            den = f * torch.outer(lB, lA) + deltas[2 * l]
+            cB = (f * lA.unsqueeze(0) / den).sum(dim=1)
+            cA = (f * lB.unsqueeze(1) / den).sum(dim=0)
+            cBb = f / (f * lBb + deltas[2 * l + 1])
+            gB.append((QB * cB) @ QB.T + (QBb * cBb) @ QBb.T)
+            gA.append((QA * cA) @ QA.T)
+        return gB, gA
+
+    def neg_marglik_adj_grad(self, train_loader, prior_precision=None, process_group=None):
+        """``-log_marginal_likelihood()`` of this fit and its gradient w.r.t. the adjacency the model propagates with --
+        what ``neg_marglik.backward()`` leaves in ``model.adj.grad`` in the reference's structure-learning loop
+        (gnn/marglik_training.py:197-216), here on the stored sparsity pattern: returns ``(neg_marglik, edge_index [2, nnz],
+        grad [nnz])`` over the stored entries of the 0/1 adjacency (``model.engine.export_adj()`` order; self loops
+        carry gradient 0 like the reference's overwritten diagonal).  ``train_loader`` must be the loader of the fit
+        (same batch boundaries: the B factors depend on them).  Inside a ``torch.distributed`` job whole batches are
+        dealt round-robin and the two accumulators are all-reduced once."""
+        if self.H_facs is None:
+            raise AttributeError("Laplace not fitted. Run fit() first.")
+        if prior_precision is not None:
+            self.prior_precision = prior_precision
+        if self.likelihood != "classification":
+            raise NotImplementedError("adjacency gradient: classification likelihood")
+        eng = self.backend.engine
+        value = -self.log_marginal_likelihood()
+        gB, gA = self._logdet_factor_gradients()
+        gB = [0.5 * g for g in gB]  # neg marglik = H_factor * loss + 1/2 (logdet P - logdet P_0 + scatter)
+        gA = [0.5 * g for g in gA]
+        grad_P = torch.zeros(eng.nnz, dtype=torch.float32, device=eng.device)
+        out_bar = torch.zeros(eng.num_nodes, eng.dims[-1], dtype=torch.float32, device=eng.device)
+        rank, world = _dist_info(process_group)
+        for t, (X, y) in enumerate(train_loader):
+            if t % world != rank:
+                continue
+            eng.adjgrad_batch(X.to(eng.device), y.to(eng.device), gB, grad_P, out_bar,
+                              fork_exact=getattr(self.backend, "fork_exact_seed", True), loss_scale=self._H_factor)
+        if world > 1:
+            all_reduce_flat_([grad_P, out_bar], process_group)
+        a_scale = len(train_loader) / len(train_loader.dataset)
+        grad = eng.adjgrad_finish(out_bar, gA, a_scale, grad_P)
+        rows, cols = eng.export_adj()
+        return value, torch.stack([rows, cols]), grad
+
     @property
     def log_det_posterior_precision(self) -> torch.Tensor:
         return self.posterior_precision.logdet()

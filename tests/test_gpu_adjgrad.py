@@ -1,0 +1,83 @@
+"""SURVEY.md 8(f)-4 on the GPU: ``KronLaplace.neg_marglik_adj_grad`` (csrc/adjgrad.hip through the C ABI) against
+(a) the reference's ``model.adj.grad`` after ``(-log_marginal_likelihood()).backward()`` on its STEGCN (goldens generated
+by oracle/make_golden.py from the reference's own autograd) and (b) the CPU oracle's hand-written reverse chain on
+seeded mid-size inputs (class chunks under a small workspace cap, repeated node ids, upstream vs fork-exact seeds).
+fp32 end to end (eigendecomposition, three chained sparse products per class plane): tolerance 1e-3 relative."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gnn_laplace_oracle as O
+from conftest import GOLDEN
+from gpu_utils import oracle_from_arrays, rel
+from test_gpu_frontend import model_from_golden
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "gcn_*.npz")) if "adjgrad_vals" in np.load(p))
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_adjacency_gradient_matches_reference_autograd(path):
+    import laplace_gnn_amd as lg
+
+    g = np.load(path)
+    model = model_from_golden(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(),
+                                  batch_size=int(g["batch_size"]))
+    la = lg.KronLaplace(model, "classification", prior_precision=float(g["adjgrad_prior"]))
+    la.fit(loader)
+    val, ei, grad = la.neg_marglik_adj_grad(loader)
+    assert np.array_equal(ei[0].cpu().numpy(), g["adj_nz_row"]) and np.array_equal(ei[1].cpu().numpy(), g["adj_nz_col"])
+    assert abs(float(val) - float(g["adjgrad_neg_marglik"])) <= 2e-4 * abs(float(g["adjgrad_neg_marglik"]))
+    assert rel(grad.cpu().numpy(), g["adjgrad_vals"]) < 1e-3
+    diag = g["adj_nz_row"] == g["adj_nz_col"]
+    assert float(grad.cpu().numpy()[diag].__abs__().max()) == 0.0  # overwritten by fill_diagonal_(1) in the reference
+    # a second call gives the same result (accumulators are the caller's, nothing is left in the context)
+    _, _, grad2 = la.neg_marglik_adj_grad(loader)
+    assert rel(grad2.cpu().numpy(), grad.cpu().numpy()) < 1e-5
+    model.engine.check_async_errors()
+
+
+@pytest.mark.parametrize("fork_exact,sym,H,C", [(True, True, 64, 10), (False, False, 32, 7), (True, False, 256, 12)])
+def test_adjacency_gradient_midsize_vs_oracle(fork_exact, sym, H, C):
+    import laplace_gnn_amd as lg
+
+    N, F, E, M = 2500, 24, 9000, 500
+    gen = torch.Generator().manual_seed(13)
+    ei = torch.randint(0, N, (2, E), generator=gen)
+    X = torch.randn(N, F, generator=gen)
+    torch.manual_seed(1)
+    model = lg.GCN(F, H, C, 2, X, ei, symmetric=sym).to("cuda").eval()
+    idx = torch.randperm(N, generator=gen)[:M]
+    idx[M // 2:M // 2 + 20] = idx[:20]  # repeated node ids inside and across batches
+    y = torch.randint(0, C, (M,), generator=gen)
+    loader = lg.TensorBatchLoader(idx.cuda(), y.cuda(), batch_size=200)  # 200 / 200 / 100
+    model.engine.set_workspace_limit(16 << 20)  # several class chunks
+    la = lg.KronLaplace(model, "classification", prior_precision=0.5, backend_kwargs=dict(fork_exact_seed=fork_exact))
+    la.fit(loader)
+    val, e2, grad = la.neg_marglik_adj_grad(loader)
+    Ws = [c.lin.weight.detach().cpu().numpy() for c in model.convs]
+    bs = [c.lin.bias.detach().cpu().numpy() for c in model.convs]
+    om = oracle_from_arrays("gcn", N, ei.numpy(), X.numpy(), Ws, bs, sym)
+    oval, rows, cols, og = O.kron_marglik_adj_grad(om, idx.numpy(), y.numpy(), 200, 0.5, fork_exact, sym)
+    assert np.array_equal(e2[0].cpu().numpy(), rows) and np.array_equal(e2[1].cpu().numpy(), cols)
+    assert abs(float(val) - oval) <= 2e-4 * abs(oval)
+    assert rel(grad.cpu().numpy(), og) < 1e-3
+    model.engine.check_async_errors()
+
+
+def test_adjacency_gradient_is_refused_outside_the_first_slice():
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, "sage_small_1batch_s0.npz"))
+    model = model_from_golden(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(), 10000)
+    la = lg.KronLaplace(model, "classification")
+    with pytest.raises(AttributeError):
+        la.neg_marglik_adj_grad(loader)
+    la.fit(loader)
+    with pytest.raises(lg._lib.HipLibraryError, match="2-layer GCN"):
+        la.neg_marglik_adj_grad(loader)
