@@ -135,7 +135,10 @@ __device__ __forceinline__ float wsum(float v) {
 
 // fbar_m = d/df sum_{k,c} Vbar[k,c] V[k,c](f) + softmax(f) - onehot(y); outbar[idx[m]] += fbar_m.  One wave per sample.
 // V[k,c] = alpha_c d_kc - beta_c u_k - gamma_c p_k (alpha = s (1 + t/2), beta = s, gamma = s t / 2, s = sqrt(p),
-// t = f - mbar, u = p (1 + t)); closed form of the derivative: oracle/gnn_laplace_oracle.py seed_adjoint.
+// t = f - mbar, u = p (1 + t)).  With dp_k/df_m = p_k (d_km - p_m), dmbar/df_m = u_m, ds_c/df_m = s_c (d_cm - p_m) / 2:
+//   fbar_m = e1_m + e2_m - p_m sum(e1) - u_m sum(e2) - rho_m (u_m + p_m) + p_m <rho, u> + u_m <rho, p> - sigma_m p_m + p_m <sigma, p>
+//   e1 = (Psi_cc alpha - r s - q gamma) / 2, e2 = s (Psi_cc - q) / 2, r_c = sum_k Psi_kc u_k, q_c = sum_k Psi_kc p_k,
+//   rho_k = sum_c beta_c Psi_kc, sigma_k = sum_c gamma_c Psi_kc      (Psi = Vbar).
 __global__ __launch_bounds__(256) void seed_adjoint_kernel(const float* __restrict__ logits, const float* __restrict__ probs,
                                                            const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
                                                            int64_t M, int64_t N, int64_t C, const float* __restrict__ vbar,
