@@ -134,6 +134,25 @@ LGNN_API int lgnn_kfac_accumulate_classes(lgnn_ctx* h, const int64_t* idx, const
                                  uint32_t flags, int64_t class_begin, int64_t class_end,
                                  float* const* A_out, float* const* B_out, float* loss_out, void* stream);
 
+/* ---- empirical / Monte-Carlo Fisher -----------------------------------------------------------------------------
+ * KFAC with FisherType.EMPIRICAL / FisherType.MC (curvlinops/kfac.py:663-674; reached through CurvlinopsEF and
+ * CurvlinopsGGN(stochastic=True), laplace/curvature/curvlinops.py:143-179): ONE backward pass per call, seeded with
+ * resid_scale * d loss(f_n, y_seed_n) / d f_n  (softmax - onehot, resp. f - y_seed for the regression likelihood);
+ * B_out[l] += b_scale * g^T g  (b_scale = 1 / mc_samples).  y_loss != NULL: the call also adds factor-free
+ * loss(model(idx), y_loss) and the A increment (once per batch); y_loss == NULL: further MC samples of a batch.
+ * MC labels are drawn by the caller (curvlinops/kfac.py:698-745 draw_label) and passed as y_seed.             */
+LGNN_API int lgnn_kfac_accumulate_fisher(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const void* y_loss, int64_t M,
+                                int64_t n_train, uint32_t flags, float resid_scale, float b_scale, float* const* A_out,
+                                float* const* B_out, float* loss_out, void* stream);
+/* Per-sample loss gradients G[m, :] = J_m^T r_m (CurvatureInterface.gradients, laplace/curvature/curvature.py:169-210)
+ * and what EFInterface (:435-504) and GGNInterface with stochastic=True (:343-364, 401-432) build from them:
+ *   grads_out [M, P]  = G (may be NULL)     diag_out [P] += scale * sum_m G[m, p]^2 (may be NULL)
+ *   full_out [P, P]  += scale * G^T G (may be NULL)         *loss_out += loss(model(idx), y_loss) when y_loss != NULL
+ * r_m = resid_scale * (softmax(f_m) - onehot(y_seed_m)), regression: resid_scale * (f_m - y_seed_m).          */
+LGNN_API int lgnn_ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const void* y_loss, int64_t M,
+                       float resid_scale, float scale, float* diag_out, float* full_out, float* grads_out,
+                       float* loss_out, void* stream);
+
 /* Host-only query (no context, no device work): which kernels lgnn_kfac_accumulate would run for a model of this
  * shape -- the per-layer choice between the fused SpMM^T -> Gram kernel and the SpMM + Gram pair through HBM, the
  * compacted backward GEMM, and the workspace layout (curvlinops/kfac.py:653-661 has one autograd backward per class

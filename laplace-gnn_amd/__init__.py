@@ -6,7 +6,7 @@ kernels behind a C ABI (``include/laplace_gnn_hip.h``), a ``laplace.curvature``-
 backend class and the thin ``Laplace`` front that drives it.
 """
 from . import _lib  # noqa: F401
-from .curvature import HipCurvatureInterface, HipGGN  # noqa: F401
+from .curvature import HipCurvatureInterface, HipEF, HipGGN  # noqa: F401
 from .data import TensorBatchLoader, batches_of_rank, units_of_rank  # noqa: F401
 from .engine import GraphEngine  # noqa: F401
 from .laplace import (BaseLaplace, DiagLaplace, FullLaplace, FullLLLaplace, KronLaplace, Laplace,  # noqa: F401
@@ -14,6 +14,6 @@ from .laplace import (BaseLaplace, DiagLaplace, FullLaplace, FullLLLaplace, Kron
 from .matrix import Kron, KronDecomposed, symeig  # noqa: F401
 from .models import GCN, GraphSAGE  # noqa: F401
 
-__all__ = ["GraphEngine", "HipGGN", "HipCurvatureInterface", "Laplace", "BaseLaplace", "ParametricLaplace",
+__all__ = ["GraphEngine", "HipGGN", "HipEF", "HipCurvatureInterface", "Laplace", "BaseLaplace", "ParametricLaplace",
            "KronLaplace", "DiagLaplace", "FullLaplace", "FullLLLaplace", "Kron", "KronDecomposed", "symeig", "GCN", "GraphSAGE",
            "TensorBatchLoader", "batches_of_rank", "units_of_rank", "all_reduce_flat_"]

@@ -345,3 +345,11 @@ extern "C" int lgnn_lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, c
   if (!h) { set_error("null context"); return 2; }
   return lastlayer_full_accumulate(h, idx, y, M, H_out, loss_out, static_cast<hipStream_t>(stream));
 }
+
+extern "C" int lgnn_ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const void* y_loss, int64_t M,
+                                  float resid_scale, float scale, float* diag_out, float* full_out, float* grads_out,
+                                  float* loss_out, void* stream) {
+  if (!h) { set_error("null context"); return 2; }
+  return ef_accumulate(h, idx, y_seed, y_loss, M, resid_scale, scale, diag_out, full_out, grads_out, loss_out,
+                       static_cast<hipStream_t>(stream));
+}

@@ -262,6 +262,47 @@ int diag_from_jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* diag_
   return 0;
 }
 
+// ---- empirical / Monte-Carlo Fisher from per-sample gradients (EFInterface, laplace/curvature/curvature.py:435-504;
+// GGNInterface with stochastic=True, :343-364): G[m, p] = sum_c r[m, c] J[m, c, p] with the functional gradient
+// r = resid_scale * (softmax(f) - onehot(y_seed))  resp.  resid_scale * (f - y_seed) for the regression likelihood.
+__global__ void ef_resid_kernel(const float* __restrict__ probs, const float* __restrict__ logits,
+                                const int64_t* __restrict__ idx, const void* __restrict__ yseed, int64_t mc, int64_t C,
+                                int64_t N, int regression, float resid_scale, float* __restrict__ r, int* __restrict__ bad) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= mc * C) return;
+  const int64_t m = t / C, c = t - m * C;
+  const int64_t n = idx[m];
+  float v = 0.f;
+  if (n >= 0 && n < N) {
+    if (regression) v = logits[n * C + c] - static_cast<const float*>(yseed)[t];
+    else {
+      const int64_t ys = static_cast<const int64_t*>(yseed)[m];
+      if (ys < 0 || ys >= C) *bad = 2;
+      v = probs[t] - (c == ys ? 1.f : 0.f);
+    }
+  }
+  r[t] = resid_scale * v;
+}
+__global__ __launch_bounds__(256) void grads_from_jac_kernel(const float* __restrict__ J, const float* __restrict__ r,
+                                                             int64_t mc, int64_t C, int64_t P, float* __restrict__ G) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t m = blockIdx.y;
+  if (p >= P) return;
+  const float* __restrict__ Jm = J + m * C * P + p;
+  float acc = 0.f;
+  for (int64_t c = 0; c < C; ++c) acc += r[m * C + c] * Jm[c * P];
+  G[m * P + p] = acc;
+}
+__global__ __launch_bounds__(256) void sumsq_rows_kernel(const float* __restrict__ G, int64_t mc, int64_t P, float scale,
+                                                         float* __restrict__ diag) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int64_t m_begin = int64_t(blockIdx.y) * 32, m_end = min(mc, m_begin + 32);
+  float acc = 0.f;
+  for (int64_t m = m_begin; m < m_end; ++m) { const float g = G[m * P + p]; acc += g * g; }
+  atomicAdd(&diag[p], scale * acc);
+}
+
 int feat_views(lgnn_ctx* h, int layer, FeatView& f) {
   f.nrows = h->N;
   // what Linear `layer` multiplies, seen from an output node: propagated input (GCN) or cat (GraphSAGE)
@@ -332,6 +373,43 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
     const dim3 grid{unsigned(cdiv(Phi.width + 1, 256)), unsigned(C), nslab};
     hipLaunchKernelGGL(diag_last_layer_kernel, grid, dim3(256), 0, s, probs, idx, M, C, slab, Phi, diag_out + off,
                        diag_out + off + C * Phi.width);
+    LGNN_HIP_CHECK(hipGetLastError());
+  }
+  LGNN_CALL(batch_epilogue(h, idx, M, s));
+  return 0;
+}
+
+int gram_rows_sgemm(const float* G, int64_t rows, int64_t P, float scale, float* out, hipStream_t s);  // jacobian.hip
+
+int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const void* y_loss, int64_t M, float resid_scale,
+                  float scale, float* diag_out, float* full_out, float* grads_out, float* loss_out, hipStream_t s) {
+  LGNN_REQUIRE(M > 0 && idx && y_seed, "empty batch or null pointers");
+  LGNN_REQUIRE(h->L >= 1, "no model bound");
+  LGNN_REQUIRE(diag_out || full_out || grads_out, "nothing to compute");
+  LGNN_REQUIRE(!y_loss || loss_out, "loss requested without an output");
+  LGNN_CALL(forward_ensure(h, s));
+  const int64_t C = h->dims[h->L], P = h->n_params, N = h->N;
+  LGNN_CALL(batch_prologue(h, idx, y_loss ? y_loss : y_seed, M, false, false, y_loss ? loss_out : nullptr, s));
+  const int64_t mc_max = std::max<int64_t>(1, std::min<int64_t>(M, (h->ws_limit / 4) / std::max<int64_t>((C + 1) * P * 4, 1)));
+  LGNN_CALL(h->ws.jac.reserve(size_t(mc_max) * (C + 1) * P * 4 + size_t(mc_max) * C * 4));
+  float* J = h->ws.jac.as<float>();
+  float* G = J + mc_max * C * P;
+  float* r = G + mc_max * P;
+  for (int64_t m0 = 0; m0 < M; m0 += mc_max) {
+    const int64_t mc = std::min(mc_max, M - m0);
+    LGNN_CALL(jacobians(h, idx + m0, mc, J, nullptr, s));
+    const void* ys = h->lik == LGNN_LIK_REGRESSION ? static_cast<const void*>(static_cast<const float*>(y_seed) + m0 * C)
+                                                   : static_cast<const void*>(static_cast<const int64_t*>(y_seed) + m0);
+    hipLaunchKernelGGL(ef_resid_kernel, dim3(unsigned(cdiv(mc * C, 256))), dim3(256), 0, s, h->ws.probs.as<float>() + m0 * C,
+                       h->fc.out.as<float>(), idx + m0, ys, mc, C, N, h->lik == LGNN_LIK_REGRESSION ? 1 : 0, resid_scale, r,
+                       h->ws.flags.as<int>());
+    hipLaunchKernelGGL(grads_from_jac_kernel, dim3(unsigned(cdiv(P, 256)), unsigned(mc)), dim3(256), 0, s, J, r, mc, C, P, G);
+    LGNN_HIP_CHECK(hipGetLastError());
+    if (grads_out) LGNN_HIP_CHECK(hipMemcpyAsync(grads_out + m0 * P, G, size_t(mc) * P * 4, hipMemcpyDeviceToDevice, s));
+    if (diag_out)
+      hipLaunchKernelGGL(sumsq_rows_kernel, dim3(unsigned(cdiv(P, 256)), unsigned(cdiv(mc, 32))), dim3(256), 0, s, G, mc, P,
+                         scale, diag_out);
+    if (full_out) LGNN_CALL(gram_rows_sgemm(G, mc, P, scale, full_out, s));
     LGNN_HIP_CHECK(hipGetLastError());
   }
   LGNN_CALL(batch_epilogue(h, idx, M, s));

@@ -77,6 +77,19 @@ int ll_bias_gemm(const float* Wq, const float* Phi, float* Sb, int64_t Q, int64_
   return 0;
 }
 
+// out[P, P] += scale * G^T G for row-major G [rows, P] (the full empirical / MC Fisher of a chunk of per-sample gradients)
+int gram_rows_sgemm(const float* G, int64_t rows, int64_t P, float scale, float* out, hipStream_t s) {
+  rocblas_handle blas = static_cast<rocblas_handle>(blas_handle(s));
+  LGNN_REQUIRE(blas != nullptr, "rocBLAS handle");
+  const float one = 1.f;
+  // column-major view of G: [P, rows] with ld = P;  out = G_cm G_cm^T (symmetric: row / column major coincide)
+  const rocblas_status st = rocblas_sgemm(blas, rocblas_operation_none, rocblas_operation_transpose, rocblas_int(P),
+                                          rocblas_int(P), rocblas_int(rows), &scale, G, rocblas_int(P), G, rocblas_int(P), &one,
+                                          out, rocblas_int(P));
+  if (st != rocblas_status_success) { set_error("rocblas_sgemm failed"); return 3; }
+  return 0;
+}
+
 int jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out, hipStream_t s) {
   LGNN_REQUIRE(h->L > 0, "no model bound");
   LGNN_CALL(forward_ensure(h, s));

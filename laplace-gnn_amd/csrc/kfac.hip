@@ -49,12 +49,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 //   upstream   : V[k,c] = sqrt(p_c) (d_kc - p_k)                       (kfac_utils.py:122-126)
 // written as seeds[first][c][k] (+=: duplicated node ids accumulate like x[x_indices]' backward).
 // loss += logsumexp(f) - f[y]   (CrossEntropyLoss(reduction='sum'))
+// seed modes: 0 upstream, 1 fork exact, 2 regression (sqrt(2) I), and the single-column "gradient" seeds of the empirical
+// / Monte-Carlo Fisher (curvlinops/kfac.py:663-674: ONE backward pass of the loss itself): 3 classification
+// V[k, 0] = rs (p_k - [k == y_seed]), 4 regression V[k, 0] = rs (f_k - y_seed_k); columns c > 0 stay zero.
 __global__ __launch_bounds__(256) void seed_kernel(const float* __restrict__ logits, int64_t C,
                                                    const int64_t* __restrict__ idx, const void* __restrict__ y_,
                                                    int64_t M, int64_t N, const int32_t* __restrict__ pos, int fork_exact,
                                                    float* __restrict__ seeds, float* __restrict__ probs,
                                                    float* __restrict__ loss, int* __restrict__ bad,
-                                                   int32_t* __restrict__ mult) {
+                                                   int32_t* __restrict__ mult, const void* __restrict__ yseed_,
+                                                   float resid_scale) {
   extern __shared__ float sm[];
   __shared__ float loss_part[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void seed_kernel(const float* __restrict__ log
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (fork_exact == 2) {
+    if (fork_exact == 2 || fork_exact == 4) {
       // regression: sum_k (f_k - y_k)^2 with float targets [M, C] (MSELoss(reduction='sum'); the factor 0.5 of the
       // interface is applied by the caller)
       if (loss) {
@@ -107,7 +111,17 @@ __global__ __launch_bounds__(256) void seed_kernel(const float* __restrict__ log
       else loss_acc += logf(se) + mx - f_s[yy];
     }
     if (lane == 0 && mult) atomicAdd(&mult[pos[n]], 1);  // how often the node occurs in the batch, kept at its first place
-    if (seeds) {
+    if (seeds && fork_exact >= 3) {
+      float* __restrict__ dst = seeds + int64_t(pos[n]) * C * C;  // row c = 0 of the block
+      if (fork_exact == 3) {
+        const int64_t ys = static_cast<const int64_t*>(yseed_)[m];
+        if (ys < 0 || ys >= C) { if (lane == 0) *bad = 2; }
+        else for (int64_t k = lane; k < C; k += 64) atomicAdd(&dst[k], resid_scale * (p_s[k] - (k == ys ? 1.f : 0.f)));
+      } else {
+        const float* __restrict__ yr = static_cast<const float*>(yseed_) + m * C;
+        for (int64_t k = lane; k < C; k += 64) atomicAdd(&dst[k], resid_scale * (f_s[k] - yr[k]));
+      }
+    } else if (seeds) {
       const int64_t first = pos[n];
       float* __restrict__ dst = seeds + first * C * C;
       const int64_t CC = C * C;
@@ -545,9 +559,11 @@ KfacPlan plan_kfac(int kind, int L, int64_t N, int64_t nnz, const int64_t* dims,
 
 // shared by kfac / diag / last layer: mark the batch, compute seeds/probs/loss.
 int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bool want_seeds, bool fork_exact,
-                   float* loss_out, hipStream_t s) {
+                   float* loss_out, hipStream_t s, const void* y_seed, float resid_scale) {
   const int64_t N = h->N, C = h->dims[h->L];
-  const int seed_mode = h->lik == LGNN_LIK_REGRESSION ? 2 : (fork_exact ? 1 : 0);
+  // y_seed != null: single-column gradient seeds of the empirical / MC Fisher (labels resp. fp32 targets to seed with)
+  const int seed_mode = y_seed ? (h->lik == LGNN_LIK_REGRESSION ? 4 : 3)
+                               : (h->lik == LGNN_LIK_REGRESSION ? 2 : (fork_exact ? 1 : 0));
   LGNN_REQUIRE(2 * C * 4 <= 64 * 1024, "too many classes for the seed kernel");
   int* bad = h->ws.flags.as<int>();  // allocated and zeroed by lgnn_create; sticky until lgnn_check_async_errors
   hipLaunchKernelGGL(mark_batch_kernel, dim3(unsigned(cdiv(M, 256))), dim3(256), 0, s, idx, M, N,
@@ -565,7 +581,7 @@ int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bo
   hipLaunchKernelGGL(seed_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M, 4), 2048))), dim3(256), size_t(8 * C) * 4, s,
                      h->fc.out.as<float>(), C, idx,
                      y, M, N, h->ws.pos.as<int32_t>(), seed_mode, seeds,
-                     h->ws.probs.as<float>(), loss_out, bad, h->ws.mult.as<int32_t>());
+                     h->ws.probs.as<float>(), loss_out, bad, h->ws.mult.as<int32_t>(), y_seed, resid_scale);
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -578,19 +594,25 @@ int batch_epilogue(lgnn_ctx* h, const int64_t* idx, int64_t M, hipStream_t s) {
 }
 
 int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train, uint32_t flags,
-                    int64_t cb, int64_t ce, float* const* A_out, float* const* B_out, float* loss_out, hipStream_t s) {
-  LGNN_REQUIRE(M > 0 && idx && y, "empty batch or null batch pointers");
+                    int64_t cb, int64_t ce, float* const* A_out, float* const* B_out, float* loss_out, hipStream_t s,
+                    const KfacFisherOpts* fisher) {
+  LGNN_REQUIRE(M > 0 && idx && (y || (fisher && !fisher->add_loss_and_A)), "empty batch or null batch pointers");
   LGNN_REQUIRE(h->L > 0, "no model bound");
   LGNN_REQUIRE(cb >= 0 && cb < ce && ce <= h->dims[h->L], "class range must satisfy 0 <= begin < end <= C");
   // B_l = sum over class columns c of g_c^T g_c: a class range is an exact additive share of the batch.
   // The share that contains class 0 also carries what exists once per batch: the loss and the A increment
   // (and, for GraphSAGE, the whole top-layer Gram, which is only M*C rows).
   const bool first = cb == 0;
+  // empirical / MC Fisher: one plane (the gradient seed sits in column 0 of the block), B scaled by 1 / mc_samples, the
+  // loss of the TRUE labels and the A increment only with the call that is told to add them
+  const bool once = fisher ? fisher->add_loss_and_A : first;
+  const float b_scale = fisher ? fisher->b_scale : 1.0f;
+  LGNN_REQUIRE(!fisher || (cb == 0 && ce == 1 && fisher->y_seed), "internal: Fisher seeds use plane 0 only");
   LGNN_REQUIRE(n_train > 0, "n_train must be positive");
   LGNN_REQUIRE(A_out && B_out && loss_out, "null output pointers");
   // the input Grams feed the A increment, which only the share with class 0 adds (ranks of a multi-GPU job that
   // hold no such share never compute them)
-  if (first) LGNN_CALL(forward_ensure_grams(h, s));
+  if (once) LGNN_CALL(forward_ensure_grams(h, s));
   else LGNN_CALL(forward_ensure(h, s));
   const int64_t N = h->N;
   const int L = h->L;
@@ -603,11 +625,12 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   const KfacPlan plan = plan_kfac(h->kind, L, N, h->nnz, h->dims, h->act, no_fuse, h->ws_limit);
   // GCN, fused path: the top-layer kernel rebuilds each sample's C x C seed block from its probabilities and logits,
   // so the blocks are never written (64 MB per arxiv-shaped batch); every other path reads them from ws.seeds
-  const bool seeds_on_the_fly = plan.seeds_on_the_fly;
-  LGNN_CALL(batch_prologue(h, idx, y, M, !seeds_on_the_fly, fork_exact, first ? loss_out : nullptr, s));
+  const bool seeds_on_the_fly = plan.seeds_on_the_fly && !fisher;  // the on-the-fly rebuild knows the GGN blocks only
+  LGNN_CALL(batch_prologue(h, idx, y, M, !seeds_on_the_fly, fork_exact, once ? loss_out : nullptr, s,
+                           fisher ? fisher->y_seed : nullptr, fisher ? fisher->resid_scale : 1.0f));
 
   // A_l += in_l^T in_l / n_train   (kfac.py:870 divides by M, curvlinops.py:46-53 multiplies by M/N)
-  for (int l = 0; first && l < L; ++l)
+  for (int l = 0; once && l < L; ++l)
     LGNN_CALL(launch_sym_accumulate(h->fc.gram_raw[l].as<float>(), h->in_dim[l], 1.0f / float(n_train), A_out[l], s));
 
   for (int l = 0; l < L; ++l) {
@@ -840,7 +863,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   }
 
   for (int l = 0; l < L; ++l)
-    LGNN_CALL(launch_sym_accumulate(h->ws.gram_scratch[l].as<float>(), h->dims[l + 1], 1.0f, B_out[l], s));
+    LGNN_CALL(launch_sym_accumulate(h->ws.gram_scratch[l].as<float>(), h->dims[l + 1], b_scale, B_out[l], s));
   LGNN_CALL(batch_epilogue(h, idx, M, s));
   return 0;
 }
@@ -861,4 +884,15 @@ extern "C" int lgnn_kfac_plan(int kind, int num_layers, const int64_t* dims, int
   out[0] = p.seeds_on_the_fly; out[1] = p.sage_compact; out[2] = p.need_pong; out[3] = p.cc_max;
   for (int l = 0; l < num_layers; ++l) out[4 + l] = (p.fuse[l] ? 1 : 0) | (p.backgemm[l] ? 2 : 0);
   return 0;
+}
+
+// Empirical / Monte-Carlo Fisher KFAC: one backward pass per call, seeded with resid_scale * d loss(f, y_seed) / d f.
+extern "C" int lgnn_kfac_accumulate_fisher(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const void* y_loss,
+                                           int64_t M, int64_t n_train, uint32_t flags, float resid_scale, float b_scale,
+                                           float* const* A_out, float* const* B_out, float* loss_out, void* stream) {
+  using namespace lgnn;
+  if (!h) { set_error("null context"); return 2; }
+  LGNN_REQUIRE(y_seed != nullptr, "the Fisher accumulate needs the labels / targets to seed with");
+  KfacFisherOpts o{y_seed, resid_scale, b_scale, y_loss != nullptr};
+  return kfac_accumulate(h, idx, y_loss, M, n_train, flags, 0, 1, A_out, B_out, loss_out, static_cast<hipStream_t>(stream), &o);
 }

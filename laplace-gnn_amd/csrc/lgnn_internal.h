@@ -249,10 +249,18 @@ struct KfacPlan {
   int64_t maxw, cc_max;        // widest GEMM output of the lower layers; class planes per chunk under the workspace cap
 };
 KfacPlan plan_kfac(int kind, int L, int64_t N, int64_t nnz, const int64_t* dims, int act, bool no_fuse, int64_t ws_limit);
+// empirical / Monte-Carlo Fisher variant of the KFAC accumulate (curvlinops/kfac.py:663-674)
+struct KfacFisherOpts {
+  const void* y_seed;   // labels int64 [M] (classification) / fp32 targets [M, C] (regression) the gradient seed uses
+  float resid_scale;    // seed = resid_scale * d loss_n / d f_n  (p - onehot resp. f - y)
+  float b_scale;        // B_out += b_scale * g^T g               (1 / mc_samples)
+  bool add_loss_and_A;  // this call also adds the loss of the true labels `y` and the A increment
+};
 int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train, uint32_t flags,
-                    int64_t class_begin, int64_t class_end, float* const* A_out, float* const* B_out, float* loss_out, hipStream_t s);
+                    int64_t class_begin, int64_t class_end, float* const* A_out, float* const* B_out, float* loss_out,
+                    hipStream_t s, const KfacFisherOpts* fisher = nullptr);
 int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bool want_seeds, bool fork_exact,
-                   float* loss_out, hipStream_t s);
+                   float* loss_out, hipStream_t s, const void* y_seed = nullptr, float resid_scale = 1.0f);
 int batch_epilogue(lgnn_ctx* h, const int64_t* idx, int64_t M, hipStream_t s);
 // timing hook (lgnn_enable_kernel_timing): one HIP event on the launch stream; callers bracket the dominant kernel
 int record_event(lgnn_ctx* h, hipStream_t s);
@@ -265,6 +273,8 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
                     float* loss_out, hipStream_t s);
 int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out,
                               float* loss_out, hipStream_t s);
+int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const void* y_loss, int64_t M, float resid_scale,
+                  float scale, float* diag_out, float* full_out, float* grads_out, float* loss_out, hipStream_t s);
 // ---- jacobian.hip -----------------------------------------------------------------------
 int jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out, hipStream_t s);
 

@@ -59,18 +59,21 @@ def _kron_class():
 class HipCurvatureInterface:
     def __init__(self, model: nn.Module, likelihood: str, last_layer: bool = False,
                  subnetwork_indices: torch.LongTensor | None = None, dict_key_x: str = "input_ids",
-                 dict_key_y: str = "labels", stochastic: bool = False, fork_exact_seed: bool = True):
+                 dict_key_y: str = "labels", stochastic: bool = False, fork_exact_seed: bool = True,
+                 num_samples: int = 1, generator: torch.Generator | None = None):
         assert likelihood in ["regression", "classification"]
         if subnetwork_indices is not None:
             raise NotImplementedError("subnetwork Laplace is out of scope for the HIP backend")
-        if stochastic:
-            raise NotImplementedError("MC Fisher (stochastic=True) is not implemented on the HIP backend")
         self.likelihood = likelihood
         self.model = model
         self.last_layer = last_layer
         self.subnetwork_indices = None
         self.dict_key_x, self.dict_key_y = dict_key_x, dict_key_y
-        self.stochastic = False
+        # stochastic=True: Monte-Carlo Fisher instead of the GGN (CurvlinopsGGN, laplace/curvature/curvlinops.py:143-167;
+        # GGNInterface, laplace/curvature/curvature.py:327-364 with ``num_samples`` draws for diag / full)
+        self.stochastic = bool(stochastic)
+        self.num_samples = int(num_samples)
+        self.generator = generator
         self.fork_exact_seed = fork_exact_seed
         if likelihood == "regression":
             self.lossfunc, self.factor = MSELoss(reduction="sum"), 0.5
@@ -120,15 +123,65 @@ class HipCurvatureInterface:
             kfacs.append([B * self.factor if self.factor != 1.0 else B.clone()])
         return _kron_class()(kfacs)
 
-    def kron(self, x: torch.Tensor, y: torch.Tensor, N: int, **kwargs: Any):
+    # Fisher type of the KFAC factors: "type2" (GGN), "mc" (stochastic=True), "empirical" (HipEF)
+    @property
+    def _kron_fisher_type(self) -> str:
+        return "mc" if self.stochastic else "type2"
+
+    def draw_labels(self, x: torch.Tensor, kfac: bool = True) -> torch.Tensor:
+        """One draw from the model's predictive distribution at the batch nodes: categorical for classification; for
+        regression N(f, 1/2) in the KFAC route (MSELoss implies variance 1/2, curvlinops/kfac.py:721-729) and N(f, 1) in
+        the Jacobian route (laplace/curvature/curvature.py:349-351)."""
+        f = self.engine.forward(x)
+        if self.likelihood == "regression":
+            std = 0.5 ** 0.5 if kfac else 1.0
+            return f + std * torch.randn(f.shape, device=f.device, dtype=f.dtype, generator=self.generator)
+        return torch.multinomial(torch.softmax(f, dim=-1), 1, generator=self.generator).squeeze(-1)
+
+    def _fisher_kron(self, x, y, N, draws, fuse: bool = True):
+        """KFAC with FisherType.EMPIRICAL (``draws = [y]``) / FisherType.MC (``draws`` = sampled labels): one backward
+        pass per draw, gradient covariance scaled by 1 / len(draws) (curvlinops/kfac.py:663-674, 806-810)."""
+        self.engine.set_likelihood(self.likelihood)
+        rs = 2.0 if self.likelihood == "regression" else 1.0  # d MSE_sum / d f = 2 (f - y)
+        _, views, loss = self.engine.new_kfac_buffers()
+        for s_, ys in enumerate(draws):
+            self.engine.kfac_accumulate_fisher(x, ys, y if s_ == 0 else None, N, views, loss, resid_scale=rs,
+                                               b_scale=1.0 / len(draws), fuse=fuse)
+        return self.factor * loss[0].clone(), self.pack_kron(views)
+
+    def kron(self, x: torch.Tensor, y: torch.Tensor, N: int, mc_samples: int = 1, mc_labels=None, **kwargs: Any):
+        """``mc_samples`` / ``mc_labels`` only matter for ``stochastic=True`` (MC Fisher): the labels are drawn on the
+        device unless the caller brings them (reproducibility across devices)."""
         if kwargs:
-            raise NotImplementedError(f"unsupported kron kwargs {sorted(kwargs)} (mc_samples / kfac_approx)")
+            raise NotImplementedError(f"unsupported kron kwargs {sorted(kwargs)} (kfac_approx)")
+        if self._kron_fisher_type == "mc":
+            draws = list(mc_labels) if mc_labels is not None else [self.draw_labels(x) for _ in range(int(mc_samples))]
+            return self._fisher_kron(x, y, N, draws)
+        if self._kron_fisher_type == "empirical":
+            return self._fisher_kron(x, y, N, [y])
         _, views, loss = self.engine.new_kfac_buffers()
         self.kron_accumulate_(views, loss, x, y, N)
         return self.factor * loss[0].clone(), self.pack_kron(views)
 
+    def _mc_functional_fisher(self, x, y, full: bool, mc_labels=None):
+        """GGNInterface with stochastic=True (laplace/curvature/curvature.py:343-364, 401-432): the functional Fisher
+        ``1/S sum_s r_s r_s^T`` (r = softmax(f) - onehot(y_s), regression: f - y_s) replaces Lambda; no factor on H."""
+        eng = self.engine
+        eng.set_likelihood(self.likelihood)
+        P = eng.n_params
+        H = torch.zeros((P, P) if full else (P,), dtype=torch.float32, device=eng.device)
+        loss = torch.zeros(1, dtype=torch.float32, device=eng.device)
+        draws = list(mc_labels) if mc_labels is not None else [self.draw_labels(x, kfac=False)
+                                                               for _ in range(self.num_samples)]
+        for s_, ys in enumerate(draws):
+            eng.ef_accumulate(x, ys, y if s_ == 0 else None, 1.0, 1.0 / len(draws), diag=None if full else H,
+                              full=H if full else None, loss=loss if s_ == 0 else None)
+        return self.factor * loss[0], H
+
     # ---- diag ----------------------------------------------------------------------------------
-    def diag(self, x: torch.Tensor, y: torch.Tensor, **kwargs: Any):
+    def diag(self, x: torch.Tensor, y: torch.Tensor, mc_labels=None, **kwargs: Any):
+        if self.stochastic:
+            return self._mc_functional_fisher(x, y, full=False, mc_labels=mc_labels)
         self.engine.set_likelihood(self.likelihood)  # regression: H = sum J^T J on the device (no factor on H)
         eng = self.engine
         H = torch.zeros(eng.n_params, dtype=torch.float32, device=eng.device)
@@ -137,7 +190,9 @@ class HipCurvatureInterface:
         return self.factor * loss[0], H
 
     # ---- full (last layer) ---------------------------------------------------------------------
-    def full(self, x: torch.Tensor, y: torch.Tensor, **kwargs: Any):
+    def full(self, x: torch.Tensor, y: torch.Tensor, mc_labels=None, **kwargs: Any):
+        if self.stochastic and not self.last_layer:
+            return self._mc_functional_fisher(x, y, full=True, mc_labels=mc_labels)
         if not self.last_layer:
             return self._full_from_jacobians(x, y)
         eng = self.engine
@@ -208,9 +263,49 @@ class HipCurvatureInterface:
     def last_layer_jacobians(self, x, enable_backprop: bool = False):
         raise NotImplementedError("last-layer Jacobians (GLM predictive of last-layer Laplace) are not implemented")
 
-    def gradients(self, x, y):
-        raise NotImplementedError("per-sample gradients (empirical Fisher) are out of scope")
+    def gradients(self, x: torch.Tensor, y: torch.Tensor):
+        """(Gs [M, P], loss): per-sample gradients of the summed loss, ``G_n = J_n^T d loss_n / d f_n``
+        (CurvatureInterface.gradients, laplace/curvature/curvature.py:169-210); loss without the interface factor."""
+        eng = self.engine
+        eng.set_likelihood(self.likelihood)
+        loss = torch.zeros(1, dtype=torch.float32, device=eng.device)
+        rs = 2.0 if self.likelihood == "regression" else 1.0
+        Gs = eng.ef_accumulate(x, y, y, rs, 1.0, grads=True, loss=loss)
+        return Gs, loss[0]
 
 
 class HipGGN(HipCurvatureInterface):
-    """GGN backend on MI355X; the counterpart of ``CurvlinopsGGN`` (curvlinops.py:143-167)."""
+    """GGN backend on MI355X; the counterpart of ``CurvlinopsGGN`` (curvlinops.py:143-167); ``stochastic=True`` switches
+    to the Monte-Carlo Fisher like the reference's flag."""
+
+
+class HipEF(HipCurvatureInterface):
+    """Empirical Fisher backend; the counterpart of ``CurvlinopsEF`` / ``EFInterface`` (laplace/curvature/curvlinops.py:
+    170-179, laplace/curvature/curvature.py:435-504): KFAC with FisherType.EMPIRICAL, ``diag = factor * sum_n G_n^2``,
+    ``full = factor * G^T G`` from the per-sample loss gradients."""
+
+    def __init__(self, model, likelihood, last_layer: bool = False, subnetwork_indices=None, dict_key_x: str = "input_ids",
+                 dict_key_y: str = "labels", **kwargs):
+        if last_layer:
+            raise NotImplementedError("empirical Fisher: all-weights Laplace only")
+        super().__init__(model, likelihood, last_layer, subnetwork_indices, dict_key_x, dict_key_y, stochastic=False, **kwargs)
+
+    @property
+    def _kron_fisher_type(self) -> str:
+        return "empirical"
+
+    def _ef(self, x, y, full: bool):
+        eng = self.engine
+        eng.set_likelihood(self.likelihood)
+        P = eng.n_params
+        H = torch.zeros((P, P) if full else (P,), dtype=torch.float32, device=eng.device)
+        loss = torch.zeros(1, dtype=torch.float32, device=eng.device)
+        rs = 2.0 if self.likelihood == "regression" else 1.0
+        eng.ef_accumulate(x, y, y, rs, self.factor, diag=None if full else H, full=H if full else None, loss=loss)
+        return self.factor * loss[0], H
+
+    def diag(self, x: torch.Tensor, y: torch.Tensor, **kwargs: Any):
+        return self._ef(x, y, full=False)
+
+    def full(self, x: torch.Tensor, y: torch.Tensor, **kwargs: Any):
+        return self._ef(x, y, full=True)

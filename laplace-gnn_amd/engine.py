@@ -258,6 +258,46 @@ class GraphEngine:
             flags, cb, ce, A, B, loss.data_ptr(), _stream(self.device))
         _lib.check(rc, "lgnn_kfac_accumulate_classes")
 
+    def kfac_accumulate_fisher(self, idx, y_seed, y_loss, n_train: int, views, loss, resid_scale: float = 1.0,
+                               b_scale: float = 1.0, fuse: bool = True):
+        """Empirical / Monte-Carlo Fisher KFAC of one batch: ONE backward pass seeded with
+        ``resid_scale * d loss(f, y_seed) / d f``; ``B += b_scale * g^T g``.  ``y_loss`` (the true labels) makes this
+        call also add the loss and the A increment -- pass it with the first draw of a batch, ``None`` afterwards."""
+        self._sync_versions()
+        idx = idx.contiguous()
+        M = idx.shape[0]
+        ys = self._labels(y_seed, M)
+        keep = self._keep if self.likelihood == "regression" else None
+        yl = self._labels(y_loss, M) if y_loss is not None else None
+        self._keep = (keep, getattr(self, "_keep", None))
+        A = _lib.ptr_array([a.data_ptr() for a, _ in views])
+        B = _lib.ptr_array([b.data_ptr() for _, b in views])
+        rc = self.lib.lgnn_kfac_accumulate_fisher(
+            self._h, _dev_ptr(idx, torch.int64, "idx"), ys, yl, M, int(n_train), 0 if fuse else _lib.FLAG_NO_FUSE,
+            float(resid_scale), float(b_scale), A, B, loss.data_ptr(), _stream(self.device))
+        _lib.check(rc, "lgnn_kfac_accumulate_fisher")
+
+    def ef_accumulate(self, idx, y_seed, y_loss=None, resid_scale: float = 1.0, scale: float = 1.0,
+                      diag: torch.Tensor | None = None, full: torch.Tensor | None = None, grads: bool = False,
+                      loss: torch.Tensor | None = None):
+        """Per-sample loss gradients ``G = J^T r`` of a batch (returned as [M, P] when ``grads``), ``diag += scale *
+        sum G^2``, ``full += scale * G^T G``; ``loss += loss(model(idx), y_loss)`` when ``y_loss`` is given."""
+        self._sync_versions()
+        idx = idx.contiguous()
+        M = idx.shape[0]
+        ys = self._labels(y_seed, M)
+        keep = self._keep if self.likelihood == "regression" else None
+        yl = self._labels(y_loss, M) if y_loss is not None else None
+        self._keep = (keep, getattr(self, "_keep", None))
+        G = torch.empty(M, self.n_params, dtype=torch.float32, device=self.device) if grads else None
+        rc = self.lib.lgnn_ef_accumulate(
+            self._h, _dev_ptr(idx, torch.int64, "idx"), ys, yl, M, float(resid_scale), float(scale),
+            None if diag is None else _dev_ptr(diag, torch.float32, "diag"),
+            None if full is None else _dev_ptr(full, torch.float32, "full"),
+            None if G is None else G.data_ptr(), None if loss is None else loss.data_ptr(), _stream(self.device))
+        _lib.check(rc, "lgnn_ef_accumulate")
+        return G
+
     def diag_accumulate(self, idx, y, diag: torch.Tensor, loss: torch.Tensor):
         """diag += diagonal GGN of the batch, loss += raw loss sum (CE, or the MSE sum for a regression binding)."""
         self._sync_versions()

@@ -446,9 +446,15 @@ class KronLaplace(ParametricLaplace):
         self.H_facs.kfacs = state_dict["H"]
         self.H = self.H_facs.decompose(damping=self.damping)
 
+    def _inplace_backend(self) -> bool:
+        """The in-place (flat buffer, class-range capable) fast path exists for the GGN factors of the HIP backend; the
+        empirical / MC Fisher variants go through ``backend.kron`` like any other backend."""
+        be = self.backend
+        return hasattr(be, "kron_accumulate_") and getattr(be, "_kron_fisher_type", "type2") == "type2"
+
     def _curv_closure(self, X, y, N, classes=None):
         be = self.backend
-        if hasattr(be, "kron_accumulate_"):  # in-place fast path of the HIP backend
+        if self._inplace_backend():  # in-place fast path of the HIP backend
             if self._flat is None:
                 self._flat = be.new_kfac_buffers() if hasattr(be, "new_kfac_buffers") else be.engine.new_kfac_buffers()
             _, views, loss_buf = self._flat
@@ -460,7 +466,7 @@ class KronLaplace(ParametricLaplace):
         """Backends that can restrict a call to a range of class columns get the balanced (batch, class)
         decomposition of ``data.units_of_rank``; others fall back to whole batches round-robin."""
         be = self.backend
-        if world == 1 or not (hasattr(be, "kron_accumulate_") and hasattr(be, "num_classes")):
+        if world == 1 or not (self._inplace_backend() and hasattr(be, "num_classes")):
             return super()._shard_plan(train_loader, rank, world)
         from .data import units_of_rank
         mine = {}
@@ -474,7 +480,7 @@ class KronLaplace(ParametricLaplace):
 
     def _reduce_tensors(self):
         be = self.backend
-        if hasattr(be, "kron_accumulate_"):
+        if self._inplace_backend():
             if self._flat is None:  # a rank without local batches still takes part in the all-reduce
                 self._flat = be.new_kfac_buffers() if hasattr(be, "new_kfac_buffers") else be.engine.new_kfac_buffers()
             flat, views, loss_buf = self._flat

@@ -227,6 +227,76 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
         out["fullla_glm_fvar"] = f_var.detach().numpy().astype(np.float32)
         out["fullla_glm_probit"] = lf(eval_idx, pred_type="glm", link_approx="probit").detach().numpy().astype(np.float32)
 
+    if with_full:
+        # empirical Fisher (EFInterface / CurvlinopsEF) and Monte-Carlo Fisher (stochastic=True) of the same model; the
+        # labels the reference draws (curvlinops/kfac.py:698-745, curvature.py:343-364) are recorded: the device path
+        # takes them as an input, a random stream cannot be reproduced across devices
+        cv, ccl = ns.curvature, ns.curvature_curvlinops
+        ef = cv.EFInterface(model, "classification")
+        Gs, l0 = ef.gradients(train_idx, train_y)
+        out["ef_grads"], out["ef_loss"] = Gs.detach().numpy().astype(np.float32), np.float32(float(l0))
+        out["ef_diag"] = ef.diag(train_idx, train_y)[1].detach().numpy().astype(np.float32)
+        out["ef_full"] = ef.full(train_idx, train_y)[1].detach().numpy().astype(np.float32)
+        le = bl.KronLaplace(model, "classification", backend=ccl.CurvlinopsEF)
+        le.fit(loader)
+        out["ef_kron_loss"] = np.float32(float(le.loss))
+        for i, Fs in enumerate(le.H_facs.kfacs):
+            for j, Hm in enumerate(Fs):
+                out[f"ef_kron_{i}_{j}"] = Hm.detach().numpy().astype(np.float32)
+        lde = bl.DiagLaplace(model, "classification", backend=ccl.CurvlinopsEF)
+        lde.fit(loader)
+        out["ef_diag_fit"] = lde.H.detach().numpy().astype(np.float32)
+        # regression EF (MSELoss gradient 2 (f - y), factor 0.5)
+        efr = cv.EFInterface(model, "regression")
+        out["reg_ef_diag"] = efr.diag(train_idx, reg_y)[1].detach().numpy().astype(np.float32)
+        ler = bl.KronLaplace(model, "regression", backend=ccl.CurvlinopsEF)
+        ler.fit(rloader)
+        for i, Fs in enumerate(ler.H_facs.kfacs):
+            for j, Hm in enumerate(Fs):
+                out[f"reg_ef_kron_{i}_{j}"] = Hm.detach().numpy().astype(np.float32)
+        # MC Fisher KFAC, 3 samples per batch
+        drawn = []
+        orig_draw = ns.kfac.KFACLinearOperator.draw_label
+
+        def recording_draw(self, output):
+            r = orig_draw(self, output)
+            drawn.append(r.clone())
+            return r
+        ns.kfac.KFACLinearOperator.draw_label = recording_draw
+        try:
+            lm = bl.KronLaplace(model, "classification", backend=ccl.CurvlinopsGGN, backend_kwargs=dict(stochastic=True),
+                                asdl_fisher_kwargs=dict(mc_samples=3))
+            lm.fit(loader)
+        finally:
+            ns.kfac.KFACLinearOperator.draw_label = orig_draw
+        out["mc_samples"] = 3
+        out["mc_kron_loss"] = np.float32(float(lm.loss))
+        for i, Fs in enumerate(lm.H_facs.kfacs):
+            for j, Hm in enumerate(Fs):
+                out[f"mc_kron_{i}_{j}"] = Hm.detach().numpy().astype(np.float32)
+        for q, lab in enumerate(drawn):  # batch t = q // 3, sample s = q % 3
+            out[f"mc_labels_{q // 3}_{q % 3}"] = lab.numpy()
+        # MC functional Fisher in the Jacobian route (GGNInterface, stochastic=True, 2 samples): one-hot draws recorded
+        hot = []
+        Mn = torch.distributions.Multinomial
+        orig_sample = Mn.sample
+
+        def recording_sample(self, *a, **k):
+            r = orig_sample(self, *a, **k)
+            hot.append(r.clone())
+            return r
+        Mn.sample = recording_sample
+        try:
+            gmc = cv.GGNInterface(model, "classification", stochastic=True, num_samples=2)
+            out["ggnmc_diag"] = gmc.diag(train_idx, train_y)[1].detach().numpy().astype(np.float32)
+            first = [h_.argmax(-1).numpy() for h_ in hot]
+            hot.clear()
+            out["ggnmc_full"] = gmc.full(train_idx, train_y)[1].detach().numpy().astype(np.float32)
+            second = [h_.argmax(-1).numpy() for h_ in hot]
+        finally:
+            Mn.sample = orig_sample
+        out["ggnmc_labels_diag"], out["ggnmc_labels_full"] = np.stack(first), np.stack(second)
+
     if kind == "gcn" and layers == 2:
         # 8(f)-4: what the GNN driver differentiates (gnn/marglik_training.py:197-216): -log marglik of a KronLaplace fit
         # w.r.t. the dense adjacency parameter of the STE model (gnn/models/models.py:65-118), same weights (same seed,
