@@ -170,6 +170,15 @@ LGNN_API int lgnn_kfac_plan(int kind, int num_layers, const int64_t* dims /* hos
 LGNN_API int lgnn_diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags,
                          float* diag_out /* [P] */, float* loss_out, void* stream);
 
+/* ---- full GGN over all weights of one mini-batch ---------------------------------------------------------------
+ * Replaces CurvlinopsInterface.full (laplace/curvature/curvlinops.py:110-140: GGNLinearOperator @ I, one GGN-vector
+ * product per column, curvlinops/ggn.py:44-75) = GGNInterface.full (laplace/curvature/curvature.py:374-410):
+ * H_out[P, P] += sum_n J_n^T Lambda_n J_n (regression: sum_n J_n^T J_n, no factor), parameters in named_parameters
+ * order; *loss_out += loss(model(idx), y) without the interface factor.  Chunks of per-sample Jacobians are mixed in
+ * place with the Hessian square root and contracted by the fp32 MFMA Gram kernel; for models whose P x P fits.     */
+LGNN_API int lgnn_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out, float* loss_out,
+                         void* stream);
+
 /* ---- last-layer full GGN of one mini-batch ------------------------------------------------------
  * Replaces GGNInterface.full with last_layer_jacobians (laplace/curvature/curvature.py:132-167,
  * 374-410): J_n = [I_C (x) phi_n^T | s_n I_C], H_out[P_ll, P_ll] += sum_n J_n^T Lambda_n J_n,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "lgnn_ef_accumulate": (_i32, [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "lgnn_kfac_plan": (_i32, [_i32, _i32, C.POINTER(_i64), _i64, _i64, _i32, _u32, _i64, C.POINTER(_i64)]),
     "lgnn_diag_accumulate": (_i32, [_vp, _vp, _vp, _i64, _u32, _vp, _vp, _vp]),
+    "lgnn_full_accumulate": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "lgnn_lastlayer_full_accumulate": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "lgnn_check_async_errors": (_i32, [_vp, _vp]),
     "lgnn_enable_kernel_timing": (_i32, [_vp, _i32]),

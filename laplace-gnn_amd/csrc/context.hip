@@ -353,3 +353,9 @@ extern "C" int lgnn_ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y
   return ef_accumulate(h, idx, y_seed, y_loss, M, resid_scale, scale, diag_out, full_out, grads_out, loss_out,
                        static_cast<hipStream_t>(stream));
 }
+
+extern "C" int lgnn_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out, float* loss_out,
+                                    void* stream) {
+  if (!h) { set_error("null context"); return 2; }
+  return full_accumulate(h, idx, y, M, H_out, loss_out, static_cast<hipStream_t>(stream));
+}

@@ -381,6 +381,50 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
 
 int gram_rows_sgemm(const float* G, int64_t rows, int64_t P, float scale, float* out, hipStream_t s);  // jacobian.hip
 
+// Full GGN over all weights (GGNInterface.full, laplace/curvature/curvature.py:374-410; the reference's default backend
+// applies a matrix-free GGN to the P columns of the identity, curvlinops/ggn.py:44-75 via laplace/curvature/
+// curvlinops.py:110-140): H = sum_n J_n^T Lambda_n J_n with Lambda_n = S_n S_n^T, S[k, c] = sqrt(p_c) (d_kc - p_k), so
+// H = X^T X for the rows X[(n, c), :] = sum_k S_n[k, c] J[n, k, :] = sqrt(p_c) (J[n, c, :] - sum_k p_k J[n, k, :]) -- one
+// in-place row mixing pass over a chunk of device Jacobians, then the fp32 MFMA Gram kernel (upper sub-tiles) straight
+// into the caller's H.  Regression (H_lik = None): X = J.
+__global__ __launch_bounds__(256) void ggn_mix_rows_kernel(float* __restrict__ J, const float* __restrict__ probs,
+                                                           int64_t mc, int64_t C, int64_t P) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t m = blockIdx.y;
+  if (p >= P) return;
+  float* __restrict__ Jm = J + m * C * P + p;
+  const float* __restrict__ pm = probs + m * C;
+  float t = 0.f;
+  for (int64_t k = 0; k < C; ++k) t += pm[k] * Jm[k * P];
+  for (int64_t c = 0; c < C; ++c) Jm[c * P] = sqrtf(pm[c]) * (Jm[c * P] - t);
+}
+
+int full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out, float* loss_out,
+                    hipStream_t s) {
+  LGNN_REQUIRE(M > 0 && idx && y && H_out && loss_out, "empty batch or null pointers");
+  LGNN_REQUIRE(h->L >= 1, "no model bound");
+  LGNN_CALL(forward_ensure(h, s));
+  const int64_t C = h->dims[h->L], P = h->n_params;
+  LGNN_REQUIRE(P * P < (int64_t(1) << 40), "full GGN: P x P does not fit");
+  LGNN_CALL(batch_prologue(h, idx, y, M, false, false, loss_out, s));
+  const int64_t mc_max = std::max<int64_t>(1, std::min<int64_t>(M, (h->ws_limit / 4) / std::max<int64_t>(C * P * 4, 1)));
+  LGNN_CALL(h->ws.jac.reserve(size_t(mc_max) * C * P * 4));
+  float* J = h->ws.jac.as<float>();
+  for (int64_t m0 = 0; m0 < M; m0 += mc_max) {
+    const int64_t mc = std::min(mc_max, M - m0);
+    LGNN_CALL(jacobians(h, idx + m0, mc, J, nullptr, s));
+    if (h->lik != LGNN_LIK_REGRESSION) {
+      hipLaunchKernelGGL(ggn_mix_rows_kernel, dim3(unsigned(cdiv(P, 256)), unsigned(mc)), dim3(256), 0, s, J,
+                         h->ws.probs.as<float>() + m0 * C, mc, C, P);
+      LGNN_HIP_CHECK(hipGetLastError());
+    }
+    LGNN_CALL(launch_gram(J, P, mc * C, P, H_out, s));
+  }
+  LGNN_CALL(launch_symmetrize_upper(H_out, P, s));
+  LGNN_CALL(batch_epilogue(h, idx, M, s));
+  return 0;
+}
+
 int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const void* y_loss, int64_t M, float resid_scale,
                   float scale, float* diag_out, float* full_out, float* grads_out, float* loss_out, hipStream_t s) {
   LGNN_REQUIRE(M > 0 && idx && y_seed, "empty batch or null pointers");

@@ -273,6 +273,7 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
                     float* loss_out, hipStream_t s);
 int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out,
                               float* loss_out, hipStream_t s);
+int full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out, float* loss_out, hipStream_t s);
 int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const void* y_loss, int64_t M, float resid_scale,
                   float scale, float* diag_out, float* full_out, float* grads_out, float* loss_out, hipStream_t s);
 // ---- jacobian.hip -----------------------------------------------------------------------

@@ -194,7 +194,7 @@ class HipCurvatureInterface:
         if self.stochastic and not self.last_layer:
             return self._mc_functional_fisher(x, y, full=True, mc_labels=mc_labels)
         if not self.last_layer:
-            return self._full_from_jacobians(x, y)
+            return self._full_all_weights(x, y)
         eng = self.engine
         p_ll = eng.in_dims[-1] * eng.dims[-1] + eng.dims[-1]
         H = torch.zeros(p_ll, p_ll, dtype=torch.float32, device=eng.device)
@@ -210,41 +210,20 @@ class HipCurvatureInterface:
         self.engine.set_likelihood("classification")
         self.engine.lastlayer_full_accumulate(x, y, H, loss_buf)
 
-    def _regression_from_jacobians(self, x: torch.Tensor, y: torch.Tensor, full: bool, chunk: int = 0):
-        """Regression GGN (H_lik = None, laplace/curvature/curvature.py:406-407, 429-430): ``H = sum J^T J`` resp.
-        its diagonal -- no factor on H -- and ``loss = 0.5 * MSE_sum``; Jacobians from the HIP engine."""
+    def _full_all_weights(self, x: torch.Tensor, y: torch.Tensor):
+        """Full GGN over all weights, ``H = sum_n J_n^T Lambda_n J_n`` (GGNInterface.full, laplace/curvature/curvature.py:
+        374-410; the reference's default backend routes this case through un-vendored backpack, the same matrix): device
+        Jacobians in chunks, mixed with the Hessian square root and contracted by the MFMA Gram kernel
+        (``lgnn_full_accumulate``).  Regression: ``sum J^T J`` (H_lik = None, :406-407), no factor on H."""
         eng = self.engine
-        C, P = eng.dims[-1], eng.n_params
-        H = torch.zeros((P, P) if full else (P,), dtype=torch.float32, device=eng.device)
-        loss = torch.zeros((), dtype=torch.float32, device=eng.device)
-        if chunk <= 0:
-            chunk = max(1, min(len(x), (1 << 28) // max(C * P, 1)))
-        for s in range(0, len(x), chunk):
-            Js, f = eng.jacobians(x[s:s + chunk])
-            H += Js.reshape(-1, P).T @ Js.reshape(-1, P) if full else (Js * Js).sum(dim=(0, 1))
-            loss = loss + self.lossfunc(f, y[s:s + chunk].to(f.dtype).reshape(f.shape))
-        return self.factor * loss, H
-
-    def _full_from_jacobians(self, x: torch.Tensor, y: torch.Tensor, chunk: int = 0):
-        """Full GGN over all weights, ``H = sum_n J_n^T Lambda_n J_n`` with ``Lambda_n = diag(p_n) - p_n p_n^T``:
-        GGNInterface.full (laplace/curvature/curvature.py:374-410; the reference's default backend routes this case
-        through un-vendored backpack, the einsum form is the same matrix).  The Jacobians come from the HIP engine
-        (csrc/jacobian.hip) in chunks of samples; the P x P contraction is one library GEMM per chunk."""
-        if self.likelihood == "regression":
-            return self._regression_from_jacobians(x, y, full=True, chunk=chunk)
-        eng = self.engine
-        C, P = eng.dims[-1], eng.n_params
+        eng.set_likelihood(self.likelihood)
+        P = eng.n_params
         H = torch.zeros(P, P, dtype=torch.float32, device=eng.device)
-        loss = torch.zeros((), dtype=torch.float32, device=eng.device)
-        if chunk <= 0:  # keep a chunk's Jacobians around 1 GiB
-            chunk = max(1, min(len(x), (1 << 28) // max(C * P, 1)))
-        for s in range(0, len(x), chunk):
-            Js, f = eng.jacobians(x[s:s + chunk])
-            p = torch.softmax(f, dim=-1)
-            K = p.unsqueeze(-1) * Js - p.unsqueeze(-1) * torch.einsum("mc,mcp->mp", p, Js).unsqueeze(1)  # Lambda J
-            H += Js.reshape(-1, P).T @ K.reshape(-1, P)
-            loss = loss + self.lossfunc(f, y[s:s + chunk])
-        return self.factor * loss, self.factor * H
+        loss = torch.zeros(1, dtype=torch.float32, device=eng.device)
+        eng.full_accumulate(x, y, H, loss)
+        if self.likelihood == "regression":
+            return self.factor * loss[0], H
+        return self.factor * loss[0], self.factor * H
 
     def check_async_errors(self):
         self.engine.check_async_errors()

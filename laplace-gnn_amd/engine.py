@@ -307,6 +307,15 @@ class GraphEngine:
             _dev_ptr(diag, torch.float32, "diag"), loss.data_ptr(), _stream(self.device))
         _lib.check(rc, "lgnn_diag_accumulate")
 
+    def full_accumulate(self, idx, y, H: torch.Tensor, loss: torch.Tensor):
+        """H [P, P] += full GGN of the batch over all weights (regression binding: sum J^T J), loss += raw loss sum."""
+        self._sync_versions()
+        idx = idx.contiguous()
+        rc = self.lib.lgnn_full_accumulate(
+            self._h, _dev_ptr(idx, torch.int64, "idx"), self._labels(y, idx.shape[0]), idx.shape[0],
+            _dev_ptr(H, torch.float32, "H"), loss.data_ptr(), _stream(self.device))
+        _lib.check(rc, "lgnn_full_accumulate")
+
     def lastlayer_full_accumulate(self, idx, y, H: torch.Tensor, loss: torch.Tensor):
         self._sync_versions()
         idx, y = idx.contiguous(), y.contiguous()

@@ -74,6 +74,46 @@ class OracleEngine:
         diag += torch.from_numpy(H)
         loss += float(l) * (2.0 if self.likelihood == "regression" else 1.0)
 
+    def full_accumulate(self, idx, y, H, loss):
+        self.calls.append(("full", tuple(idx.tolist())))
+        l, Hb = O.full_batch(self._om(), idx.numpy(), y.numpy(), self.likelihood)
+        H += torch.from_numpy(Hb)
+        loss += float(l) * (2.0 if self.likelihood == "regression" else 1.0)
+
+    def kfac_accumulate_fisher(self, idx, y_seed, y_loss, n_train, views, loss, resid_scale=1.0, b_scale=1.0, fuse=True):
+        self.calls.append(("kfac_fisher", tuple(idx.tolist())))
+        om = self._om()
+        out, _, _ = O.forward_all(om)
+        r = O.fisher_residual(out[idx.numpy()], y_seed.numpy(), self.likelihood, resid_scale)
+        first = y_loss is not None
+        l, kfacs = O.kfac_batch(om, idx.numpy(), (y_loss if first else y_seed).numpy(), n_train,
+                                likelihood="classification", seed_override=r[:, :, None] * np.sqrt(b_scale))
+        for k, (A, B) in enumerate(views):
+            B += torch.from_numpy(np.ascontiguousarray(kfacs[2 * k][0]))
+            if first:
+                A += torch.from_numpy(np.ascontiguousarray(kfacs[2 * k][1]))
+        if first:
+            f = out[idx.numpy()]
+            if self.likelihood == "regression":
+                d = f - y_loss.numpy().reshape(f.shape)
+                loss += float((d * d).sum())
+            else:
+                loss += float(O.ce_sum(f, y_loss.numpy()))
+
+    def ef_accumulate(self, idx, y_seed, y_loss=None, resid_scale=1.0, scale=1.0, diag=None, full=None, grads=False,
+                      loss=None):
+        self.calls.append(("ef", tuple(idx.tolist())))
+        Gs, _ = O.ef_gradients(self._om(), idx.numpy(), y_seed.numpy(), self.likelihood, resid_scale)
+        G = torch.from_numpy(Gs)
+        if diag is not None:
+            diag += scale * (G * G).sum(0)
+        if full is not None:
+            full += scale * G.T @ G
+        if y_loss is not None and loss is not None:
+            _, l = O.ef_gradients(self._om(), idx.numpy(), y_loss.numpy(), self.likelihood, resid_scale)
+            loss += float(l)
+        return G if grads else None
+
     def lastlayer_full_accumulate(self, idx, y, H, loss):
         self.calls.append(("ll_full", tuple(idx.tolist())))
         l, Hb = O.lastlayer_full_batch(self._om(), idx.numpy(), y.numpy())

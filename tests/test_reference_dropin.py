@@ -150,3 +150,27 @@ def test_reference_rejects_nothing_about_the_class_name(ref):
     """baselaplace.py:142-149 refuses backends whose class name contains 'backpack' / 'asdfghjkl' once a parameter is
     excluded; ours must not trip that."""
     assert "backpack" not in lg.HipGGN.__name__.lower() and "asdfghjkl" not in lg.HipGGN.__name__.lower()
+
+
+def test_reference_fronts_run_on_the_empirical_and_mc_fisher_backends(ref):
+    """``backend=HipEF`` (the CurvlinopsEF counterpart) and ``backend=HipGGN, backend_kwargs=dict(stochastic=True)`` inside
+    the reference's own KronLaplace / DiagLaplace, against the goldens of the reference's own EF / MC backends."""
+    g = np.load(os.path.join(GOLDEN, "gcn_small_1batch_s0.npz"))
+    model = _cpu_model(g)
+    le = ref.baselaplace.KronLaplace(model, "classification", backend=lg.HipEF)
+    le.fit(_loader(g))
+    for i, Fs in enumerate(le.H_facs.kfacs):
+        for j, Hm in enumerate(Fs):
+            assert rel(Hm.numpy(), g[f"ef_kron_{i}_{j}"]) < RTOL, (i, j)
+    ld = ref.baselaplace.DiagLaplace(model, "classification", backend=lg.HipEF)
+    ld.fit(_loader(g))
+    assert rel(ld.H.numpy(), g["ef_diag_fit"]) < RTOL
+    S = int(g["mc_samples"])
+    draws = [torch.from_numpy(g[f"mc_labels_0_{s}"]) for s in range(S)]
+    lm = ref.baselaplace.KronLaplace(model, "classification", backend=lg.HipGGN, backend_kwargs=dict(stochastic=True),
+                                     asdl_fisher_kwargs=dict(mc_labels=draws))
+    lm.fit(_loader(g))
+    assert lm.backend.stochastic
+    for i, Fs in enumerate(lm.H_facs.kfacs):
+        for j, Hm in enumerate(Fs):
+            assert rel(Hm.numpy(), g[f"mc_kron_{i}_{j}"]) < RTOL, (i, j)
