@@ -76,6 +76,9 @@ LGNN_API void lgnn_destroy(lgnn_ctx* h);
 /* nnz of the stored 0/1 adjacency (incl. self loops for GCN).  host value. */
 LGNN_API int64_t lgnn_nnz(const lgnn_ctx* h);
 LGNN_API int64_t lgnn_num_nodes(const lgnn_ctx* h);
+/* Rows of the backward propagation matrix with more than 64 stored entries (hubs): the 256-wide fused kernel receives
+ * them finished from a side kernel instead of gathering them in one wave.  -1 until the first KFAC call built the list. */
+LGNN_API int64_t lgnn_num_long_rows(const lgnn_ctx* h);
 /* 1 if the stored adjacency equals its transpose (then forward and backward share one CSR) */
 LGNN_API int lgnn_is_symmetric(const lgnn_ctx* h);
 

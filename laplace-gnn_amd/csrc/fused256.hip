@@ -133,7 +133,11 @@ __device__ __forceinline__ void mfma_wave(const FusedArgs& a, const float* __res
 // MODE 1: GraphSAGE with ReLU, nothing conditional in the row loop: the self row is a buffer load whose offset is out
 //         of range for rows flagged as all zero (no memory access), the derivative comes from the row's bit mask
 //         (32 B instead of 1 KiB), both fetched one row ahead.
-template <int MODE>
+// HUB: rows with more than 64 stored entries ("long rows": hubs of a power-law graph) are not gathered here -- one wave
+//      would walk thousands of neighbours while its workgroup waits at the barrier -- but arrive finished from
+//      long_rows_spmm (longrows.hip) through a.hub, fetched like MODE 1's self rows: a buffer load whose offset is out of
+//      range (no memory access) for ordinary rows, issued one row ahead of its use.
+template <int MODE, bool HUB>
 __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
   __shared__ float tile[2][KT256][256];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -146,6 +150,8 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
   const int64_t blocks_per_plane = (a.nrows + KT256 - 1) / KT256;
   const int64_t nblocks = blocks_per_plane * a.nplanes;
   const int64_t nb = nblocks > int64_t(blockIdx.x) ? (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  // (Dealing every XCD a contiguous range of each plane's row blocks instead of this round-robin was measured and
+  //  dropped: +10 % per launch on the uniform graph, +18 % on the power-law one -- DESIGN.md section 8.)
 
   if (wave < 4) {
     // ------------------------------------------------ gather waves
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
       }
       return rp;
     };
-    auto load_block_entries = [&](int64_t i, int32_t rp, RowEntries (&ent)[RPWB]) {
+    auto load_block_entries = [&](int64_t i, int32_t rp, int32_t sl, RowEntries (&ent)[RPWB]) {
       int64_t plane = 0, rb = 0;
       if (i < nb) block_coords(i, plane, rb);
 #pragma unroll
@@ -183,9 +189,25 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
         if (i < nb && rb + r < a.nrows) {
           s = __builtin_amdgcn_readlane(rp, r);
           e = __builtin_amdgcn_readlane(rp, r + 1);
+          if constexpr (HUB) {
+            if (__builtin_amdgcn_readlane(sl, r) >= 0) e = s;  // a long row: nothing to gather, it comes from a.hub
+          }
         }
         ent[it] = load_entries(colp, valp, s, e, lane);
       }
+    };
+    // HUB: slot of the block's 32 rows in a.hub (-1: an ordinary row), one per lane, fetched with the row pointers
+    auto load_slot = [&](int64_t i) -> int32_t {
+      int32_t sl = -1;
+      if constexpr (HUB) {
+        if (i < nb) {
+          int64_t plane, rb;
+          block_coords(i, plane, rb);
+          const int64_t r = rb + (lane & 31);
+          if (r < a.nrows) sl = a.long_slot[r];
+        }
+      }
+      return sl;
     };
     // MODE 1: self-row flags of the block's 32 rows, one per lane, fetched with the row pointers
     auto load_fl = [&](int64_t i) -> int32_t {
@@ -198,7 +220,8 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
     RowEntries ent[RPWB], ent_next[RPWB];
     int32_t rp_next = load_rp(0);
     int32_t fl_cur = load_fl(0), fl_next = 0;
-    load_block_entries(0, rp_next, ent);
+    int32_t sl_cur = load_slot(0), sl_next = load_slot(1);
+    load_block_entries(0, rp_next, sl_cur, ent);
     rp_next = load_rp(1);
     for (int64_t i = 0; i <= nb; ++i) {
       if (i < nb && a.debug != 2 && a.debug != 4) {
@@ -231,6 +254,22 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
           }
         };
         fetch_self_mask(0);
+        // HUB: the finished row of a long row (zeros without a memory access for ordinary rows), issued one row ahead
+        // and BEFORE the gathers of the rows behind it, so that waiting for it never waits for those
+        float4 hub_nx = make_float4(0.f, 0.f, 0.f, 0.f);
+        srd_t srd_hub = srd;
+        if constexpr (HUB)
+          srd_hub = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.hub + plane * a.hub_plane_stride), 0,
+                                                      int(uint32_t(a.n_long * a.width * 4)), 0x00020000);
+        auto fetch_hub = [&](int itn) {
+          if constexpr (HUB) {
+            const int32_t slot = __builtin_amdgcn_readlane(sl_cur, itn * 4 + wave);
+            const int32_t soff = slot >= 0 ? int32_t(uint32_t(slot) * uint32_t(a.width * 4)) : int32_t(0xfffffff0u);
+            const u32x4 th = __builtin_amdgcn_raw_buffer_load_b128(srd_hub, voff, soff, 0);
+            hub_nx = make_float4(__uint_as_float(th.x), __uint_as_float(th.y), __uint_as_float(th.z), __uint_as_float(th.w));
+          }
+        };
+        fetch_hub(0);
         // gathers DEPTH rows deep: rows it+1 .. it+DEPTH-1 are in flight while row it is consumed
         float4 x[DEPTH][UNR];
 #pragma unroll
@@ -238,14 +277,16 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
           issue_gathers<true>(ent[d], 0, srd, voff, x[d]);
 #pragma unroll
         for (int it = 0; it < RPWB; ++it) {
+          const float4 hub_row = hub_nx;
+          if (it + 1 < RPWB) fetch_hub(it + 1);
           if (it + DEPTH - 1 < RPWB)
             issue_gathers<true>(ent[it + DEPTH - 1], 0, srd, voff, x[(it + DEPTH - 1) % DEPTH]);
           if (it + DEPTH - 1 == RPWB - 1) {  // all gathers of this block are issued: fetch the next block's rows
-            load_block_entries(i + 1, rp_next, ent_next);
+            load_block_entries(i + 1, rp_next, sl_next, ent_next);
             rp_next = load_rp(i + 2);
             fl_next = load_fl(i + 1);
           }
-          float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+          float4 y = hub_row;  // zeros unless HUB and the row is a long one
           accumulate<true>(y, ent[it], 0, x[it % DEPTH]);
           if (ent[it].nlive > UNR || ent[it].e - ent[it].s > 64)
             gather_rest(y, ent[it], colp, valp, srd, voff, row_bytes, lane);
@@ -284,6 +325,7 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
 #pragma unroll
         for (int it = 0; it < RPWB; ++it) ent[it] = ent_next[it];
         fl_cur = fl_next;
+        if constexpr (HUB) { sl_cur = sl_next; sl_next = load_slot(i + 2); }
       }
       if (a.debug != 4) __syncthreads();
     }
@@ -309,12 +351,16 @@ int launch_spmm_gram256(const FusedArgs& a_in, hipStream_t s) {
   LGNN_REQUIRE(a.nrows * a.in_ld * 4 < (int64_t(1) << 32) - 4096, "plane too large for 32-bit buffer offsets");
   const int64_t nblocks = cdiv(a.nrows, KT256) * a.nplanes;
   const unsigned grid = unsigned(std::min<int64_t>(nblocks, 256));  // one persistent workgroup per CU
+  const bool hub = a.long_slot != nullptr && a.hub != nullptr && a.n_long > 0;
+  LGNN_REQUIRE(!hub || a.n_long * a.width * 4 < (int64_t(1) << 32) - 4096, "long-row buffer too large for 32-bit offsets");
   if (a.self && a.self_rows && a.mask_bits) {
     LGNN_REQUIRE(a.nrows * a.self_ld * 4 < (int64_t(1) << 32) - 4096, "self plane too large for 32-bit buffer offsets");
     LGNN_REQUIRE(a.mask_words * 32 >= a.width, "mask words do not cover the plane width");
-    hipLaunchKernelGGL(spmm_gram256_kernel<1>, dim3(grid), dim3(512), 0, s, a);
+    if (hub) hipLaunchKernelGGL((spmm_gram256_kernel<1, true>), dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((spmm_gram256_kernel<1, false>), dim3(grid), dim3(512), 0, s, a);
   } else {
-    hipLaunchKernelGGL(spmm_gram256_kernel<0>, dim3(grid), dim3(512), 0, s, a);
+    if (hub) hipLaunchKernelGGL((spmm_gram256_kernel<0, true>), dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((spmm_gram256_kernel<0, false>), dim3(grid), dim3(512), 0, s, a);
   }
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;

@@ -520,6 +520,20 @@ int record_event(lgnn_ctx* h, hipStream_t s) {
   return 0;
 }
 
+// 256-wide fused kernel: rows of P^T with more than kLongRow stored entries are computed by whole workgroups first
+// (longrows.hip) and handed over as finished rows; the list is built on the first call (one stream synchronisation).
+static int attach_long_rows(lgnn_ctx* h, FusedArgs& a, hipStream_t s) {
+  if (a.width <= 128) return 0;  // the narrower kernels keep their own row loop
+  LGNN_CALL(long_rows_ensure(h, s));
+  if (h->n_long <= 0) return 0;
+  LGNN_CALL(launch_long_rows_spmm(h, a.val, a.in, a.in_ld, a.in_plane_stride, a.nplanes, a.width, s));
+  a.long_slot = h->long_slot.as<int32_t>();
+  a.hub = h->hub.as<float>();
+  a.hub_plane_stride = h->n_long * a.width;
+  a.n_long = h->n_long;
+  return 0;
+}
+
 // Every path decision of kfac_accumulate as a pure function of the shapes (base pointers come from hipMalloc and
 // are 256-byte aligned, so alignment follows from the widths).  One helper serves the launch loop, the workspace
 // sizing (need_pong, cc_max) and lgnn_kfac_plan, so that the prediction cannot drift from what the loop does.
@@ -781,6 +795,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           a.store = store ? pong : nullptr; a.store_ld = d; a.store_plane_stride = N * d;
           a.width = d; a.scratch = scratch;
           if (fuse_here) {
+            LGNN_CALL(attach_long_rows(h, a, s));
             if (h->timing && dominant) LGNN_CALL(record_event(h, s));
             LGNN_CALL(launch_spmm_gram_ex(a, s));
             if (h->timing && dominant) { LGNN_CALL(record_event(h, s)); h->ev_planes += cc; }
@@ -834,6 +849,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           a.store = store ? pong : nullptr; a.store_ld = d; a.store_plane_stride = N * d;
           a.width = d; a.scratch = scratch;
           if (plan.fuse[l]) {
+            LGNN_CALL(attach_long_rows(h, a, s));
             if (h->timing && dominant) LGNN_CALL(record_event(h, s));
             LGNN_CALL(launch_spmm_gram_ex(a, s));
             if (h->timing && dominant) { LGNN_CALL(record_event(h, s)); h->ev_planes += cc; }

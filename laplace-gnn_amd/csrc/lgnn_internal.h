@@ -122,6 +122,10 @@ struct lgnn_ctx {
   lgnn::ForwardCache fc;
   lgnn::Workspace ws;
   int64_t ws_limit = int64_t(32) << 30;  // backward planes (ping + pong) per class chunk: 288 GB of HBM, keep chunks large
+  // rows of P^T with more than kLongRow stored entries (hubs), built once on first use (longrows.hip)
+  int64_t n_long = -1;             // -1: not looked at yet
+  int64_t n_long_tasks = 0;
+  lgnn::DevBuf long_rows, long_slot, long_tasks, hub;
   // timing of the dominant kernel
   bool timing = false;
   std::vector<hipEvent_t> ev;   // pairs (start, stop), grown on demand
@@ -166,6 +170,9 @@ struct FusedArgs {
   int64_t width;     // D <= DT
   float* scratch;    // [D, D]
   int debug;         // dev experiments: 1 = skip MFMAs, 2 = skip gathers
+  // 256-wide kernel: rows with more than 64 stored entries arrive finished from long_rows_spmm (longrows.hip):
+  // long_slot[row] = slot in hub (-1: ordinary row), hub [plane][n_long][width]
+  const int32_t* long_slot; const float* hub; int64_t hub_plane_stride; int64_t n_long;
 };
 
 struct BackGemmArgs {
@@ -239,6 +246,12 @@ int launch_fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s);
 int launch_gather_rows(const float* in, int64_t ld, int64_t nrows_in, const int64_t* idx, int64_t M, int64_t width,
                        float* out, int* bad_flag, hipStream_t s);
 
+// ---- longrows.hip -----------------------------------------------------------------------
+constexpr int kLongRow = 64;  // rows of P^T with more stored entries leave the fused kernel's per-wave gather
+int long_rows_ensure(lgnn_ctx* h, hipStream_t s);  // builds h->long_* once (synchronises the stream that one time)
+// hub[plane][slot][0:width) = sum_j val[j] * in[plane][col[j]][0:width) for the long rows of P^T
+int launch_long_rows_spmm(lgnn_ctx* h, const float* val, const float* in, int64_t in_ld, int64_t in_plane_stride,
+                          int64_t nplanes, int64_t width, hipStream_t s);
 // ---- kfac.hip ---------------------------------------------------------------------------
 struct KfacPlan {
   bool seeds_on_the_fly;       // GCN top layer rebuilds the seed blocks from probabilities + logits

@@ -91,6 +91,11 @@ class GraphEngine:
     def is_symmetric(self) -> bool:
         return bool(self.lib.lgnn_is_symmetric(self._h))
 
+    @property
+    def num_long_rows(self) -> int:
+        """Rows with more than 64 stored entries that the 256-wide fused kernel takes from the side kernel (-1: not built)."""
+        return int(self.lib.lgnn_num_long_rows(self._h))
+
     def export_adj(self):
         nnz = self.nnz
         rows = torch.empty(nnz, dtype=torch.int64, device=self.device)

@@ -260,6 +260,37 @@ def test_kfac_kernel_variants_vs_oracle(kind, H, C, L):
     eng.close()
 
 
+@pytest.mark.parametrize("kind,H,L", [("gcn", 256, 2), ("sage", 256, 2), ("gcn", 192, 3), ("sage", 132, 3)])
+def test_long_rows_take_the_side_kernel_vs_oracle(kind, H, L):
+    """Hub rows (more than 64 stored entries, up to thousands) leave the 256-wide fused kernel's per-wave gather: a side
+    kernel computes them with whole workgroups (rows longer than 1 024 entries split over several, float atomics) and the
+    fused kernel fetches the finished rows -- MODE 0 and MODE 1, stored planes for three layers, class chunks."""
+    N, F, C, E = 5000, 32, 6, 20000
+    ei, X, Ws, bs = _make(kind, N, F, H, C, E, L=L, seed=41)
+    g = torch.Generator().manual_seed(2)
+    hubs = []  # hubs of 2 600 / 1 100 / 300 / 90 / 65 neighbours on top of the uniform background
+    for hub, deg in ((7, 2600), (1234, 1100), (4999, 300), (42, 90), (3000, 65)):
+        nb = torch.randperm(N, generator=g)[:deg]
+        hubs.append(torch.stack([torch.full((deg,), hub), nb]))
+    ei = torch.cat([ei] + hubs, dim=1)
+    idx = torch.randperm(N, generator=g)[:600]
+    y = torch.randint(0, C, (600,), generator=g)
+    eng = _engine(kind, N, ei, X, Ws, bs)
+    eng.set_workspace_limit(96 << 20)
+    views, loss = kfac_fit_engine(eng, idx.cuda(), y.cuda(), 250)  # 250 / 250 / 100
+    assert eng.num_long_rows >= 5, eng.num_long_rows
+    rows, _ = eng.export_adj()
+    assert int(torch.bincount(rows, minlength=N).max()) > 1024  # at least one row is split over several tasks
+    om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], True)
+    oloss, oH = O.fit_kron(om, idx.numpy(), y.numpy(), 250)
+    for l, (A, B) in enumerate(views):
+        assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL, f"B_{l}"
+        assert rel(A.cpu().numpy(), oH[2 * l][1]) < RTOL, f"A_{l}"
+    assert abs(loss - float(oloss)) < RTOL * abs(float(oloss))
+    eng.check_async_errors()
+    eng.close()
+
+
 def _random_config(seed):
     r = np.random.default_rng(seed)
     kind = "gcn" if r.random() < 0.6 else "sage"
