@@ -189,6 +189,16 @@ LGNN_API int lgnn_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y
 LGNN_API int lgnn_lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M,
                                    float* H_out, float* loss_out, void* stream);
 
+/* The same matrix accumulated in its natural layout: H = sum_n Lambda_n (x) phi~_n phi~_n^T, so block (c, c') of H is the
+ * weighted Gram Phi~^T diag(Lambda[:, c, c']) Phi~ -- symmetric in (c, c') and inside the block.  S_pairs
+ * [C (C + 1) / 2][D][D] (pairs c <= c' row major; the upper 32 x 32 sub-tiles of each block are valid) and Sb_pairs
+ * [C (C + 1) / 2][D + 1] (bias column of each block) are caller-owned and ADDED to: a fit accumulates every batch
+ * there (a data-parallel caller all-reduces them: half the bytes of H) and calls lgnn_lastlayer_pairs_place ONCE,
+ * which adds the blocks into H_out [P_ll, P_ll] and mirrors the upper triangle.                                  */
+LGNN_API int lgnn_lastlayer_pairs_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* S_pairs,
+                                    float* Sb_pairs, float* loss_out, void* stream);
+LGNN_API int lgnn_lastlayer_pairs_place(lgnn_ctx* h, const float* S_pairs, const float* Sb_pairs, float* H_out, void* stream);
+
 /* Invalid batch contents (node ids outside [0, N), labels outside [0, C)) are detected on the device: such
  * samples contribute nothing and a sticky flag is raised.  This call synchronises `stream`, reports the flag
  * (non-zero return + message) and clears it; call it once per fit, not per batch.                          */

@@ -360,3 +360,13 @@ extern "C" int lgnn_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void*
   if (!h) { set_error("null context"); return 2; }
   return full_accumulate(h, idx, y, M, H_out, loss_out, static_cast<hipStream_t>(stream));
 }
+
+extern "C" int lgnn_lastlayer_pairs_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* S_pairs,
+                                               float* Sb_pairs, float* loss_out, void* stream) {
+  if (!h) { set_error("null context"); return 2; }
+  return lastlayer_pairs_accumulate(h, idx, y, M, S_pairs, Sb_pairs, loss_out, static_cast<hipStream_t>(stream));
+}
+extern "C" int lgnn_lastlayer_pairs_place(lgnn_ctx* h, const float* S_pairs, const float* Sb_pairs, float* H_out, void* stream) {
+  if (!h) { set_error("null context"); return 2; }
+  return lastlayer_pairs_place(h, S_pairs, Sb_pairs, H_out, static_cast<hipStream_t>(stream));
+}

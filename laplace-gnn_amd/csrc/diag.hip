@@ -196,28 +196,51 @@ __global__ void ll_pair_weights_kernel(const float* __restrict__ probs, const in
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) zsign[q] = c == c2 ? 1.f : -1.f;
 }
-// S[q] [D x D] (upper sub-tiles valid) and Sb[q] [D + 1] (bias column) -> upper triangle of H.
+// S[q] [D x D] (upper 32 x 32 sub-tiles valid) and Sb[q] [D + 1] (bias column) -> upper triangle of H.
 // H index of (class c, column a): a < D -> c * D + a, a == D (bias) -> C * D + c.
-__global__ void ll_place_pairs_kernel(const float* __restrict__ S, const float* __restrict__ Sb, int64_t D, int64_t C,
-                                      int64_t q0, float* __restrict__ Hout) {
-  const int64_t D1 = D + 1, P = C * D + C;
-  const int64_t q = blockIdx.y;
+// One workgroup per (32 x 32 tile (ti <= tj) of the block, pair): the tile goes through LDS so that the block's (ti, tj)
+// part and -- for c < c' or an off-diagonal tile -- its mirror image (tj, ti) are both written with coalesced rows.
+__global__ __launch_bounds__(256) void ll_place_tiles_kernel(const float* __restrict__ S, int64_t D, int64_t C, int64_t q0,
+                                                             float* __restrict__ Hout) {
+  __shared__ float t[32][33];
+  const int64_t P = C * D + C;
   int64_t c, c2;
-  pair_of(q0 + q, C, c, c2);
-  const float* __restrict__ Sq = S + q * D * D;
-  const float* __restrict__ Sbq = Sb + q * D1;
-  const int64_t total = D1 * D1;
+  pair_of(q0 + blockIdx.z, C, c, c2);
+  const int64_t ti = blockIdx.y, tj = blockIdx.x;
+  if (ti > tj) return;
+  const float* __restrict__ Sq = S + int64_t(blockIdx.z) * D * D;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = ti * 32 + r, j = tj * 32 + tx;
+    t[r][tx] = (i < D && j < D) ? Sq[i * D + j] : 0.f;
+  }
+  __syncthreads();
+  // block element (i, j) -> H[c D + i][c2 D + j]   (c <= c2: always in the upper triangle for c < c2; for c == c2 keep i <= j)
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = ti * 32 + r, j = tj * 32 + tx;
+    if (i < D && j < D && (c < c2 || i <= j)) Hout[(c * D + i) * P + c2 * D + j] += t[r][tx];
+  }
+  if (ti < tj && c < c2) {  // the block is symmetric: element (j, i) of it equals (i, j); rows j of H, coalesced over i
+    for (int r = ty; r < 32; r += 8) {
+      const int64_t j = tj * 32 + r, i = ti * 32 + tx;
+      if (i < D && j < D) Hout[(c * D + j) * P + c2 * D + i] += t[tx][r];
+    }
+  }
+}
+// bias column of every block: H[(c, a)][(bias c2)] and H[(c2, a)][(bias c)] for a < D, H[bias c][bias c2]
+__global__ void ll_place_bias_kernel(const float* __restrict__ Sb, int64_t D, int64_t C, int64_t q0, int64_t nq,
+                                     float* __restrict__ Hout) {
+  const int64_t D1 = D + 1, P = C * D + C;
+  const int64_t total = nq * D1;
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t a = t / D1, b = t - a * D1;
-    if (c == c2 && a > b) continue;  // diagonal pair: its own upper half only
-    float v;
-    if (a < D && b < D) v = Sq[(a < b ? a : b) * D + (a < b ? b : a)];
-    else v = Sbq[a == D ? b : a];  // (bias, j) or (j, bias); (bias, bias) = Sbq[D]
-    const int64_t ra = a < D ? c * D + a : C * D + c;
-    const int64_t rb = b < D ? c2 * D + b : C * D + c2;
-    const int64_t lo = ra < rb ? ra : rb, hi = ra < rb ? rb : ra;
-    Hout[lo * P + hi] += v;
+  for (int64_t tq = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; tq < total; tq += stride) {
+    const int64_t q = tq / D1, a = tq - q * D1;
+    int64_t c, c2;
+    pair_of(q0 + q, C, c, c2);
+    const float v = Sb[tq];
+    if (a == D) { Hout[(C * D + c) * P + C * D + c2] += v; continue; }  // (bias c, bias c2), c <= c2
+    Hout[(c * D + a) * P + C * D + c2] += v;                            // ((c, a), bias c2): row < column always
+    if (c != c2) Hout[(c2 * D + a) * P + C * D + c] += v;               // ((c2, a), bias c)
   }
 }
 
@@ -460,9 +483,13 @@ int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const voi
   return 0;
 }
 
-int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out,
-                              float* loss_out, hipStream_t s) {
-  LGNN_REQUIRE(M > 0 && idx && y && H_out && loss_out, "empty batch or null pointers");
+// Pair-major accumulation: S [Q][D][D] (upper sub-tiles of each block) and Sb [Q][D + 1] are the CALLER's buffers and are
+// added to -- a fit accumulates all its batches there and places them into H once (lastlayer_pairs_place), instead of one
+// placement (1.2 GB of read-modify-write) + mirror pass per batch; a data-parallel caller all-reduces the pair buffers,
+// half the bytes of H.
+int lastlayer_pairs_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* S, float* Sb,
+                               float* loss_out, hipStream_t s) {
+  LGNN_REQUIRE(M > 0 && idx && y && S && Sb && loss_out, "empty batch or null pointers");
   LGNN_REQUIRE(h->lik == LGNN_LIK_CLASSIFICATION, "last-layer full GGN kernels: classification likelihood");
   LGNN_CALL(forward_ensure_aux(h, s));
   const int L = h->L;
@@ -471,21 +498,17 @@ int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, in
   const float* probs = h->ws.probs.as<float>();
   FeatView Phi;
   feat_views(h, L - 1, Phi);
-  const int64_t D = Phi.width, D1 = D + 1, P = C * D + C;
-
-  // weighted Grams over the class pairs (see the kernels above), in chunks of pairs that fit the workspace cap
+  const int64_t D = Phi.width, D1 = D + 1;
   const int64_t Q = C * (C + 1) / 2, ldp = cdiv(D1, 4) * 4;
-  const int64_t per_pair = (D * D + 2 * M + D1 + 1) * 4;
+  // chunks of pairs: the row-scale / weight vectors [qc][M] live in the workspace
+  const int64_t per_pair = (2 * M + 1) * 4;
   const int64_t qc_max = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(Q, 32768), h->ws_limit / per_pair));
-  LGNN_CALL(h->ws.planes_a.reserve(size_t(M) * ldp * 4 + size_t(qc_max) * (2 * M + D1 + 1) * 4));
+  LGNN_CALL(h->ws.planes_a.reserve(size_t(M) * ldp * 4 + size_t(qc_max) * (2 * M + 1) * 4));
   h->ws.planes_a_zero_ptr = nullptr;
-  LGNN_CALL(h->ws.planes_b.reserve(size_t(qc_max) * D * D * 4));
   float* PhiM = h->ws.planes_a.as<float>();
   float* rs = PhiM + M * ldp;
   float* wsg = rs + qc_max * M;
-  float* Sb = wsg + qc_max * M;
-  float* zsign = Sb + qc_max * D1;
-  float* S = h->ws.planes_b.as<float>();
+  float* zsign = wsg + qc_max * M;
   hipLaunchKernelGGL(ll_build_phi_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M * ldp, 256), 8192))), dim3(256), 0, s,
                      idx, M, Phi, ldp, PhiM);
   LGNN_HIP_CHECK(hipGetLastError());
@@ -494,21 +517,47 @@ int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, in
     hipLaunchKernelGGL(ll_pair_weights_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M, 256), 64)), unsigned(qc)),
                        dim3(256), 0, s, probs, idx, Phi, M, C, q0, rs, wsg, zsign);
     LGNN_HIP_CHECK(hipGetLastError());
-    LGNN_HIP_CHECK(hipMemsetAsync(S, 0, size_t(qc) * D * D * 4, s));
-    // S[q] = sign_q * (diag(rs_q) Phi)^T (diag(rs_q) Phi) over the D feature columns
+    // S[q] += sign_q * (diag(rs_q) Phi)^T (diag(rs_q) Phi) over the D feature columns
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the last-layer path (bench.py roofline)
-    LGNN_CALL(launch_gram_batched(PhiM, ldp, M, D, S, D * D, qc, rs, zsign, 1.0f, s));
+    LGNN_CALL(launch_gram_batched(PhiM, ldp, M, D, S + q0 * D * D, D * D, qc, rs, zsign, 1.0f, s));
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += qc; }
-    // bias column: Sb[q][j] = sum_m w_qm s_m phi~[m][j], one library GEMM [qc x M] * [M x D1]
-    LGNN_CALL(ll_bias_gemm(wsg, PhiM, Sb, qc, M, D1, ldp, s));
-    hipLaunchKernelGGL(ll_place_pairs_kernel, dim3(unsigned(std::min<int64_t>(cdiv(D1 * D1, 256), 1024)), unsigned(qc)),
-                       dim3(256), 0, s, S, Sb, D, C, q0, H_out);
+    // bias column: Sb[q][j] += sum_m w_qm s_m phi~[m][j], one library GEMM [qc x M] * [M x D1]
+    LGNN_CALL(ll_bias_gemm(wsg, PhiM, Sb + q0 * D1, qc, M, D1, ldp, s, 1.0f));
   }
-  LGNN_HIP_CHECK(hipGetLastError());
-  // everything above touched the upper triangle (and the diagonal 32 x 32 blocks); mirror it
-  LGNN_CALL(launch_symmetrize_upper(H_out, P, s));
   LGNN_CALL(batch_epilogue(h, idx, M, s));
   return 0;
+}
+
+// H_out [P, P] += the blocks of the pair-major accumulators (upper triangle), then the mirror pass
+int lastlayer_pairs_place(lgnn_ctx* h, const float* S, const float* Sb, float* H_out, hipStream_t s) {
+  LGNN_REQUIRE(S && Sb && H_out && h->L > 0, "null pointers / no model bound");
+  const int64_t C = h->dims[h->L], D = h->in_dim[h->L - 1], P = C * D + C;
+  const int64_t Q = C * (C + 1) / 2;
+  const unsigned nt = unsigned(cdiv(D, 32));
+  for (int64_t q0 = 0; q0 < Q; q0 += 32768) {
+    const int64_t qc = std::min<int64_t>(32768, Q - q0);
+    hipLaunchKernelGGL(ll_place_tiles_kernel, dim3(nt, nt, unsigned(qc)), dim3(256), 0, s, S + q0 * D * D, D, C, q0, H_out);
+  }
+  hipLaunchKernelGGL(ll_place_bias_kernel, dim3(unsigned(std::min<int64_t>(cdiv(Q * (D + 1), 256), 4096))), dim3(256), 0, s,
+                     Sb, D, C, int64_t(0), Q, H_out);
+  LGNN_HIP_CHECK(hipGetLastError());
+  LGNN_CALL(launch_symmetrize_upper(H_out, P, s));
+  return 0;
+}
+
+// One batch straight into H (the entry point of the first round): pair buffers from the workspace, zeroed, accumulated,
+// placed and mirrored in this call.
+int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out,
+                              float* loss_out, hipStream_t s) {
+  LGNN_REQUIRE(M > 0 && idx && y && H_out && loss_out, "empty batch or null pointers");
+  LGNN_REQUIRE(h->L > 0, "no model bound");
+  const int64_t C = h->dims[h->L], D = h->in_dim[h->L - 1], D1 = D + 1, Q = C * (C + 1) / 2;
+  LGNN_CALL(h->ws.planes_b.reserve(size_t(Q) * (D * D + D1) * 4));
+  float* S = h->ws.planes_b.as<float>();
+  float* Sb = S + Q * D * D;
+  LGNN_HIP_CHECK(hipMemsetAsync(S, 0, size_t(Q) * (D * D + D1) * 4, s));
+  LGNN_CALL(lastlayer_pairs_accumulate(h, idx, y, M, S, Sb, loss_out, s));
+  return lastlayer_pairs_place(h, S, Sb, H_out, s);
 }
 
 }  // namespace lgnn

@@ -65,10 +65,10 @@ __global__ __launch_bounds__(256) void plane_colsum_kernel(const float* __restri
 
 // row major C[Q, D1] = A[Q, M] * B[M, D1] (ld ldp): the bias column of the last-layer pair Grams (diag.hip)
 int ll_bias_gemm(const float* Wq, const float* Phi, float* Sb, int64_t Q, int64_t M, int64_t D1, int64_t ldp,
-                 hipStream_t s) {
+                 hipStream_t s, float beta) {
   rocblas_handle blas = static_cast<rocblas_handle>(blas_handle(s));
   LGNN_REQUIRE(blas != nullptr, "rocBLAS handle");
-  const float one = 1.f, zero = 0.f;
+  const float one = 1.f, zero = beta;
   // column-major view: C^T[D1, Q] = B^T[D1, M] * A^T[M, Q]
   const rocblas_status st = rocblas_sgemm(blas, rocblas_operation_none, rocblas_operation_none, rocblas_int(D1),
                                           rocblas_int(Q), rocblas_int(M), &one, Phi, rocblas_int(ldp), Wq, rocblas_int(M),

@@ -226,7 +226,8 @@ int launch_gram_scaled(const float* X, int64_t ld, int64_t R, int64_t D, float* 
 int launch_gram_batched(const float* X, int64_t ld, int64_t R, int64_t D, float* out, int64_t out_zstride, int64_t nz,
                         const float* row_scale, const float* zscale, float scale, hipStream_t s);
 // row major Sb[Q, D1] = Wq[Q, M] * Phi[M, D1] (rocBLAS; jacobian.hip)
-int ll_bias_gemm(const float* Wq, const float* Phi, float* Sb, int64_t Q, int64_t M, int64_t D1, int64_t ldp, hipStream_t s);
+int ll_bias_gemm(const float* Wq, const float* Phi, float* Sb, int64_t Q, int64_t M, int64_t D1, int64_t ldp, hipStream_t s,
+                 float beta = 0.f);  // Sb = Wq Phi + beta Sb
 // lower triangle <- upper triangle
 int launch_symmetrize_upper(float* H, int64_t D, hipStream_t s);
 // out[i,j] += scale * scratch[min(i,j), max(i,j)]
@@ -286,6 +287,9 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
                     float* loss_out, hipStream_t s);
 int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out,
                               float* loss_out, hipStream_t s);
+int lastlayer_pairs_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* S, float* Sb,
+                               float* loss_out, hipStream_t s);
+int lastlayer_pairs_place(lgnn_ctx* h, const float* S, const float* Sb, float* H_out, hipStream_t s);
 int full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out, float* loss_out, hipStream_t s);
 int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const void* y_loss, int64_t M, float resid_scale,
                   float scale, float* diag_out, float* full_out, float* grads_out, float* loss_out, hipStream_t s);

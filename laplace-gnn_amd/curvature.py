@@ -202,6 +202,14 @@ class HipCurvatureInterface:
         eng.lastlayer_full_accumulate(x, y, H, loss)
         return self.factor * loss[0], H
 
+    def lastlayer_pairs_(self, S: torch.Tensor, Sb: torch.Tensor, loss_buf: torch.Tensor, x: torch.Tensor, y: torch.Tensor):
+        """Last-layer full GGN of one batch added to the caller's pair-major accumulators (``GraphEngine.
+        new_lastlayer_pair_buffers``); ``GraphEngine.lastlayer_pairs_place`` turns them into the P x P matrix once per fit."""
+        if not self.last_layer or self.likelihood != "classification" or self.factor != 1.0:
+            raise NotImplementedError("pair-major accumulation exists for the last-layer classification GGN")
+        self.engine.set_likelihood("classification")
+        self.engine.lastlayer_pairs_accumulate(x, y, S, Sb, loss_buf)
+
     def full_accumulate_(self, H: torch.Tensor, loss_buf: torch.Tensor, x: torch.Tensor, y: torch.Tensor):
         """Last-layer full GGN of one batch added IN PLACE to the caller's ``H`` (and the raw loss to ``loss_buf``): no
         ``P x P`` temporary per batch -- 2.3 GB each at the products shape."""

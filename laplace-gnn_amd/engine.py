@@ -329,6 +329,30 @@ class GraphEngine:
             _dev_ptr(H, torch.float32, "H"), loss.data_ptr(), _stream(self.device))
         _lib.check(rc, "lgnn_lastlayer_full_accumulate")
 
+    def new_lastlayer_pair_buffers(self):
+        """Zeroed pair-major accumulators of the last-layer full GGN as ONE flat buffer [S | Sb | loss] (one all-reduce)
+        plus views: S [Q, D, D], Sb [Q, D + 1], loss [1], Q = C (C + 1) / 2."""
+        C, D = self.dims[-1], self.in_dims[-1]
+        Q = C * (C + 1) // 2
+        flat = torch.zeros(Q * (D * D + D + 1) + 1, dtype=torch.float32, device=self.device)
+        S = flat[:Q * D * D].view(Q, D, D)
+        Sb = flat[Q * D * D:Q * (D * D + D + 1)].view(Q, D + 1)
+        return flat, S, Sb, flat[-1:]
+
+    def lastlayer_pairs_accumulate(self, idx, y, S: torch.Tensor, Sb: torch.Tensor, loss: torch.Tensor):
+        self._sync_versions()
+        idx, y = idx.contiguous(), y.contiguous()
+        rc = self.lib.lgnn_lastlayer_pairs_accumulate(
+            self._h, _dev_ptr(idx, torch.int64, "idx"), _dev_ptr(y, torch.int64, "y"), idx.shape[0],
+            _dev_ptr(S, torch.float32, "S"), _dev_ptr(Sb, torch.float32, "Sb"), loss.data_ptr(), _stream(self.device))
+        _lib.check(rc, "lgnn_lastlayer_pairs_accumulate")
+
+    def lastlayer_pairs_place(self, S: torch.Tensor, Sb: torch.Tensor, H: torch.Tensor):
+        """H [P_ll, P_ll] += the accumulated blocks (upper triangle), then the mirror pass."""
+        rc = self.lib.lgnn_lastlayer_pairs_place(self._h, _dev_ptr(S, torch.float32, "S"), _dev_ptr(Sb, torch.float32, "Sb"),
+                                                 _dev_ptr(H, torch.float32, "H"), _stream(self.device))
+        _lib.check(rc, "lgnn_lastlayer_pairs_place")
+
     def jacobians(self, idx: torch.Tensor):
         """(J [M, C, P], f [M, C]): per-sample Jacobians of the logits w.r.t. all parameters, parameters in
         module order (weight row major, bias) -- laplace/curvature/curvature.py:89-130."""

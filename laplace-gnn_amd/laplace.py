@@ -177,6 +177,7 @@ class ParametricLaplace(BaseLaplace):
         if world > 1:
             all_reduce_flat_(self._reduce_tensors() + [loss], process_group)
             self._after_reduce()
+        self._post_accumulate()  # e.g. the last-layer pair accumulators are placed into H here, once per fit
         if H_prev is not None:
             H_prev += self.H
             self.H = H_prev
@@ -205,6 +206,9 @@ class ParametricLaplace(BaseLaplace):
         pass
 
     def _after_reduce(self):
+        pass
+
+    def _post_accumulate(self):
         pass
 
     # ---- posterior samples and the sampling ("nn", link_approx="mc") predictive the GNN driver evaluates with
@@ -642,13 +646,21 @@ class FullLLLaplace(ParametricLaplace):
     def _init_H(self):
         self.H = torch.zeros(self.n_params, self.n_params, device=self._device)
         self._loss_buf = None
+        self._pairs = None
+
+    def _pair_path(self) -> bool:
+        """HIP backend: the batches of a fit accumulate in the pair-major layout of the weighted Grams and are placed into
+        the P x P matrix once -- no placement / mirror pass per batch (2.3 GB each at the products shape), and the
+        all-reduce of a data-parallel fit moves the pair buffers, half the bytes of H."""
+        return hasattr(self.backend, "lastlayer_pairs_")
 
     def _curv_closure(self, X, y, N):
         be = self.backend
-        if hasattr(be, "full_accumulate_"):  # in-place fast path of the HIP backend: H is 2.3 GB at the products shape
-            if self._loss_buf is None:
-                self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self._device)
-            be.full_accumulate_(self.H, self._loss_buf, X, y)
+        if self._pair_path():
+            if self._pairs is None:
+                self._pairs = be.engine.new_lastlayer_pair_buffers()
+            _, S, Sb, loss_buf = self._pairs
+            be.lastlayer_pairs_(S, Sb, loss_buf, X, y)
             return 0.0, None
         return be.full(X, y, N=N)
 
@@ -658,15 +670,23 @@ class FullLLLaplace(ParametricLaplace):
 
     def fit(self, train_loader, override: bool = True, progress_bar: bool = False, process_group=None) -> None:
         super().fit(train_loader, override=override, progress_bar=progress_bar, process_group=process_group)
-        if self._loss_buf is not None:  # (all-reduced together with H, see _reduce_tensors)
-            self.loss = self.loss + self._loss_buf[0].clone()
+        if self._loss_buf is not None:  # (all-reduced together with the pair buffers, see _reduce_tensors)
+            self.loss = self.loss + self._loss_buf
             self._loss_buf = None
 
     def _reduce_tensors(self):
-        be = self.backend
-        if hasattr(be, "full_accumulate_") and self._loss_buf is None:  # a rank without local samples still reduces
-            self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self._device)
-        return [self.H] + ([self._loss_buf] if self._loss_buf is not None else [])
+        if self._pair_path():
+            if self._pairs is None:  # a rank without local samples still takes part in the all-reduce
+                self._pairs = self.backend.engine.new_lastlayer_pair_buffers()
+            return [self._pairs[0]]  # [S | Sb | loss]: one flat buffer, reduced in place
+        return [self.H]
+
+    def _post_accumulate(self):
+        if self._pairs is not None:
+            _, S, Sb, loss_buf = self._pairs
+            self.backend.engine.lastlayer_pairs_place(S, Sb, self.H)
+            self._loss_buf = self.backend.factor * loss_buf[0].clone()
+            self._pairs = None
 
     @property
     def posterior_precision(self) -> torch.Tensor:
