@@ -507,7 +507,10 @@ __device__ __forceinline__ void gram_flush(float* __restrict__ scratch, int64_t 
   }
 }
 
-template <int DT, int VEC>
+// TILES: 0 = blockIdx.x walks all tile pairs ti <= tj (slots sized for an off-diagonal pair: a diagonal pair then idles
+//            6 of its 16 slots); 1 = diagonal pairs only (one panel, 3 slots per wave for the 10 upper sub-tiles instead
+//            of 4); 2 = off-diagonal pairs only.  Factors wider than one tile are launched as (1) + (2).
+template <int DT, int VEC, int TILES>
 __global__ __launch_bounds__(256) void gram_mem_kernel(const float* __restrict__ X, int64_t ld, int64_t R, int64_t D,
                                                        float* __restrict__ scratch, int64_t rows_per_wg, int ntile,
                                                        float scale, int direct, const float* __restrict__ row_scale,
@@ -518,15 +521,20 @@ __global__ __launch_bounds__(256) void gram_mem_kernel(const float* __restrict__
   scratch += int64_t(blockIdx.z) * out_zstride;
   if (zscale) scale *= zscale[blockIdx.z];
   using Cfg = GramCfg<DT>;
-  constexpr int NSLOT = Cfg::NSLOT;
-  constexpr int PANELS = Cfg::HAS_OFF ? 2 : 1;
+  constexpr int NSLOT = TILES == 1 ? (Cfg::NP_DIAG + 3) / 4 : Cfg::NSLOT;
+  constexpr int PANELS = (Cfg::HAS_OFF && TILES != 1) ? 2 : 1;
   __shared__ float tile[PANELS][KT][DT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // tile pair (ti <= tj) from blockIdx.x
   int ti, tj;
-  decode_upper(int(blockIdx.x), ntile, ti, tj);
+  if (TILES == 1) { ti = tj = int(blockIdx.x); }
+  else if (TILES == 2) {  // strictly upper pairs, row major
+    int p = int(blockIdx.x), i = 0;
+    while (p >= ntile - 1 - i) { p -= ntile - 1 - i; ++i; }
+    ti = i; tj = i + 1 + p;
+  } else decode_upper(int(blockIdx.x), ntile, ti, tj);
   const bool diag = ti == tj;
   const int np = diag ? Cfg::NP_DIAG : Cfg::NP_OFF;
   int si[NSLOT], sj[NSLOT];
@@ -631,14 +639,22 @@ int launch_gram_batched(const float* X, int64_t ld, int64_t R, int64_t D, float*
   const int64_t ksplit = cdiv(R, rows_per_wg);
   LGNN_REQUIRE(ksplit < 65536, "gram split too large");
   const int direct = ksplit == 1 ? 1 : 0;
-  const dim3 grid{unsigned(npairs), unsigned(ksplit), unsigned(nz)};
-#define LGNN_GRAM_LAUNCH(DTV)                                                                                   \
-  if (vec) hipLaunchKernelGGL((gram_mem_kernel<DTV, 4>), grid, dim3(256), 0, s, X, ld, R, D, out, rows_per_wg, ntile, scale, direct, row_scale, out_zstride, zscale); \
-  else hipLaunchKernelGGL((gram_mem_kernel<DTV, 1>), grid, dim3(256), 0, s, X, ld, R, D, out, rows_per_wg, ntile, scale, direct, row_scale, out_zstride, zscale);
+  // several tiles: the diagonal pairs and the off-diagonal pairs as two launches with their own slot counts
+  const bool split = ntile > 1;
+#define LGNN_GRAM_LAUNCH1(DTV, TV, NPAIR)                                                                        \
+  {                                                                                                              \
+    const dim3 grid{unsigned(NPAIR), unsigned(ksplit), unsigned(nz)};                                            \
+    if (vec) hipLaunchKernelGGL((gram_mem_kernel<DTV, 4, TV>), grid, dim3(256), 0, s, X, ld, R, D, out, rows_per_wg, ntile, scale, direct, row_scale, out_zstride, zscale); \
+    else hipLaunchKernelGGL((gram_mem_kernel<DTV, 1, TV>), grid, dim3(256), 0, s, X, ld, R, D, out, rows_per_wg, ntile, scale, direct, row_scale, out_zstride, zscale); \
+  }
+#define LGNN_GRAM_LAUNCH(DTV)                                                          \
+  if (split) { LGNN_GRAM_LAUNCH1(DTV, 1, ntile) LGNN_GRAM_LAUNCH1(DTV, 2, npairs - ntile) } \
+  else LGNN_GRAM_LAUNCH1(DTV, 0, npairs)
   if (dt == 64) { LGNN_GRAM_LAUNCH(64) }
   else if (dt == 128) { LGNN_GRAM_LAUNCH(128) }
-  else { LGNN_GRAM_LAUNCH(256) }
+  else { LGNN_GRAM_LAUNCH1(256, 0, npairs) }
 #undef LGNN_GRAM_LAUNCH
+#undef LGNN_GRAM_LAUNCH1
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }
