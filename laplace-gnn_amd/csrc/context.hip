@@ -150,6 +150,11 @@ int forward_ensure_aux(lgnn_ctx* h, hipStream_t s) {
       LGNN_CALL(launch_spmm(h->P, h->N, h->fc.lin_in_p[l], h->fc.lin_in_ld[l], h->fc.prop_in[l].as<float>(), d, d, 0, s));
     }
   }
+  if (h->L == 2) {  // act'(h_1), contiguous [N, H]: the first-layer diagonal kernel multiplies with it (one FMA per element)
+    const int64_t H = h->dims[1];
+    LGNN_CALL(h->fc.dact0.reserve(size_t(h->N) * H * 4));
+    LGNN_CALL(launch_act_deriv(h->fc.hact_p[0], h->fc.hact_ld[0], h->N, H, h->act, h->fc.dact0.as<float>(), s));
+  }
   h->fc.aux_valid = true;
   return 0;
 }
@@ -191,7 +196,7 @@ extern "C" void lgnn_destroy(lgnn_ctx* h) {
   if (!h) return;
   (void)hipDeviceSynchronize();
   DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
-                    &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult, &h->ws.planes_a,
+                    &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->fc.dact0, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult, &h->ws.planes_a,
                     &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->long_rows, &h->long_slot, &h->long_tasks, &h->hub, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (DevBuf* b : bufs) b->release();
   for (int l = 0; l < kMaxLayers; ++l) {
@@ -256,7 +261,7 @@ extern "C" int64_t lgnn_device_bytes(const lgnn_ctx* h) {
   if (!h) return -1;
   size_t t = 0;
   const DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
-                          &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult,
+                          &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->fc.dact0, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult,
                           &h->ws.planes_a, &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->long_rows, &h->long_slot, &h->long_tasks, &h->hub, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (const DevBuf* b : bufs) t += b->bytes;
   for (int l = 0; l < kMaxLayers; ++l)

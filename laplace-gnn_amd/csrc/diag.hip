@@ -69,74 +69,125 @@ __global__ void q_kernel(const float* __restrict__ probs, int64_t M, int64_t C, 
 }
 
 constexpr int JPT = 16;  // hidden units per thread
+constexpr int DCH = 32;  // (sample, neighbour) entries staged per chunk
 
-// grid (i-chunks of 64, j-chunks of 64, sample slabs); block 256 = 64 i-lanes x 4 j-groups of JPT
+// grid (i-chunks of 64, j-chunks of 64, sample slabs); block 256 = 64 i-lanes x 4 j-groups of JPT.
+//   T[n, j, i] = sum_v P[n, v] act'(h_1[v, j]) E[v, i]     diag(W_0)[j, i] += q[n, j] T^2  (+ the GraphSAGE self terms)
+// At the shapes this runs at (Cora: 16 MB in total) the kernel is bound by load LATENCY, not bytes or flops: a thread
+// that walks its samples' neighbours one after the other waits for one dependent load chain per neighbour (0.25 ms for
+// 1 299 samples).  So the slab's (sample, neighbour) entries are laid out as ONE list -- every sample followed by a
+// virtual entry for the node itself that closes the sample (and carries the self row GraphSAGE needs) -- and consumed in
+// chunks of DCH: wave 0 resolves the chunk's entries (sample, column, value), all four waves then fetch the entries'
+// feature and derivative row slices into LDS with every load of the chunk in flight at once, and the FMAs run from LDS.
+template <int HAS_SELF>
 __global__ __launch_bounds__(256) void diag_first_layer_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
-    const int64_t* __restrict__ idx, int64_t M, int64_t slab, FeatView E, const float* __restrict__ hact,
-    int64_t hact_ld, int act, int64_t H, const float* __restrict__ q, int has_self, float* __restrict__ diag_w,
-    float* __restrict__ diag_b) {
-  const int lane = threadIdx.x & 63, jg = threadIdx.x >> 6;
+    const int64_t* __restrict__ idx, int64_t M, int64_t slab, FeatView E, const float* __restrict__ dact,
+    int64_t H, const float* __restrict__ q, float* __restrict__ diag_w, float* __restrict__ diag_b) {
+  __shared__ float sE[DCH][64], sD[DCH][64], sQ[HAS_SELF ? 3 : 1][DCH][64];
+  __shared__ float sa[DCH];
+  __shared__ int32_t sv[DCH], sm[DCH];  // column (node) of the entry; sample index if the entry closes its sample, else -1
+  __shared__ int32_t soff[65], snode[64];
+  const int tid = threadIdx.x, lane = tid & 63, jg = tid >> 6;
   const int64_t i = int64_t(blockIdx.x) * 64 + lane;
-  const int64_t j0 = int64_t(blockIdx.y) * 64 + jg * JPT;
+  const int64_t j0 = int64_t(blockIdx.y) * 64;
   const int64_t ncols = E.width + 1;
   const bool i_ok = i < ncols;
-  if (j0 >= H) return;
-  const int nj = int(min(int64_t(JPT), H - j0));
-  const bool hvec = (hact_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(hact) & 15) == 0);
-  float acc[JPT];
-#pragma unroll
-  for (int jj = 0; jj < JPT; ++jj) acc[jj] = 0.f;
   const int64_t m_begin = int64_t(blockIdx.z) * slab, m_end = min(M, m_begin + slab);
-  for (int64_t m = m_begin; m < m_end; ++m) {
-    const int64_t node = idx[m];
-    if (node < 0 || node >= E.nrows) continue;  // flagged by the batch prologue
-    float T[JPT];
+  const int ns = int(m_end - m_begin);  // <= 64
+  // entry offsets of the slab's samples: len(row) + 1 each (invalid node ids: 0, flagged by the batch prologue)
+  if (tid < 64) {
+    int32_t len = 0, node = -1;
+    if (tid < ns) {
+      const int64_t n = idx[m_begin + tid];
+      if (n >= 0 && n < E.nrows) { node = int32_t(n); len = rowptr[n + 1] - rowptr[n] + 1; }
+    }
+    snode[tid] = node;
+    int32_t incl = len;  // inclusive scan over the wave
 #pragma unroll
-    for (int jj = 0; jj < JPT; ++jj) T[jj] = 0.f;
-    for (int32_t p = rowptr[node]; p < rowptr[node + 1]; ++p) {
-      const int64_t v = col[p];
-      const float pv = val[p];
-      const float e = i_ok ? feat(E, v, i) * pv : 0.f;
-      const float* __restrict__ hr = hact + v * hact_ld + j0;
-      float hvals[JPT];
-      if (hvec && nj == JPT) {  // 4 x 16-byte broadcast loads instead of 16 scalar ones
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    soff[tid + 1] = incl;
+    if (tid == 0) soff[0] = 0;
+  }
+  __syncthreads();
+  const int32_t etot = soff[64];
+  float acc[JPT], T[JPT];
+#pragma unroll
+  for (int jj = 0; jj < JPT; ++jj) { acc[jj] = 0.f; T[jj] = 0.f; }
+
+  for (int32_t c0 = 0; c0 < etot; c0 += DCH) {
+    const int cn = min(DCH, int(etot - c0));
+    // (1) wave 0: resolve the chunk's entries
+    if (tid < DCH) {
+      int32_t v = 0, mk = -1;
+      float a = 0.f;
+      if (tid < cn) {
+        const int32_t g = c0 + tid;
+        int lo = 0, hi = ns;  // sample k with soff[k] <= g < soff[k + 1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (soff[mid] <= g) lo = mid; else hi = mid; }
+        const int32_t node = snode[lo], r = g - soff[lo], len = soff[lo + 1] - soff[lo] - 1;
+        if (r < len) { const int32_t p = rowptr[node] + r; v = col[p]; a = val[p]; }
+        else { v = node; mk = lo; }  // the virtual entry: closes sample lo, weight 0
+      }
+      sv[tid] = v; sa[tid] = a; sm[tid] = mk;
+    }
+    __syncthreads();
+    // (2) all waves: the entries' row slices, every load of the chunk in flight at once
+    for (int e = jg; e < cn; e += 4) {
+      const int64_t v = sv[e];
+      sE[e][lane] = i_ok ? feat(E, v, i) : 0.f;
+      sD[e][lane] = (j0 + lane < H) ? dact[v * H + j0 + lane] : 0.f;
+      const int mk = sm[e];
+      if (mk >= 0) {
+        const int64_t m = m_begin + mk;
+        const bool ok = j0 + lane < H;
+        sQ[0][e][lane] = ok ? q[m * H + j0 + lane] : 0.f;
+        if (HAS_SELF) {
+          sQ[1][e][lane] = ok ? q[M * H + m * H + j0 + lane] : 0.f;
+          sQ[2][e][lane] = ok ? q[2 * M * H + m * H + j0 + lane] : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    // (3) FMAs from LDS; a closing entry folds the finished T into the accumulator
+    for (int e = 0; e < cn; ++e) {
+      const float ev = sE[e][lane];
+      const float4* __restrict__ dr = reinterpret_cast<const float4*>(&sD[e][jg * JPT]);
+      const int mk = sm[e];
+      if (mk < 0) {
+        const float ea = ev * sa[e];
 #pragma unroll
         for (int q4 = 0; q4 < JPT / 4; ++q4) {
-          const float4 t4 = *reinterpret_cast<const float4*>(hr + 4 * q4);
-          hvals[4 * q4] = t4.x; hvals[4 * q4 + 1] = t4.y; hvals[4 * q4 + 2] = t4.z; hvals[4 * q4 + 3] = t4.w;
+          const float4 d4 = dr[q4];
+          T[4 * q4] = fmaf(d4.x, ea, T[4 * q4]); T[4 * q4 + 1] = fmaf(d4.y, ea, T[4 * q4 + 1]);
+          T[4 * q4 + 2] = fmaf(d4.z, ea, T[4 * q4 + 2]); T[4 * q4 + 3] = fmaf(d4.w, ea, T[4 * q4 + 3]);
         }
       } else {
 #pragma unroll
-        for (int jj = 0; jj < JPT; ++jj) hvals[jj] = jj < nj ? hr[jj] : 0.f;
-      }
-#pragma unroll
-      for (int jj = 0; jj < JPT; ++jj)
-        if (jj < nj) T[jj] += act_deriv_from_out(hvals[jj], act) * e;
-    }
-    if (has_self) {
-      const float e = i_ok ? feat(E, node, i) : 0.f;
-      const float* __restrict__ hr = hact + node * hact_ld + j0;
-#pragma unroll
-      for (int jj = 0; jj < JPT; ++jj) {
-        if (jj < nj) {
-          const float sf = act_deriv_from_out(hr[jj], act) * e;
-          const float qbb = q[m * H + j0 + jj], qab = q[M * H + m * H + j0 + jj], qaa = q[2 * M * H + m * H + j0 + jj];
-          acc[jj] += qbb * T[jj] * T[jj] + 2.f * qab * sf * T[jj] + qaa * sf * sf;
+        for (int jj = 0; jj < JPT; ++jj) {
+          const float qbb = sQ[0][e][jg * JPT + jj];
+          if (HAS_SELF) {
+            const float sf = sD[e][jg * JPT + jj] * ev;
+            acc[jj] += qbb * T[jj] * T[jj] + 2.f * sQ[1][e][jg * JPT + jj] * sf * T[jj] + sQ[2][e][jg * JPT + jj] * sf * sf;
+          } else {
+            acc[jj] += qbb * T[jj] * T[jj];
+          }
+          T[jj] = 0.f;
         }
       }
-    } else {
-#pragma unroll
-      for (int jj = 0; jj < JPT; ++jj)
-        if (jj < nj) acc[jj] += q[m * H + j0 + jj] * T[jj] * T[jj];
     }
+    __syncthreads();
   }
   if (!i_ok) return;
 #pragma unroll
   for (int jj = 0; jj < JPT; ++jj) {
-    if (jj < nj) {
-      if (i < E.width) atomicAdd(&diag_w[(j0 + jj) * E.width + i], acc[jj]);
-      else atomicAdd(&diag_b[j0 + jj], acc[jj]);
+    const int64_t j = j0 + jg * JPT + jj;
+    if (j < H) {
+      if (i < E.width) atomicAdd(&diag_w[j * E.width + i], acc[jj]);
+      else atomicAdd(&diag_b[j], acc[jj]);
     }
   }
 }
@@ -369,6 +420,8 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
   // while every slab costs one atomic per output element: aim for ~2048 workgroups.
   int64_t tiles = 1;
   if (h->L == 2) tiles = cdiv(h->in_dim[0] + 1, 64) * cdiv(h->dims[1], 64);
+  // (measured at the Cora shape: 1 024 - 2 048 workgroups are the optimum -- fewer lengthen the per-workgroup chain,
+  //  more multiply the float atomics of the flush: 0.13 ms at 2 048, 0.26 ms at 8 192)
   int64_t slab = std::max<int64_t>(8, std::min<int64_t>(64, cdiv(M * tiles, 2048)));
   const unsigned nslab = unsigned(cdiv(M, slab));
 
@@ -384,8 +437,12 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
     feat_views(h, 0, E);
     const dim3 grid{unsigned(cdiv(E.width + 1, 64)), unsigned(cdiv(H, 64)), nslab};
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the diagonal path (bench.py roofline)
-    hipLaunchKernelGGL(diag_first_layer_kernel, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab,
-                       E, h->fc.hact_p[0], h->fc.hact_ld[0], h->act, H, q, has_self, diag_out, diag_out + H * in0);
+    if (has_self)
+      hipLaunchKernelGGL(diag_first_layer_kernel<1>, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab, E,
+                         h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
+    else
+      hipLaunchKernelGGL(diag_first_layer_kernel<0>, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab, E,
+                         h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += M; }
     off = H * in0 + H;

@@ -845,6 +845,23 @@ int launch_spmm_gram(const Csr& m, int64_t nrows, int64_t nplanes, const float* 
 // =====================================================================================
 // small utilities
 // =====================================================================================
+__global__ void act_deriv_kernel(const float* __restrict__ h, int64_t ld, int64_t N, int64_t H, int act,
+                                 float* __restrict__ out) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < N * H; q += stride) {
+    const int64_t n = q / H, j = q - n * H;
+    out[q] = act_deriv_from_out(h[n * ld + j], act);
+  }
+}
+// out[n, j] = act'(.) at the pre-activation whose activation output is h[n, j]   (row stride ld -> contiguous)
+int launch_act_deriv(const float* h, int64_t ld, int64_t N, int64_t H, int act, float* out, hipStream_t s) {
+  if (N * H <= 0) return 0;
+  hipLaunchKernelGGL(act_deriv_kernel, dim3(unsigned(std::min<int64_t>(cdiv(N * H, 256), 4096))), dim3(256), 0, s, h, ld, N, H,
+                     act, out);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 __global__ void transpose_kernel(const float* __restrict__ in, int64_t rows, int64_t cols, float* __restrict__ out) {
   __shared__ float t[32][33];
   const int64_t bx = int64_t(blockIdx.x) * 32, by = int64_t(blockIdx.y) * 32;

@@ -71,6 +71,7 @@ struct ForwardCache {
   DevBuf gram_raw[kMaxLayers];       // [in_l, in_l] raw in^T in (upper sub-tiles valid)
   DevBuf prop_in[kMaxLayers];        // P @ lin_in[l]  [N, in_l]   (diag / last layer; GCN)
   DevBuf rowsum;                     // rowsum(P) [N]
+  DevBuf dact0;                      // act'(h_1) [N, dims[1]] (closed-form diagonal GGN of 2-layer models)
   DevBuf mask_bits[kMaxLayers];      // ReLU: bit j of word w of node n = (h_{l+1}[n][32w+j] > 0)
 };
 
@@ -243,6 +244,7 @@ int launch_spmm_gram(const Csr& m, int64_t nrows, int64_t nplanes, const float* 
                      int64_t width, float* scratch, hipStream_t s);
 
 int launch_transpose(const float* in, int64_t rows, int64_t cols, float* out, hipStream_t s);
+int launch_act_deriv(const float* h, int64_t ld, int64_t N, int64_t H, int act, float* out, hipStream_t s);
 int launch_fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s);
 int launch_gather_rows(const float* in, int64_t ld, int64_t nrows_in, const int64_t* idx, int64_t M, int64_t width,
                        float* out, int* bad_flag, hipStream_t s);
