@@ -433,7 +433,7 @@ int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A1, flo
   LGNN_HIP_CHECK(hipGetLastError());
   GemmEpilogue eb0;
   eb0.bias = h->b[0];
-  LGNN_CALL(launch_gemm(h->X, F, h->Wt[0].as<float>(), H, Z, H, N, F, H, eb0, s));
+  LGNN_CALL(launch_gemm(h->fc.lin_in_p[0], h->fc.lin_in_ld[0], h->Wt[0].as<float>(), H, Z, H, N, F, H, eb0, s));
   LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, Hb, H, 0, Z, H, 0, H, 1, grad_P, s));
   // normalize_adj backward + the straight-through binarisation
   LGNN_CALL(h->ws.misc.reserve(size_t(2) * N * 4 + size_t(h->nnz) * 4));

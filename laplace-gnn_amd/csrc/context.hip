@@ -49,6 +49,17 @@ static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
     LGNN_CALL(fc.tmp.reserve(size_t(N) * maxw * 4));
     fc.lin_in_p[0] = h->X;
     fc.lin_in_ld[0] = h->dims[0];
+    if (h->dims[0] % 4 != 0) {  // unaligned feature rows: a padded copy, made once per binding
+      const int64_t ldx = cdiv(h->dims[0], 4) * 4;
+      if (!fc.x_valid) {
+        LGNN_CALL(fc.Xpad.reserve(size_t(N) * ldx * 4));
+        LGNN_HIP_CHECK(hipMemsetAsync(fc.Xpad.p, 0, size_t(N) * ldx * 4, s));
+        LGNN_HIP_CHECK(hipMemcpy2DAsync(fc.Xpad.p, size_t(ldx) * 4, h->X, size_t(h->dims[0]) * 4, size_t(h->dims[0]) * 4,
+                                        size_t(N), hipMemcpyDeviceToDevice, s));
+      }
+      fc.lin_in_p[0] = fc.Xpad.as<float>();
+      fc.lin_in_ld[0] = ldx;
+    }
     for (int l = 0; l < L; ++l) {
       const int64_t din = h->dims[l], dout = h->dims[l + 1];
       GemmEpilogue ep;
@@ -120,7 +131,10 @@ int forward_ensure(lgnn_ctx* h, hipStream_t s) {
   LGNN_CALL(gcn_or_sage_forward(h, s));
   h->fc.valid = true;
   h->fc.aux_valid = false;
-  for (int l = 0; l < kMaxLayers; ++l) h->fc.gram_valid[l] = false;
+  // layer 0 of a GCN sees X itself: its input Gram and P X do not depend on the weights
+  const bool keep0 = h->fc.x_valid && h->kind == LGNN_KIND_GCN;
+  for (int l = 0; l < kMaxLayers; ++l) h->fc.gram_valid[l] = (l == 0 && keep0) ? h->fc.gram_valid[0] : false;
+  h->fc.x_valid = true;
   return 0;
 }
 
@@ -139,17 +153,24 @@ int forward_ensure_grams(lgnn_ctx* h, hipStream_t s) {
 
 // rowsum(P) and P @ lin_in[l] for GCN (closed-form diagonal GGN and last-layer features)
 int forward_ensure_aux(lgnn_ctx* h, hipStream_t s) {
+  const bool had_x = h->fc.x_valid && h->fc.px_valid;
   LGNN_CALL(forward_ensure(h, s));
   if (h->fc.aux_valid) return 0;
-  LGNN_CALL(h->fc.rowsum.reserve(size_t(h->N) * 4));
-  LGNN_CALL(launch_csr_rowsum(h->P, h->N, h->fc.rowsum.as<float>(), s));
+  if (!had_x) {
+    LGNN_CALL(h->fc.rowsum.reserve(size_t(h->N) * 4));
+    LGNN_CALL(launch_csr_rowsum(h->P, h->N, h->fc.rowsum.as<float>(), s));
+  }
   if (h->kind == LGNN_KIND_GCN) {
     for (int l = 0; l < h->L; ++l) {
-      const int64_t d = h->dims[l];
+      if (l == 0 && had_x) continue;  // P X depends on the graph and X only: kept across weight updates
+      // (the padded width of an unaligned X is propagated as a whole: the padding columns stay zero)
+      const int64_t d = l == 0 ? h->fc.lin_in_ld[0] : h->dims[l];
+      h->fc.prop_ld[l] = d;
       LGNN_CALL(h->fc.prop_in[l].reserve(size_t(h->N) * d * 4));
       LGNN_CALL(launch_spmm(h->P, h->N, h->fc.lin_in_p[l], h->fc.lin_in_ld[l], h->fc.prop_in[l].as<float>(), d, d, 0, s));
     }
   }
+  h->fc.px_valid = true;
   if (h->L == 2) {  // act'(h_1), contiguous [N, H]: the first-layer diagonal kernel multiplies with it (one FMA per element)
     const int64_t H = h->dims[1];
     LGNN_CALL(h->fc.dact0.reserve(size_t(h->N) * H * 4));
@@ -196,7 +217,7 @@ extern "C" void lgnn_destroy(lgnn_ctx* h) {
   if (!h) return;
   (void)hipDeviceSynchronize();
   DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
-                    &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->fc.dact0, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult, &h->ws.planes_a,
+                    &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->fc.dact0, &h->fc.Xpad, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult, &h->ws.planes_a,
                     &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->long_rows, &h->long_slot, &h->long_tasks, &h->hub, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (DevBuf* b : bufs) b->release();
   for (int l = 0; l < kMaxLayers; ++l) {
@@ -239,14 +260,20 @@ extern "C" int lgnn_bind_model(lgnn_ctx* h, int num_layers, const int64_t* dims,
   // binding (other widths) must not inherit that claim: the old layout's spare rows hold stale backward-GEMM stores
   h->ws.planes_a_zero_ptr = nullptr;
   h->ws.planes_a_zero_bytes = 0;
+  h->fc.x_valid = false;  // a new X / new widths: nothing survives
+  h->fc.px_valid = false;
+  h->fc.gram_valid[0] = false;
   return lgnn_invalidate(h);
 }
 
+// Weights changed: the forward pass, the activations' Grams and everything derived from them are stale.  What depends on
+// the graph and X only (padded X, rowsum(P), P X, X^T X of a GCN's first layer) is kept; lgnn_bind_model drops that too.
 extern "C" int lgnn_invalidate(lgnn_ctx* h) {
   if (!h) { set_error("null context"); return 2; }
   h->fc.valid = false;
   h->fc.aux_valid = false;
-  for (int l = 0; l < kMaxLayers; ++l) h->fc.gram_valid[l] = false;
+  const bool keep0 = h->fc.x_valid && h->kind == LGNN_KIND_GCN;
+  for (int l = 0; l < kMaxLayers; ++l) h->fc.gram_valid[l] = (l == 0 && keep0) ? h->fc.gram_valid[0] : false;
   return 0;
 }
 
@@ -261,7 +288,7 @@ extern "C" int64_t lgnn_device_bytes(const lgnn_ctx* h) {
   if (!h) return -1;
   size_t t = 0;
   const DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
-                          &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->fc.dact0, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult,
+                          &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->fc.dact0, &h->fc.Xpad, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult,
                           &h->ws.planes_a, &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->long_rows, &h->long_slot, &h->long_tasks, &h->hub, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (const DevBuf* b : bufs) t += b->bytes;
   for (int l = 0; l < kMaxLayers; ++l)

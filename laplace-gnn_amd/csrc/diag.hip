@@ -382,7 +382,7 @@ int feat_views(lgnn_ctx* h, int layer, FeatView& f) {
   // what Linear `layer` multiplies, seen from an output node: propagated input (GCN) or cat (GraphSAGE)
   if (h->kind == LGNN_KIND_GCN) {
     f.base = h->fc.prop_in[layer].as<float>();
-    f.ld = h->dims[layer];
+    f.ld = h->fc.prop_ld[layer];
     f.width = h->dims[layer];
     f.bias_col = h->fc.rowsum.as<float>();
   } else {

@@ -59,6 +59,12 @@ constexpr int kMaxLayers = 8;
 struct ForwardCache {
   bool valid = false;
   bool aux_valid = false;            // rowsum / propagated inputs for diag + last layer
+  // What depends on the graph and X only -- not on the weights -- survives lgnn_invalidate and is rebuilt at bind time:
+  bool x_valid = false;              // Xpad, gram_raw[0] (GCN: X^T X)
+  bool px_valid = false;             // rowsum, prop_in[0] (GCN: P X)
+  DevBuf Xpad;                       // GCN, F % 4 != 0: X copied to rows of F rounded up to 4 floats (zero padded) so that
+                                     // the first GEMM, SpMM and Gram run their 16-byte paths (Cora: F = 1 433)
+  int64_t prop_ld[kMaxLayers] = {};  // row stride of prop_in[l]
   bool gram_valid[kMaxLayers] = {};  // raw input Grams (upper triangle) per layer
   DevBuf lin_in[kMaxLayers];         // GraphSAGE: cat_l = [h_l | P h_l]  [N, 2 d_l]
   DevBuf act_out[kMaxLayers];        // GCN: h_{l+1} = act(P Z_l), l < L-1 : [N, out_l]
