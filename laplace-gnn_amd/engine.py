@@ -391,6 +391,21 @@ class GraphEngine:
         _lib.check(rc, "lgnn_adjgrad_finish")
         return out
 
+    def glm_variance(self, idx: torch.Tensor, S0, S1, kappa, QA0=None, QB0=None, QA1=None, QB1sq=None):
+        """Matrix-free GLM predictive of a 2-layer GCN: (f_mu [M, C], diag(J P^-1 J^T) [M, C]) from the closed-form
+        Jacobian (see include/laplace_gnn_hip.h lgnn_glm_variance for the operand conventions)."""
+        self._sync_versions()
+        idx = idx.contiguous()
+        M, C = idx.shape[0], self.dims[-1]
+        f_mu = torch.empty(M, C, dtype=torch.float32, device=self.device)
+        f_var = torch.empty(M, C, dtype=torch.float32, device=self.device)
+        keep = [t.contiguous().to(torch.float32) if t is not None else None for t in (QA0, QB0, S0, QA1, S1, QB1sq, kappa)]
+        ptr = [None if t is None else _dev_ptr(t, torch.float32, "posterior operand") for t in keep]
+        rc = self.lib.lgnn_glm_variance(self._h, _dev_ptr(idx, torch.int64, "idx"), M, *ptr, f_mu.data_ptr(), f_var.data_ptr(),
+                                        _stream(self.device))
+        _lib.check(rc, "lgnn_glm_variance")
+        return f_mu, f_var
+
     def check_async_errors(self):
         """Synchronise and raise if any batch since the last check contained an invalid node id or label."""
         _lib.check(self.lib.lgnn_check_async_errors(self._h, _stream(self.device)), "lgnn_check_async_errors")

@@ -266,8 +266,30 @@ class ParametricLaplace(BaseLaplace):
     def functional_variance(self, Js: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
 
+    def _matrix_free_operands(self):
+        """Operands of ``GraphEngine.glm_variance`` for this posterior, or None when the matrix-free route does not apply."""
+        return None
+
+    def _glm_variance_matrix_free(self, x):
+        """(f_mu [M, C], diag f_var [M, C]) without Jacobians (csrc/predictive.hip), or None: 2-layer GCN models with a
+        ReLU, hidden width <= 256, classification, Kronecker or diagonal posterior over all weights."""
+        eng = getattr(self.backend, "engine", None)
+        if (eng is None or not hasattr(eng, "glm_variance") or getattr(eng, "kind", None) != "gcn" or len(eng.dims) != 3
+                or eng.dims[1] > 256 or getattr(eng, "_bind_opts", ("relu",))[0] != "relu" or self.likelihood != "classification"):
+            return None
+        ops = self._matrix_free_operands()
+        if ops is None:
+            return None
+        eng.set_likelihood("classification")
+        return eng.glm_variance(x, **ops)
+
     def _glm_predictive_distribution(self, x, diagonal_output: bool = False):
-        """(f_mu [M, C], f_var [M, C, C]) (laplace/baselaplace.py:1123-1158)."""
+        """(f_mu [M, C], f_var [M, C, C]) (laplace/baselaplace.py:1123-1158); ``diagonal_output``: f_var [M, C], matrix free
+        where the model family allows it."""
+        if diagonal_output:
+            fast = self._glm_variance_matrix_free(x)
+            if fast is not None:
+                return fast
         Js, f_mu = self.backend.jacobians(x, enable_backprop=False)
         if Js.shape[1:] != (self.n_outputs, self.n_params):
             raise ValueError("Invalid Jacobians shape for Laplace posterior approx.")
@@ -278,12 +300,13 @@ class ParametricLaplace(BaseLaplace):
 
     def _glm_forward_call(self, x, link_approx, n_samples, diagonal_output, generator, eps):
         """laplace/baselaplace.py:570-665 (classification branches)."""
+        if link_approx == "probit":  # reads the diagonal of f_var only (laplace/baselaplace.py:610-616)
+            f_mu, f_var_diag = self._glm_predictive_distribution(x, diagonal_output=True)
+            kappa = 1 / torch.sqrt(1.0 + pi / 8 * f_var_diag)
+            return torch.softmax(kappa * f_mu, dim=-1)
         f_mu, f_var = self._glm_predictive_distribution(x)
         if link_approx == "mc":
             return self._glm_predictive_samples(f_mu, f_var, n_samples, diagonal_output, generator, eps).mean(dim=0)
-        if link_approx == "probit":
-            kappa = 1 / torch.sqrt(1.0 + pi / 8 * f_var.diagonal(dim1=1, dim2=2))
-            return torch.softmax(kappa * f_mu, dim=-1)
         # Laplace bridge with zero-mean correction (:630-660)
         f_mu = f_mu - (f_var.sum(-1) * f_mu.sum(-1).reshape(-1, 1) / f_var.sum(dim=(1, 2)).reshape(-1, 1))
         f_var = f_var - torch.einsum("bi,bj->bij", f_var.sum(-1), f_var.sum(-2)) / f_var.sum(dim=(1, 2)).reshape(-1, 1, 1)
@@ -594,6 +617,24 @@ class KronLaplace(ParametricLaplace):
     def log_det_posterior_precision(self) -> torch.Tensor:
         return self.posterior_precision.logdet()
 
+    def _matrix_free_operands(self):
+        H = self.H
+        if not isinstance(H, KronDecomposed) or H.damping or len(H.eigenvalues) != 4:
+            return None
+        (lB0, lA0), (QB0, QA0) = H.eigenvalues[0], H.eigenvectors[0]
+        (lB0b,), (QB0b,) = H.eigenvalues[1], H.eigenvectors[1]
+        (lB1, lA1), (QB1, QA1) = H.eigenvalues[2], H.eigenvectors[2]
+        (lB1b,), (QB1b,) = H.eigenvalues[3], H.eigenvectors[3]
+        if not (QB0b is QB0 or torch.equal(QB0b, QB0)):  # the bias block must share its weight block's eigenbasis of B_0
+            return None
+        pp = torch.as_tensor(self.prior_precision, dtype=torch.float32, device=self._device).reshape(-1)
+        d = pp.expand(4) if pp.numel() == 1 else pp
+        f = self._H_factor
+        S0 = torch.cat([1.0 / (f * torch.outer(lB0, lA0) + d[0]), (1.0 / (f * lB0b + d[1])).unsqueeze(1)], dim=1)
+        S1 = 1.0 / (f * torch.outer(lB1, lA1) + d[2])
+        kappa = (QB1b * QB1b) @ (1.0 / (f * lB1b + d[3]))
+        return dict(S0=S0, S1=S1, kappa=kappa, QA0=QA0, QB0=QB0, QA1=QA1, QB1sq=QB1 * QB1)
+
     def _scale_samples(self, eps):  # laplace/baselaplace.py:1646-1655
         return self.posterior_precision.bmm(eps, exponent=-0.5).reshape(eps.shape[0], self.n_params)
 
@@ -621,6 +662,18 @@ class DiagLaplace(ParametricLaplace):
     @property
     def log_det_posterior_precision(self) -> torch.Tensor:
         return self.posterior_precision.log().sum()
+
+    def _matrix_free_operands(self):
+        shapes = [tuple(p.shape) for p in self.params]
+        if len(shapes) != 4:
+            return None
+        (Hd, F), _, (C, _), _ = shapes
+        inv = 1.0 / self.posterior_precision
+        o = 0
+        w0 = inv[o:o + Hd * F].view(Hd, F); o += Hd * F
+        b0 = inv[o:o + Hd].view(Hd, 1); o += Hd
+        w1 = inv[o:o + C * Hd].view(C, Hd); o += C * Hd
+        return dict(S0=torch.cat([w0, b0], dim=1), S1=w1, kappa=inv[o:o + C])
 
     def _scale_samples(self, eps):  # laplace/baselaplace.py:1912-1919: samples * posterior_scale
         return eps * (1.0 / self.posterior_precision.sqrt()).reshape(1, self.n_params)

@@ -409,3 +409,36 @@ def test_invalid_labels_and_indices_are_reported_at_the_end_of_fit():
     # the context stays usable afterwards
     la.fit(lg.TensorBatchLoader(idx, torch.from_numpy(g["train_y"]).cuda(), 10000))
     assert rel(la.H_facs.kfacs[0][0].cpu().numpy(), g["kron_0_0"]) < RTOL
+
+
+@pytest.mark.parametrize("name", ["gcn_small_1batch_s0", "gcn_small_3batch_s1", "gcn_mid_1batch_s0", "gcn_mid_3batch_sym_s1",
+                                  "gcn_small_isolated_s0"])
+def test_matrix_free_glm_variance_matches_the_jacobian_route_and_the_reference(name):
+    """csrc/predictive.hip: diag(J P^-1 J^T) per node without Jacobians, Kronecker (scalar and per-block prior) and diagonal
+    posterior, against (a) this package's Jacobian route (KronDecomposed.inv_square_form / the diagonal einsum) and (b) the
+    reference's f_var golden."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = model_from_golden(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(),
+                                  batch_size=int(g["batch_size"]))
+    x = torch.from_numpy(g["pred_idx"]).cuda()
+    for cls, key in ((lg.KronLaplace, "kron"), (lg.DiagLaplace, "diag")):
+        la = cls(model, "classification")
+        la.fit(loader)
+        for pp in (1.0, torch.tensor([0.5, 2.0, 1.5, 0.25]) if cls is lg.KronLaplace else 0.7):
+            la.prior_precision = pp
+            fast = la._glm_variance_matrix_free(x)
+            assert fast is not None
+            f_mu, f_vd = fast
+            Js, f_j = la.backend.jacobians(x)
+            ref = torch.diagonal(la.functional_variance(Js), dim1=1, dim2=2)
+            assert rel(f_mu.cpu().numpy(), f_j.cpu().numpy()) < 1e-6
+            assert rel(f_vd.cpu().numpy(), ref.cpu().numpy()) < 1e-4, (key, pp)
+        la.prior_precision = 1.0
+        f_mu, f_vd = la._glm_variance_matrix_free(x)
+        gold = np.diagonal(g[key + "_glm_fvar"], axis1=1, axis2=2)
+        assert rel(f_vd.cpu().numpy(), gold) < 1e-3, key
+        assert rel(la(x, link_approx="probit").cpu().numpy(), g[key + "_glm_probit"]) < 1e-3
+    model.engine.check_async_errors()

@@ -395,3 +395,32 @@ def test_diag_lastlayer_jacobians_random_configurations_vs_oracle(seed):
         assert close(Hl.cpu().numpy(), oh), ("last layer", cfg)
     eng.check_async_errors()
     eng.close()
+
+
+def test_glm_predictive_on_every_node_of_the_arxiv_shape(arxiv):
+    """la(x) -- the reference's default GLM predictive with the probit link -- for ALL 169 343 nodes of the arxiv-shaped
+    model: the Jacobian route would need M * C * P = 1.2 PB; the matrix-free route (csrc/predictive.hip) is checked
+    against the Jacobian route on 24 of the nodes and must give a valid distribution everywhere."""
+    import time
+
+    import laplace_gnn_amd as lg
+
+    w, model, idx, y, X = arxiv
+    loader = lg.TensorBatchLoader(idx, y, batch_size=w["batch"])
+    la = lg.KronLaplace(model, "classification", prior_precision=2.0)
+    la.fit(loader)
+    every = torch.arange(w["N"], device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    probs = la(every, link_approx="probit")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert probs.shape == (w["N"], w["C"]) and bool(torch.isfinite(probs).all())
+    assert float((probs.sum(-1) - 1).abs().max()) < 1e-4 and float(probs.min()) >= 0
+    sub = torch.randperm(w["N"], generator=torch.Generator().manual_seed(0))[:24].cuda()
+    Js, f = la.backend.jacobians(sub)
+    ref = torch.diagonal(la.functional_variance(Js), dim1=1, dim2=2)
+    f_mu, f_vd = la._glm_variance_matrix_free(sub)
+    assert rel(f_vd.cpu().numpy(), ref.cpu().numpy()) < 1e-4 and rel(f_mu.cpu().numpy(), f.cpu().numpy()) < 1e-6
+    print(f"GLM predictive of {w['N']} nodes: {dt * 1e3:.1f} ms")
+    assert dt < 30.0
