@@ -24,6 +24,13 @@ namespace lgnn {
 
 namespace {
 
+// ablation switches (tools/sweep_fused.py) exist in `make DEV=1` builds only: the production kernels test nothing in their loops
+#ifdef LGNN_DEV
+#define LGNN_DBG(a) ((a).debug)
+#else
+#define LGNN_DBG(a) 0
+#endif
+
 constexpr int KT256 = 32;  // rows per block
 constexpr int UNR = 12;    // neighbour rows in flight per lane and per pipelined row
 constexpr int DEPTH = 3;   // rows whose gathers are in flight per wave
@@ -123,8 +130,8 @@ __device__ __forceinline__ void mfma_wave(const FusedArgs& a, const float* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
   for (int64_t i = 0; i <= nb; ++i) {
-    if (i > 0 && a.debug != 1) gram256_block<W, KT256 / 2>(tiles + ((i - 1) & 1) * KT256 * 256, lane, acc);
-    if (a.debug != 4) __syncthreads();
+    if (i > 0 && LGNN_DBG(a) != 1) gram256_block<W, KT256 / 2>(tiles + ((i - 1) & 1) * KT256 * 256, lane, acc);
+    if (LGNN_DBG(a) != 4) __syncthreads();
   }
   gram256_flush<W>(a.scratch, a.width, lane, acc);
 }
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
     load_block_entries(0, rp_next, sl_cur, ent);
     rp_next = load_rp(1);
     for (int64_t i = 0; i <= nb; ++i) {
-      if (i < nb && a.debug != 2 && a.debug != 4) {
+      if (i < nb && LGNN_DBG(a) != 2 && LGNN_DBG(a) != 4) {
         int64_t plane, rb;
         block_coords(i, plane, rb);
         const float* in = a.in + plane * a.in_plane_stride;
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
         fl_cur = fl_next;
         if constexpr (HUB) { sl_cur = sl_next; sl_next = load_slot(i + 2); }
       }
-      if (a.debug != 4) __syncthreads();
+      if (LGNN_DBG(a) != 4) __syncthreads();
     }
   } else {
     // ------------------------------------------------ MFMA waves

@@ -249,7 +249,13 @@ __global__ __launch_bounds__(1024) void seed_spmm_gram_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, int64_t N, int C,
     const int32_t* __restrict__ pos, const float* __restrict__ probs, const float* __restrict__ logits,
     const int32_t* __restrict__ mult, int fork_exact, float* __restrict__ g, const int32_t* __restrict__ act_list,
-    const int32_t* __restrict__ act_count, int cb, int ce, float* __restrict__ scratch, int ldb, int debug) {
+    const int32_t* __restrict__ act_count, int cb, int ce, float* __restrict__ scratch, int ldb, int debug_arg) {
+#ifdef LGNN_DEV  // ablation switches exist in `make DEV=1` builds only
+  const int debug = debug_arg;
+#else
+  (void)debug_arg;
+  constexpr int debug = 0;
+#endif
   constexpr int NT = NBLK * (NBLK + 1) / 2;
   extern __shared__ float sm[];
   const int lane = threadIdx.x & 63;

@@ -442,3 +442,40 @@ def test_matrix_free_glm_variance_matches_the_jacobian_route_and_the_reference(n
         assert rel(f_vd.cpu().numpy(), gold) < 1e-3, key
         assert rel(la(x, link_approx="probit").cpu().numpy(), g[key + "_glm_probit"]) < 1e-3
     model.engine.check_async_errors()
+
+
+def test_rccl_backend_initialises_and_reduces_on_this_box():
+    """The N > 1 path uses ``dist.init_process_group("nccl", device_id=...)`` (RCCL) and one flat all-reduce.  The pool has
+    one GPU per box and RCCL refuses two ranks on one device, so the collective itself can only be exercised at world
+    size 1 here: init, an all-reduce of the KFAC flat buffer and of a 64 MiB tensor (the in-place branch of
+    all_reduce_flat_), a fit inside the group, destroy -- in a child process."""
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import laplace_gnn_amd as lg
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+g = torch.Generator().manual_seed(0)
+N, F, H, C = 400, 16, 32, 5
+model = lg.GCN(F, H, C, 2, torch.randn(N, F, generator=g), torch.randint(0, N, (2, 1500), generator=g), symmetric=True).to(dev)
+idx = torch.randperm(N, generator=g)[:200].to(dev); y = torch.randint(0, C, (200,), generator=g).to(dev)
+la = lg.KronLaplace(model, "classification"); la.fit(lg.TensorBatchLoader(idx, y, 80), process_group=dist.group.WORLD)
+flat, views, loss = model.engine.new_kfac_buffers()
+model.engine.kfac_accumulate(idx[:80], y[:80], 200, views, loss)
+before = flat.clone(); dist.all_reduce(flat); torch.cuda.synchronize()
+assert torch.equal(before, flat)
+big = torch.ones(1 << 24, device=dev); small = torch.ones(3, device=dev)
+dist.all_reduce(big); dist.all_reduce(small); torch.cuda.synchronize()
+assert float(big.sum()) == float(1 << 24) and float(small.sum()) == 3.0
+dist.destroy_process_group(); print("rccl ok")
+'''
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
