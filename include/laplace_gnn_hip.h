@@ -189,6 +189,12 @@ LGNN_API int lgnn_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y
 LGNN_API int lgnn_lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M,
                                    float* H_out, float* loss_out, void* stream);
 
+/* What CurvatureInterface.last_layer_jacobians (laplace/curvature/curvature.py:132-167) builds its Jacobians from:
+ * phi_out [M, D + 1] = [input row of the final nn.Linear seen from the batch node | bias scale s_n] (GraphSAGE:
+ * [h_n | (A_bar h)_n | 1]; GCN: [(A_hat h)_n | rowsum(A_hat)_n]), f_out [M, C] = logits (or NULL);
+ * J_n = [I_C (x) phi_n^T | s_n I_C].                                                                              */
+LGNN_API int lgnn_lastlayer_features(lgnn_ctx* h, const int64_t* idx, int64_t M, float* phi_out, float* f_out, void* stream);
+
 /* The same matrix accumulated in its natural layout: H = sum_n Lambda_n (x) phi~_n phi~_n^T, so block (c, c') of H is the
  * weighted Gram Phi~^T diag(Lambda[:, c, c']) Phi~ -- symmetric in (c, c') and inside the block.  S_pairs
  * [C (C + 1) / 2][D][D] (pairs c <= c' row major; the upper 32 x 32 sub-tiles of each block are valid) and Sb_pairs

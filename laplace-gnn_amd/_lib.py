@@ -45,6 +45,7 @@ SIGNATURES = {
     "lgnn_diag_accumulate": (_i32, [_vp, _vp, _vp, _i64, _u32, _vp, _vp, _vp]),
     "lgnn_full_accumulate": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "lgnn_lastlayer_full_accumulate": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "lgnn_lastlayer_features": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "lgnn_lastlayer_pairs_accumulate": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "lgnn_lastlayer_pairs_place": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "lgnn_check_async_errors": (_i32, [_vp, _vp]),

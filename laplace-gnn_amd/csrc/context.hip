@@ -41,6 +41,11 @@ static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
   ForwardCache& fc = h->fc;
   const int64_t N = h->N;
   const int L = h->L;
+  // hub rows of the forward matrix go to a whole workgroup each (list built once per graph)
+  LGNN_CALL(long_rows_fwd_ensure(h, s));
+  const int32_t* lr = h->n_long_fwd > 0 ? (h->P.rowptr == h->PT.rowptr ? h->long_rows.as<int32_t>() : h->long_rows_fwd.as<int32_t>())
+                                         : nullptr;
+  const int64_t nlr = h->n_long_fwd > 0 ? h->n_long_fwd : 0;
   int64_t maxw = 0;
   for (int l = 0; l < L; ++l) maxw = std::max(maxw, h->dims[l + 1]);
   LGNN_CALL(fc.out.reserve(size_t(N) * h->dims[L] * 4));
@@ -71,7 +76,7 @@ static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
         LGNN_CALL(fc.act_out[l].reserve(size_t(N) * dout * 4));
         // h_{l+1} = act(A_hat Z_l)  (norm = Identity, dropout = identity in eval; base_gnn.py:141-156)
         LGNN_CALL(launch_spmm(h->P, N, fc.tmp.as<float>(), dout, fc.act_out[l].as<float>(), dout, dout,
-                              h->act == LGNN_ACT_RELU ? 1 : 2, s));
+                              h->act == LGNN_ACT_RELU ? 1 : 2, s, lr, nlr));
         fc.hact_p[l] = fc.act_out[l].as<float>();
         fc.hact_ld[l] = dout;
         if (h->act == LGNN_ACT_RELU) {
@@ -81,7 +86,7 @@ static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
         fc.lin_in_p[l + 1] = fc.hact_p[l];
         fc.lin_in_ld[l + 1] = dout;
       } else {
-        LGNN_CALL(launch_spmm(h->P, N, fc.tmp.as<float>(), dout, fc.out.as<float>(), dout, dout, 0, s));
+        LGNN_CALL(launch_spmm(h->P, N, fc.tmp.as<float>(), dout, fc.out.as<float>(), dout, dout, 0, s, lr, nlr));
       }
     }
   } else {
@@ -100,6 +105,7 @@ static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
       SpmmArgs a{};
       a.rowptr = h->P.rowptr; a.col = h->P.col; a.val = h->P.val; a.nrows = N;
       a.in = cat; a.in_ld = 2 * d; a.out = cat + d; a.out_ld = 2 * d; a.width = d; a.out_act = -1;
+      a.long_rows = lr; a.n_long = nlr;
       LGNN_CALL(launch_spmm_ex(a, 1, s));
       GemmEpilogue ep;
       ep.bias = h->b[l];
@@ -218,7 +224,7 @@ extern "C" void lgnn_destroy(lgnn_ctx* h) {
   (void)hipDeviceSynchronize();
   DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
                     &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->fc.dact0, &h->fc.Xpad, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult, &h->ws.planes_a,
-                    &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->long_rows, &h->long_slot, &h->long_tasks, &h->hub, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
+                    &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->long_rows, &h->long_slot, &h->long_tasks, &h->hub, &h->long_rows_fwd, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (DevBuf* b : bufs) b->release();
   for (int l = 0; l < kMaxLayers; ++l) {
     h->Wt[l].release(); h->fc.lin_in[l].release(); h->fc.act_out[l].release(); h->fc.gram_raw[l].release();
@@ -289,7 +295,7 @@ extern "C" int64_t lgnn_device_bytes(const lgnn_ctx* h) {
   size_t t = 0;
   const DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
                           &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->fc.dact0, &h->fc.Xpad, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult,
-                          &h->ws.planes_a, &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->long_rows, &h->long_slot, &h->long_tasks, &h->hub, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
+                          &h->ws.planes_a, &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->long_rows, &h->long_slot, &h->long_tasks, &h->hub, &h->long_rows_fwd, &h->ws.top, &h->ws.flags, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (const DevBuf* b : bufs) t += b->bytes;
   for (int l = 0; l < kMaxLayers; ++l)
     t += h->Wt[l].bytes + h->fc.lin_in[l].bytes + h->fc.act_out[l].bytes + h->fc.gram_raw[l].bytes +
@@ -401,4 +407,9 @@ extern "C" int lgnn_lastlayer_pairs_accumulate(lgnn_ctx* h, const int64_t* idx, 
 extern "C" int lgnn_lastlayer_pairs_place(lgnn_ctx* h, const float* S_pairs, const float* Sb_pairs, float* H_out, void* stream) {
   if (!h) { set_error("null context"); return 2; }
   return lastlayer_pairs_place(h, S_pairs, Sb_pairs, H_out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lgnn_lastlayer_features(lgnn_ctx* h, const int64_t* idx, int64_t M, float* phi_out, float* f_out, void* stream) {
+  if (!h) { set_error("null context"); return 2; }
+  return lastlayer_features(h, idx, M, phi_out, f_out, static_cast<hipStream_t>(stream));
 }

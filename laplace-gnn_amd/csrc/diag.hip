@@ -540,6 +540,23 @@ int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const voi
   return 0;
 }
 
+// phi~ of the batch rows: out [M, D + 1] = [last layer's input features at the node | bias scale]
+// (last_layer_jacobians, laplace/curvature/curvature.py:132-167: J_n = [I_C (x) phi_n^T | s_n I_C])
+int lastlayer_features(lgnn_ctx* h, const int64_t* idx, int64_t M, float* out, float* f_out, hipStream_t s) {
+  LGNN_REQUIRE(M > 0 && idx && out, "empty batch or null pointers");
+  LGNN_CALL(forward_ensure_aux(h, s));
+  FeatView Phi;
+  feat_views(h, h->L - 1, Phi);
+  const int64_t D1 = Phi.width + 1;
+  hipLaunchKernelGGL(ll_build_phi_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M * D1, 256), 8192))), dim3(256), 0, s, idx, M,
+                     Phi, D1, out);
+  LGNN_HIP_CHECK(hipGetLastError());
+  if (f_out)
+    LGNN_CALL(launch_gather_rows(h->fc.out.as<float>(), h->dims[h->L], h->N, idx, M, h->dims[h->L], f_out,
+                                 h->ws.flags.as<int>() + 2, s));
+  return 0;
+}
+
 // Pair-major accumulation: S [Q][D][D] (upper sub-tiles of each block) and Sb [Q][D + 1] are the CALLER's buffers and are
 // added to -- a fit accumulates all its batches there and places them into H once (lastlayer_pairs_place), instead of one
 // placement (1.2 GB of read-modify-write) + mirror pass per batch; a data-parallel caller all-reduces the pair buffers,

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a) {
   const float* __restrict__ in = a.in + plane * a.in_plane_stride;
   float* __restrict__ out = a.out + plane * a.out_plane_stride;
   const int32_t s = a.rowptr[row], e = a.rowptr[row + 1];
+  if (a.n_long > 0 && e - s > kLongRow) return;  // a hub row: spmm_long_rows_kernel writes it
   for (int64_t c0 = int64_t(sl) * VEC; c0 < a.width; c0 += int64_t(LPR) * VEC) {
     float acc[VEC];
 #pragma unroll
@@ -81,6 +82,53 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a) {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Hub rows of an SpMM (more than kLongRow stored entries): a whole workgroup per (row, plane, 256-column pass) -- eight
+// waves share the row's entries, four rows of the operand in flight per wave -- instead of one (sub-)wave walking
+// thousands of neighbours at the end of the launch (products shape: rows of up to 4 * 10^4 entries).
+__global__ __launch_bounds__(512) void spmm_long_rows_kernel(SpmmArgs a) {
+  __shared__ float red[8][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = a.long_rows[blockIdx.x];
+  const int64_t plane = blockIdx.y;
+  const int64_t c0 = int64_t(blockIdx.z) * 256 + lane * 4;
+  const bool col_ok = c0 < a.width;  // width % 4 == 0 (launcher: vector path only)
+  const float* __restrict__ in = a.in + plane * a.in_plane_stride;
+  const int32_t s = a.rowptr[row], e = a.rowptr[row + 1];
+  float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int UNR = 4;
+  for (int32_t p0 = s + wave * UNR; p0 < e; p0 += 8 * UNR) {
+    float v[UNR];
+    int32_t j[UNR];
+    float4 x[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const bool ok = p0 + u < e;
+      v[u] = ok ? a.val[p0 + u] : 0.f;
+      j[u] = ok ? a.col[p0 + u] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v[u] != 0.f && col_ok) x[u] = *reinterpret_cast<const float4*>(in + int64_t(j[u]) * a.in_ld + c0);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      y.x += v[u] * x[u].x; y.y += v[u] * x[u].y; y.z += v[u] * x[u].z; y.w += v[u] * x[u].w;
+    }
+  }
+  *reinterpret_cast<float4*>(&red[wave][lane * 4]) = y;
+  __syncthreads();
+  const int t = threadIdx.x;
+  const int64_t c = int64_t(blockIdx.z) * 256 + t;
+  if (t < 256 && c < a.width) {
+    float r = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) + ((red[4][t] + red[5][t]) + (red[6][t] + red[7][t]));
+    if (a.self) r += a.self[plane * a.self_plane_stride + row * a.self_ld + c];
+    if (a.hact) r *= act_deriv_from_out(a.hact[row * a.hact_ld + c], a.act);
+    if (a.out_act >= 0) r = act_apply(r, a.out_act);
+    a.out[plane * a.out_plane_stride + row * a.out_ld + c] = r;
+  }
+}
+
 template <int VEC>
 static int spmm_dispatch(const SpmmArgs& a, int64_t nplanes, hipStream_t s) {
   const int64_t lanes_needed = cdiv(a.width, VEC);
@@ -102,18 +150,27 @@ static int spmm_dispatch(const SpmmArgs& a, int64_t nplanes, hipStream_t s) {
   return 0;
 }
 
-int launch_spmm_ex(const SpmmArgs& a, int64_t nplanes, hipStream_t s) {
+int launch_spmm_ex(const SpmmArgs& a_in, int64_t nplanes, hipStream_t s) {
+  SpmmArgs a = a_in;
   if (a.nrows <= 0 || a.width <= 0 || nplanes <= 0) return 0;
   LGNN_REQUIRE(nplanes < 65536, "too many planes for one launch");
   const bool vec = (a.width % 4 == 0) && (a.in_ld % 4 == 0) && (a.out_ld % 4 == 0) &&
                    (a.in_plane_stride % 4 == 0) && (a.out_plane_stride % 4 == 0) && aligned16(a.in) &&
                    aligned16(a.out);
+  if (!vec || a.long_rows == nullptr || a.n_long >= 65536 * 16) a.n_long = 0;  // hub rows: vector path only
+  if (a.n_long > 0) {
+    LGNN_REQUIRE(a.n_long < (int64_t(1) << 31), "too many long rows");
+    hipLaunchKernelGGL(spmm_long_rows_kernel, dim3(unsigned(a.n_long), unsigned(nplanes), unsigned(cdiv(a.width, 256))),
+                       dim3(512), 0, s, a);
+    LGNN_HIP_CHECK(hipGetLastError());
+  }
   return vec ? spmm_dispatch<4>(a, nplanes, s) : spmm_dispatch<1>(a, nplanes, s);
 }
 
 int launch_spmm(const Csr& m, int64_t nrows, const float* in, int64_t in_ld, float* out, int64_t out_ld,
-                int64_t width, int epilogue, hipStream_t s) {
+                int64_t width, int epilogue, hipStream_t s, const int32_t* long_rows, int64_t n_long) {
   SpmmArgs a{};
+  a.long_rows = long_rows; a.n_long = n_long;
   a.rowptr = m.rowptr; a.col = m.col; a.val = m.val; a.nrows = nrows;
   a.in = in; a.in_ld = in_ld; a.out = out; a.out_ld = out_ld; a.width = width;
   a.out_act = epilogue == 0 ? -1 : (epilogue == 1 ? LGNN_ACT_RELU : LGNN_ACT_TANH);

@@ -133,6 +133,9 @@ struct lgnn_ctx {
   int64_t n_long = -1;             // -1: not looked at yet
   int64_t n_long_tasks = 0;
   lgnn::DevBuf long_rows, long_slot, long_tasks, hub;
+  // the same list for the forward matrix P (the forward SpMMs)
+  int64_t n_long_fwd = -1;
+  lgnn::DevBuf long_rows_fwd;
   // timing of the dominant kernel
   bool timing = false;
   std::vector<hipEvent_t> ev;   // pairs (start, stop), grown on demand
@@ -161,6 +164,9 @@ struct SpmmArgs {
   int64_t hact_ld;
   int act;
   int out_act;  // -1 none, else apply activation to the result
+  // rows with more than kLongRow stored entries (hubs), optional: the row kernel skips them and a side kernel with a
+  // whole workgroup per row writes them (vector path only)
+  const int32_t* long_rows; int64_t n_long;
 };
 
 struct FusedArgs {
@@ -208,7 +214,7 @@ int graph_build(lgnn_ctx* h, const int64_t* edge_index, int64_t E, hipStream_t s
 // out[r, 0:width) = sum_j val[j] * in[col[j], 0:width)   for r in [0, nrows)
 // epilogue: 0 none, 1 relu, 2 tanh
 int launch_spmm(const Csr& m, int64_t nrows, const float* in, int64_t in_ld, float* out, int64_t out_ld,
-                int64_t width, int epilogue, hipStream_t s);
+                int64_t width, int epilogue, hipStream_t s, const int32_t* long_rows = nullptr, int64_t n_long = 0);
 // rowsum of the CSR values
 int launch_csr_rowsum(const Csr& m, int64_t nrows, float* out, hipStream_t s);
 
@@ -258,6 +264,7 @@ int launch_gather_rows(const float* in, int64_t ld, int64_t nrows_in, const int6
 // ---- longrows.hip -----------------------------------------------------------------------
 constexpr int kLongRow = 64;  // rows of P^T with more stored entries leave the fused kernel's per-wave gather
 int long_rows_ensure(lgnn_ctx* h, hipStream_t s);  // builds h->long_* once (synchronises the stream that one time)
+int long_rows_fwd_ensure(lgnn_ctx* h, hipStream_t s);  // the list of long rows of P (forward SpMMs)
 // hub[plane][slot][0:width) = sum_j val[j] * in[plane][col[j]][0:width) for the long rows of P^T
 int launch_long_rows_spmm(lgnn_ctx* h, const float* val, const float* in, int64_t in_ld, int64_t in_plane_stride,
                           int64_t nplanes, int64_t width, hipStream_t s);
@@ -297,6 +304,7 @@ int lastlayer_full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, in
                               float* loss_out, hipStream_t s);
 int lastlayer_pairs_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* S, float* Sb,
                                float* loss_out, hipStream_t s);
+int lastlayer_features(lgnn_ctx* h, const int64_t* idx, int64_t M, float* out, float* f_out, hipStream_t s);
 int lastlayer_pairs_place(lgnn_ctx* h, const float* S, const float* Sb, float* H_out, hipStream_t s);
 int full_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, float* H_out, float* loss_out, hipStream_t s);
 int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const void* y_loss, int64_t M, float resid_scale,

@@ -120,6 +120,31 @@ int long_rows_ensure(lgnn_ctx* h, hipStream_t s) {
   return done(0);
 }
 
+int long_rows_fwd_ensure(lgnn_ctx* h, hipStream_t s) {
+  if (h->n_long_fwd >= 0) return 0;
+  h->n_long_fwd = 0;
+  if (h->nnz <= 0) return 0;
+  if (h->P.rowptr == h->PT.rowptr) {  // symmetric graph: one structure serves both directions
+    LGNN_CALL(long_rows_ensure(h, s));
+    h->n_long_fwd = h->n_long;
+    return 0;
+  }
+  const int64_t N = h->N;
+  DevBuf flags, cnt, tmp;
+  auto done = [&](int rc) { flags.release(); cnt.release(); tmp.release(); return rc; };
+  if (flags.reserve(size_t(N)) || cnt.reserve(64)) return done(1);
+  hipLaunchKernelGGL(flag_long_rows_kernel, dim3(unsigned(cdiv(N, 256))), dim3(256), 0, s, h->P.rowptr, N, flags.as<uint8_t>());
+  if (h->long_rows_fwd.reserve(size_t(N) * 4)) return done(1);
+  if (compact_flags(flags.as<uint8_t>(), N, h->long_rows_fwd.as<int32_t>(), cnt.as<int32_t>(), tmp, s)) return done(1);
+  int32_t n = 0;
+  if (hipMemcpyAsync(&n, cnt.p, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    set_error("long rows: count copy failed");
+    return done(1);
+  }
+  h->n_long_fwd = n;
+  return done(0);
+}
+
 int launch_long_rows_spmm(lgnn_ctx* h, const float* val, const float* in, int64_t in_ld, int64_t in_plane_stride,
                           int64_t nplanes, int64_t width, hipStream_t s) {
   if (h->n_long <= 0 || nplanes <= 0) return 0;

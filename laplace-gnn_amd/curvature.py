@@ -242,13 +242,24 @@ class HipCurvatureInterface:
         if enable_backprop:
             raise NotImplementedError("the HIP Jacobians carry no autograd graph (enable_backprop=False only)")
         if self.last_layer:
-            raise NotImplementedError("last-layer Jacobians: use the all-weights Jacobians' last block")
+            return self.last_layer_jacobians(x)
         return self.engine.jacobians(x)
 
     functorch_jacobians = jacobians
 
-    def last_layer_jacobians(self, x, enable_backprop: bool = False):
-        raise NotImplementedError("last-layer Jacobians (GLM predictive of last-layer Laplace) are not implemented")
+    def last_layer_jacobians(self, x: torch.Tensor, enable_backprop: bool = False):
+        """(Js [M, C, C * D + C], f [M, C]) of the final nn.Linear alone (CurvatureInterface.last_layer_jacobians,
+        laplace/curvature/curvature.py:132-167): ``J_n = [I_C (x) phi_n^T | s_n I_C]`` -- weight index c * D + d, then the C
+        bias entries; phi_n / s_n from the device (``lgnn_lastlayer_features``)."""
+        if enable_backprop:
+            raise NotImplementedError("the HIP Jacobians carry no autograd graph (enable_backprop=False only)")
+        phi, s, f = self.engine.lastlayer_features(x)
+        M, D = phi.shape
+        C = f.shape[1]
+        eye = torch.eye(C, device=phi.device, dtype=phi.dtype)
+        Jw = torch.einsum("kp,ij->kijp", phi, eye).reshape(M, C, C * D)
+        Jb = s.reshape(M, 1, 1) * eye.unsqueeze(0)
+        return torch.cat([Jw, Jb], dim=2), f
 
     def gradients(self, x: torch.Tensor, y: torch.Tensor):
         """(Gs [M, P], loss): per-sample gradients of the summed loss, ``G_n = J_n^T d loss_n / d f_n``

@@ -329,6 +329,17 @@ class GraphEngine:
             _dev_ptr(H, torch.float32, "H"), loss.data_ptr(), _stream(self.device))
         _lib.check(rc, "lgnn_lastlayer_full_accumulate")
 
+    def lastlayer_features(self, idx: torch.Tensor):
+        """(phi [M, D], s [M], f [M, C]): the last Linear's input row seen from the batch node, the bias scale, the logits."""
+        self._sync_versions()
+        idx = idx.contiguous()
+        M, D, C = idx.shape[0], self.in_dims[-1], self.dims[-1]
+        out = torch.empty(M, D + 1, dtype=torch.float32, device=self.device)
+        f = torch.empty(M, C, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.lgnn_lastlayer_features(self._h, _dev_ptr(idx, torch.int64, "idx"), M, out.data_ptr(), f.data_ptr(),
+                                                    _stream(self.device)), "lgnn_lastlayer_features")
+        return out[:, :D], out[:, D], f
+
     def new_lastlayer_pair_buffers(self):
         """Zeroed pair-major accumulators of the last-layer full GGN as ONE flat buffer [S | Sb | loss] (one all-reduce)
         plus views: S [Q, D, D], Sb [Q, D + 1], loss [1], Q = C (C + 1) / 2."""

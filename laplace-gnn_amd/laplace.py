@@ -749,6 +749,10 @@ class FullLLLaplace(ParametricLaplace):
     def log_det_posterior_precision(self) -> torch.Tensor:
         return self.posterior_precision.logdet()
 
+    def functional_variance(self, Js):  # laplace/lllaplace.py via FullLaplace.functional_variance (baselaplace.py:1488-1489)
+        cov = torch.linalg.inv(self.posterior_precision)
+        return torch.einsum("ncp,pq,nkq->nck", Js, cov, Js)
+
 
 class FullLaplace(ParametricLaplace):
     """Full GGN over all weights (laplace/baselaplace.py:1380-1470): dense ``P x P`` precision, Cholesky-based scale,

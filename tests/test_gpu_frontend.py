@@ -479,3 +479,25 @@ dist.destroy_process_group(); print("rccl ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", ["gcn_small_1batch_s0", "sage_small_1batch_s0", "sage3_small_1batch_s0"])
+def test_last_layer_jacobians_are_the_last_block_of_the_full_jacobians(name):
+    """CurvatureInterface.last_layer_jacobians (laplace/curvature/curvature.py:132-167): J_n = [I_C (x) phi_n^T | s_n I_C] equals
+    the last layer's columns of the reference's all-weights Jacobian golden; the GLM predictive of the last-layer Laplace
+    runs on them."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = model_from_golden(g)
+    be = lg.HipGGN(model, "classification", last_layer=True)
+    x = torch.from_numpy(g["train_idx"]).cuda()
+    Js, f = be.last_layer_jacobians(x)
+    L = int(g["num_layers"])
+    p_ll = g[f"W{L - 1}"].size + g[f"b{L - 1}"].size
+    assert rel(Js.cpu().numpy(), g["jac_first_batch"][:, :, -p_ll:]) < RTOL
+    assert rel(f.cpu().numpy(), g["f_first_batch"]) < RTOL
+    la = lg.Laplace(model, "classification", subset_of_weights="last_layer", hessian_structure="full")
+    la.fit(lg.TensorBatchLoader(x, torch.from_numpy(g["train_y"]).cuda(), batch_size=10000))
+    probs = la(x[:8], link_approx="probit")
+    assert probs.shape == (8, f.shape[1]) and float((probs.sum(-1) - 1).abs().max()) < 1e-5
