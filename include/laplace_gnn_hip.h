@@ -239,12 +239,19 @@ LGNN_API int lgnn_jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J
  *                lgnn_export_propagation);  out_bar [N, C] += d/d(all-node logits) of loss_scale * CE and of the seeds
  *   once      :  adds the forward-pass terms (a_scale = batches / N_train: A_1 = a_scale * H1^T H1) to grad_P, then
  *                grad_adj [nnz] = gradient w.r.t. the stored entries of the 0/1 adjacency, order of lgnn_export_adj
- *                (diagonal 0: fill_diagonal_(1) overwrites it; symmetric models: average of (i,j) and (j,i)).     */
+ *                (diagonal 0: fill_diagonal_(1) overwrites it; symmetric models: average of (i,j) and (j,i)).
+ * Candidate edges (num_cand may be 0): the reference's dense adj.grad also has an entry for every NON-edge -- that is how
+ * its structure learning proposes edges.  cand_a / cand_b int32 [num_cand] list pairs in the propagation matrix's
+ * coordinates (entry (i, j) of the adjacency <-> a = j, b = i); grad_cand [num_cand] accumulates like grad_P and
+ * lgnn_adjgrad_finish writes grad_cand_adj [num_cand] = d / d adj[i, j] (no symmetrisation: a symmetric model's caller
+ * lists both orientations and averages).                                                                        */
 LGNN_API int lgnn_kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags,
                             const float* const* gamma_B /* host array of L device ptrs */, float loss_scale,
-                            float* grad_P, float* out_bar, void* stream);
+                            float* grad_P, float* out_bar, const int32_t* cand_a, const int32_t* cand_b, int64_t num_cand,
+                            float* grad_cand, void* stream);
 LGNN_API int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* const* gamma_A /* host array of L device ptrs */,
-                        float a_scale, float* grad_P, float* grad_adj, void* stream);
+                        float a_scale, float* grad_P, float* grad_adj, const int32_t* cand_a, const int32_t* cand_b,
+                        int64_t num_cand, float* grad_cand, float* grad_cand_adj, void* stream);
 
 /* ---- matrix-free GLM predictive ("next" row 8(f)-3 at scale) -------------------------------------------------------
  * Replaces the Jacobian route of the default la(x) (laplace/baselaplace.py:1123-1158 + laplace/utils/matrix.py:396-451 resp.

@@ -80,6 +80,84 @@ int launch_sddmm(const Csr& m, int64_t nrows, const int32_t* rows, const int32_t
   return 0;
 }
 
+// The same contraction on an arbitrary list of (a, b) pairs (candidate edges that are NOT stored: the reference's dense
+// adj.grad has an entry for every pair, which is how its structure learning proposes new edges).
+template <int LPR>
+__global__ __launch_bounds__(256) void sddmm_coo_kernel(const int32_t* __restrict__ ca, const int32_t* __restrict__ cb, int64_t K,
+                                                        const float* __restrict__ Lp, int64_t l_ld, int64_t l_stride,
+                                                        const float* __restrict__ Rp, int64_t r_ld, int64_t r_stride,
+                                                        int64_t width, int64_t nplanes, const uint8_t* __restrict__ a_active,
+                                                        float* __restrict__ out) {
+  constexpr int EPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPR, sl = lane % LPR;
+  const int64_t k = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * EPW + sub;
+  const bool ok = k < K;
+  const int64_t a = ok ? ca[k] : 0, b = ok ? cb[k] : 0;
+  float acc = 0.f;
+  if (ok && (a_active == nullptr || a_active[a])) {
+    for (int64_t c = 0; c < nplanes; ++c) {
+      const float* __restrict__ lrow = Lp + c * l_stride + a * l_ld;
+      const float* __restrict__ rrow = Rp + c * r_stride + b * r_ld;
+      for (int64_t q = sl; q < width; q += LPR) acc += lrow[q] * rrow[q];
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (ok && sl == 0) out[k] += acc;
+}
+
+int launch_sddmm_coo(const int32_t* ca, const int32_t* cb, int64_t K, const float* L, int64_t l_ld, int64_t l_stride,
+                     const float* R, int64_t r_ld, int64_t r_stride, int64_t width, int64_t nplanes, const uint8_t* a_active,
+                     float* out, hipStream_t s) {
+  if (K <= 0 || width <= 0 || nplanes <= 0) return 0;
+#define LGNN_SDDMM_COO(LPRV)                                                                                               \
+  hipLaunchKernelGGL(sddmm_coo_kernel<LPRV>, dim3(unsigned(cdiv(K, 4 * (64 / LPRV)))), dim3(256), 0, s, ca, cb, K, L, l_ld, \
+                     l_stride, R, r_ld, r_stride, width, nplanes, a_active, out)
+  if (width <= 8) LGNN_SDDMM_COO(8);
+  else if (width <= 16) LGNN_SDDMM_COO(16);
+  else if (width <= 32) LGNN_SDDMM_COO(32);
+  else LGNN_SDDMM_COO(64);
+#undef LGNN_SDDMM_COO
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// candidate pairs against the scattered seed planes: only pairs whose a is a batch node contribute
+__global__ __launch_bounds__(256) void sddmm_coo_seed_kernel(const int32_t* __restrict__ ca, const int32_t* __restrict__ cb,
+                                                             int64_t K, int64_t N, int64_t C, const int32_t* __restrict__ pos,
+                                                             const float* __restrict__ seeds, const float* __restrict__ g1bar,
+                                                             int64_t c0, int64_t cc, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t k = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (k >= K) return;
+  const int64_t a = ca[k], b = cb[k];
+  const int32_t m = pos[a];
+  if (m == INT32_MAX) return;
+  const float* __restrict__ sd = seeds + int64_t(m) * C * C + c0 * C;
+  const int64_t nq = cc * C;
+  float acc = 0.f;
+  for (int64_t q = lane; q < nq; q += 64) {
+    const int64_t c = q / C, kk = q - c * C;
+    acc += sd[q] * g1bar[(c * N + b) * C + kk];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) out[k] += acc;
+}
+
+// candidate (a, b) of P = entry (i = b, j = a) of A:  gA = gP d_i d_j - 1/2 d_i^2 (rs[i] + cs[i]);  i == j -> 0
+__global__ void cand_adj_grad_kernel(const int32_t* __restrict__ ca, const int32_t* __restrict__ cb, int64_t K,
+                                     const int32_t* __restrict__ a_rowptr, const float* __restrict__ gPc,
+                                     const float* __restrict__ rs, const float* __restrict__ cs, float* __restrict__ out) {
+  const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const int64_t j = ca[k], i = cb[k];
+  if (i == j) { out[k] = 0.f; return; }
+  const float di = rsqrtf(float(a_rowptr[i + 1] - a_rowptr[i])), dj = rsqrtf(float(a_rowptr[j + 1] - a_rowptr[j]));
+  out[k] = gPc[k] * di * dj - 0.5f * di * di * (rs[i] + cs[i]);
+}
+
 // gradP[(a, b)] += sum_{c in [c0, c0+cc)} sum_k seeds[m][c][k] * g1bar[c - c0][b][k]  for the first occurrence m of every
 // batch node a = idx[m] (the scattered seed planes G_c are non-zero on those rows only and hold the accumulated seeds of
 // duplicated node ids).  One wave per sample; lanes over (c, k).
@@ -330,7 +408,9 @@ int check_model(const lgnn_ctx* h) {
 }  // namespace
 
 int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags, const float* gamma_B0,
-                       const float* gamma_B1, float loss_scale, float* grad_P, float* out_bar, hipStream_t s) {
+                       const float* gamma_B1, float loss_scale, float* grad_P, float* out_bar, const int32_t* cand_a,
+                       const int32_t* cand_b, int64_t K, float* grad_cand, hipStream_t s) {
+  LGNN_REQUIRE(K == 0 || (cand_a && cand_b && grad_cand), "candidate pairs without their buffers");
   LGNN_CALL(check_model(h));
   LGNN_REQUIRE(M > 0 && idx && y && gamma_B0 && gamma_B1 && grad_P && out_bar, "empty batch or null pointers");
   LGNN_CALL(forward_ensure(h, s));
@@ -380,6 +460,7 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
     // gradP[(a,b)] += sum_c <u_c[a], g0bar_c[b]>; u is zero outside the active rows
     LGNN_CALL(launch_sddmm(h->P, N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(), U, H, N * H, G0B, H, N * H,
                            H, cc, grad_P, s));
+    LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, U, H, N * H, G0B, H, N * H, H, cc, h->ws.active.as<uint8_t>(), grad_cand, s));
     // ubar = mask * (P g0bar)  (overwrites u)
     SpmmArgs sb{};
     sb.rowptr = h->P.rowptr; sb.col = h->P.col; sb.val = h->P.val; sb.nrows = N;
@@ -394,6 +475,9 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
     hipLaunchKernelGGL(sddmm_seed_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, h->P.rowptr, h->P.col, idx, M, N, C,
                        h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), G1B, c0, cc, grad_P);
     LGNN_HIP_CHECK(hipGetLastError());
+    if (K > 0)
+      hipLaunchKernelGGL(sddmm_coo_seed_kernel, dim3(unsigned(cdiv(K, 4))), dim3(256), 0, s, cand_a, cand_b, K, N, C,
+                         h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), G1B, c0, cc, grad_cand);
     hipLaunchKernelGGL(seed_adjoint_gather_kernel, dim3(unsigned(cdiv(M * cc * C, 256))), dim3(256), 0, s, h->P.rowptr,
                        h->P.col, h->P.val, idx, M, N, C, G1B, c0, cc, vbar);
     LGNN_HIP_CHECK(hipGetLastError());
@@ -408,7 +492,9 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
 }
 
 int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A1, float a1_scale, float* grad_P, float* grad_adj,
+                   const int32_t* cand_a, const int32_t* cand_b, int64_t K, float* grad_cand, float* grad_cand_adj,
                    hipStream_t s) {
+  LGNN_REQUIRE(K == 0 || (cand_a && cand_b && grad_cand && grad_cand_adj), "candidate pairs without their buffers");
   LGNN_CALL(check_model(h));
   LGNN_REQUIRE(out_bar && gamma_A1 && grad_P && grad_adj, "null pointers");
   LGNN_CALL(forward_ensure(h, s));
@@ -424,6 +510,7 @@ int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A1, flo
   eb1.bias = h->b[1];
   LGNN_CALL(launch_gemm(h->fc.hact_p[0], h->fc.hact_ld[0], h->Wt[1].as<float>(), C, Z, C, N, H, C, eb1, s));
   LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, out_bar, C, 0, Z, C, 0, C, 1, grad_P, s));
+  LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, out_bar, C, 0, Z, C, 0, C, 1, nullptr, grad_cand, s));
   // Z1bar = P^T outbar;  H1bar = Z1bar W1 + 2 a1_scale H1 Gamma_A1;  P0bar = mask * H1bar
   LGNN_CALL(launch_spmm(h->PT, N, out_bar, C, Zb, C, C, 0, s));
   LGNN_CALL(sgemm_rm(s, N, H, C, 1.f, Zb, C, h->W[1], H, 0.f, Hb, H));
@@ -435,6 +522,7 @@ int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A1, flo
   eb0.bias = h->b[0];
   LGNN_CALL(launch_gemm(h->fc.lin_in_p[0], h->fc.lin_in_ld[0], h->Wt[0].as<float>(), H, Z, H, N, F, H, eb0, s));
   LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, Hb, H, 0, Z, H, 0, H, 1, grad_P, s));
+  LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, Hb, H, 0, Z, H, 0, H, 1, nullptr, grad_cand, s));
   // normalize_adj backward + the straight-through binarisation
   LGNN_CALL(h->ws.misc.reserve(size_t(2) * N * 4 + size_t(h->nnz) * 4));
   float* rs = h->ws.misc.as<float>();
@@ -449,6 +537,9 @@ int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A1, flo
   if (h->sym)
     hipLaunchKernelGGL(adj_grad_symmetrize_kernel, dim3(unsigned(cdiv(N, 256))), dim3(256), 0, s, h->A.rowptr, h->A.col, tmp,
                        N, grad_adj);
+  if (K > 0)  // candidates: un-symmetrised d/dA[i, j]; a symmetric model's caller passes both orientations and averages
+    hipLaunchKernelGGL(cand_adj_grad_kernel, dim3(unsigned(cdiv(K, 256))), dim3(256), 0, s, cand_a, cand_b, K, h->A.rowptr,
+                       grad_cand, rs, cs, grad_cand_adj);
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -457,14 +548,17 @@ int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A1, flo
 
 extern "C" int lgnn_kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags,
                                        const float* const* gamma_B, float loss_scale, float* grad_P, float* out_bar,
+                                       const int32_t* cand_a, const int32_t* cand_b, int64_t num_cand, float* grad_cand,
                                        void* stream) {
   if (!h || !gamma_B) { lgnn::set_error("null argument"); return 2; }
-  return lgnn::kfac_adjgrad_batch(h, idx, y, M, flags, gamma_B[0], gamma_B[1], loss_scale, grad_P, out_bar,
-                                  static_cast<hipStream_t>(stream));
+  return lgnn::kfac_adjgrad_batch(h, idx, y, M, flags, gamma_B[0], gamma_B[1], loss_scale, grad_P, out_bar, cand_a, cand_b,
+                                  num_cand, grad_cand, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* const* gamma_A, float a_scale,
-                                   float* grad_P, float* grad_adj, void* stream) {
+                                   float* grad_P, float* grad_adj, const int32_t* cand_a, const int32_t* cand_b,
+                                   int64_t num_cand, float* grad_cand, float* grad_cand_adj, void* stream) {
   if (!h || !gamma_A) { lgnn::set_error("null argument"); return 2; }
-  return lgnn::adjgrad_finish(h, out_bar, gamma_A[1], a_scale, grad_P, grad_adj, static_cast<hipStream_t>(stream));
+  return lgnn::adjgrad_finish(h, out_bar, gamma_A[1], a_scale, grad_P, grad_adj, cand_a, cand_b, num_cand, grad_cand,
+                              grad_cand_adj, static_cast<hipStream_t>(stream));
 }

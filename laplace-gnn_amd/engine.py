@@ -377,30 +377,45 @@ class GraphEngine:
         return J, f
 
     # -- marginal-likelihood gradient w.r.t. the adjacency ("next" row 8(f)-4) ---------------------------------
+    @staticmethod
+    def _cand_ptrs(cand):
+        """cand = (a int32 [K], b int32 [K], accumulator fp32 [K]) in the propagation matrix's coordinates, or None."""
+        if cand is None:
+            return None, None, 0, None
+        a, b, acc = cand
+        return _dev_ptr(a, torch.int32, "cand_a"), _dev_ptr(b, torch.int32, "cand_b"), int(a.shape[0]), \
+            _dev_ptr(acc, torch.float32, "grad_cand")
+
     def adjgrad_batch(self, idx, y, gammas_B, grad_P: torch.Tensor, out_bar: torch.Tensor, fork_exact: bool = True,
-                      loss_scale: float = 1.0):
-        """Add one batch's terms to ``grad_P`` [nnz] (stored entries of the propagation matrix) and ``out_bar`` [N, C]."""
+                      loss_scale: float = 1.0, cand=None):
+        """Add one batch's terms to ``grad_P`` [nnz] (stored entries of the propagation matrix), ``out_bar`` [N, C] and,
+        for candidate pairs ``cand = (a, b, acc)``, to ``acc``."""
         self._sync_versions()
         idx, y = idx.contiguous(), y.contiguous()
         self._keep = [g.contiguous() for g in gammas_B]
         gb = _lib.ptr_array([_dev_ptr(g, torch.float32, "gamma_B").value for g in self._keep])
+        ca, cb, K, cacc = self._cand_ptrs(cand)
         rc = self.lib.lgnn_kfac_adjgrad_batch(
             self._h, _dev_ptr(idx, torch.int64, "idx"), _dev_ptr(y, torch.int64, "y"), idx.shape[0],
             _lib.FLAG_FORK_EXACT_SEED if fork_exact else 0, gb, float(loss_scale),
-            _dev_ptr(grad_P, torch.float32, "grad_P"), _dev_ptr(out_bar, torch.float32, "out_bar"), _stream(self.device))
+            _dev_ptr(grad_P, torch.float32, "grad_P"), _dev_ptr(out_bar, torch.float32, "out_bar"), ca, cb, K, cacc,
+            _stream(self.device))
         _lib.check(rc, "lgnn_kfac_adjgrad_batch")
 
-    def adjgrad_finish(self, out_bar: torch.Tensor, gammas_A, a_scale: float, grad_P: torch.Tensor) -> torch.Tensor:
+    def adjgrad_finish(self, out_bar: torch.Tensor, gammas_A, a_scale: float, grad_P: torch.Tensor, cand=None):
         """Forward-pass terms + normalize_adj / STE backward: gradient w.r.t. the stored entries of the 0/1 adjacency
-        (``export_adj`` order)."""
+        (``export_adj`` order); with candidates also ``d / d adj[i, j]`` of every listed pair (second return value)."""
         self._sync_versions()
         keep = [g.contiguous() for g in gammas_A]
         ga = _lib.ptr_array([_dev_ptr(g, torch.float32, "gamma_A").value for g in keep])
         out = torch.zeros(self.nnz, dtype=torch.float32, device=self.device)
+        ca, cb, K, cacc = self._cand_ptrs(cand)
+        cout = torch.zeros(K, dtype=torch.float32, device=self.device) if K else None
         rc = self.lib.lgnn_adjgrad_finish(self._h, _dev_ptr(out_bar, torch.float32, "out_bar"), ga, float(a_scale),
-                                          _dev_ptr(grad_P, torch.float32, "grad_P"), out.data_ptr(), _stream(self.device))
+                                          _dev_ptr(grad_P, torch.float32, "grad_P"), out.data_ptr(), ca, cb, K, cacc,
+                                          None if cout is None else cout.data_ptr(), _stream(self.device))
         _lib.check(rc, "lgnn_adjgrad_finish")
-        return out
+        return out if cand is None else (out, cout)
 
     def glm_variance(self, idx: torch.Tensor, S0, S1, kappa, QA0=None, QB0=None, QA1=None, QB1sq=None):
         """Matrix-free GLM predictive of a 2-layer GCN: (f_mu [M, C], diag(J P^-1 J^T) [M, C]) from the closed-form

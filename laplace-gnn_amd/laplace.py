@@ -579,14 +579,18 @@ class KronLaplace(ParametricLaplace):
             gA.append((QA * cA) @ QA.T)
         return gB, gA
 
-    def neg_marglik_adj_grad(self, train_loader, prior_precision=None, process_group=None):
+    def neg_marglik_adj_grad(self, train_loader, prior_precision=None, process_group=None, candidates=None):
         """``-log_marginal_likelihood()`` of this fit and its gradient w.r.t. the adjacency the model propagates with --
         what ``neg_marglik.backward()`` leaves in ``model.adj.grad`` in the reference's structure-learning loop
         (gnn/marglik_training.py:197-216), here on the stored sparsity pattern: returns ``(neg_marglik, edge_index [2, nnz],
         grad [nnz])`` over the stored entries of the 0/1 adjacency (``model.engine.export_adj()`` order; self loops
         carry gradient 0 like the reference's overwritten diagonal).  ``train_loader`` must be the loader of the fit
         (same batch boundaries: the B factors depend on them).  Inside a ``torch.distributed`` job whole batches are
-        dealt round-robin and the two accumulators are all-reduced once."""
+        dealt round-robin and the accumulators are all-reduced once.
+
+        ``candidates`` (int64 [2, K], pairs (i, j) that are NOT stored): the reference's dense ``adj.grad`` also has an
+        entry for every non-edge -- that is how its structure learning proposes new edges.  With candidates a fourth value
+        is returned: ``d(-marglik) / d adj[i, j]`` for each listed pair."""
         if self.H_facs is None:
             raise AttributeError("Laplace not fitted. Run fit() first.")
         if prior_precision is not None:
@@ -601,17 +605,31 @@ class KronLaplace(ParametricLaplace):
         grad_P = torch.zeros(eng.nnz, dtype=torch.float32, device=eng.device)
         out_bar = torch.zeros(eng.num_nodes, eng.dims[-1], dtype=torch.float32, device=eng.device)
         rank, world = _dist_info(process_group)
+        cand, sym = None, bool(getattr(self.model, "symmetric", False))
+        if candidates is not None:
+            ci, cj = candidates[0].to(eng.device), candidates[1].to(eng.device)
+            if sym:  # (adj + adj^T) / 2 feeds the model: both orientations are needed
+                ci, cj = torch.cat([ci, cj]), torch.cat([cj, ci])
+            # entry (i, j) of the adjacency is entry (a = j, b = i) of the propagation matrix D A^T D
+            cand = (cj.to(torch.int32).contiguous(), ci.to(torch.int32).contiguous(),
+                    torch.zeros(ci.shape[0], dtype=torch.float32, device=eng.device))
         for t, (X, y) in enumerate(train_loader):
             if t % world != rank:
                 continue
             eng.adjgrad_batch(X.to(eng.device), y.to(eng.device), gB, grad_P, out_bar,
-                              fork_exact=getattr(self.backend, "fork_exact_seed", True), loss_scale=self._H_factor)
+                              fork_exact=getattr(self.backend, "fork_exact_seed", True), loss_scale=self._H_factor, cand=cand)
         if world > 1:
-            all_reduce_flat_([grad_P, out_bar], process_group)
+            all_reduce_flat_([grad_P, out_bar] + ([cand[2]] if cand is not None else []), process_group)
         a_scale = len(train_loader) / len(train_loader.dataset)
-        grad = eng.adjgrad_finish(out_bar, gA, a_scale, grad_P)
         rows, cols = eng.export_adj()
-        return value, torch.stack([rows, cols]), grad
+        if cand is None:
+            grad = eng.adjgrad_finish(out_bar, gA, a_scale, grad_P)
+            return value, torch.stack([rows, cols]), grad
+        grad, gc = eng.adjgrad_finish(out_bar, gA, a_scale, grad_P, cand=cand)
+        if sym:
+            K = candidates.shape[1]
+            gc = 0.5 * (gc[:K] + gc[K:])
+        return value, torch.stack([rows, cols]), grad, gc
 
     @property
     def log_det_posterior_precision(self) -> torch.Tensor:

@@ -35,9 +35,13 @@ def test_adjacency_gradient_matches_reference_autograd(path):
     assert rel(grad.cpu().numpy(), g["adjgrad_vals"]) < 1e-3
     diag = g["adj_nz_row"] == g["adj_nz_col"]
     assert float(grad.cpu().numpy()[diag].__abs__().max()) == 0.0  # overwritten by fill_diagonal_(1) in the reference
-    # a second call gives the same result (accumulators are the caller's, nothing is left in the context)
-    _, _, grad2 = la.neg_marglik_adj_grad(loader)
+    # a second call gives the same result (accumulators are the caller's, nothing is left in the context); this one also
+    # asks for candidate pairs that are NOT edges: the reference's dense adj.grad has them (that is how its structure
+    # learning proposes new edges), 200 of them are in the fixture
+    cand = torch.from_numpy(np.stack([g["adjgrad_ne_row"], g["adjgrad_ne_col"]])).cuda()
+    _, _, grad2, gc = la.neg_marglik_adj_grad(loader, candidates=cand)
     assert rel(grad2.cpu().numpy(), grad.cpu().numpy()) < 1e-5
+    assert rel(gc.cpu().numpy(), g["adjgrad_ne_val"]) < 1e-3
     model.engine.check_async_errors()
 
 

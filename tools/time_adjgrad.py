@@ -1,0 +1,19 @@
+"""dev: wall time of KronLaplace.neg_marglik_adj_grad at the arxiv shape (with / without candidate pairs)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+import laplace_gnn_amd as lg
+
+w, ei, X, tri, try_ = bench.make_workload("arxiv", "cuda")
+torch.manual_seed(0)
+model = lg.GCN(w["F"], w["H"], w["C"], 2, X, ei, symmetric=True).to("cuda")
+loader = lg.TensorBatchLoader(tri.cuda(), try_.cuda(), batch_size=w["batch"])
+la = lg.KronLaplace(model, "classification")
+la.fit(loader)
+for cand in (None, torch.randint(0, w["N"], (2, 100_000), generator=torch.Generator().manual_seed(1)).cuda()):
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = la.neg_marglik_adj_grad(loader, candidates=cand)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("candidates" if cand is not None else "stored only", f"{dt * 1e3:.1f} ms", float(out[0]), float(out[2].abs().sum()))
