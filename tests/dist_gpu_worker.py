@@ -40,6 +40,33 @@ def main():
         ld.fit(loader)
         assert rel(ld.H.cpu().numpy(), g["diag_H"]) < 1e-4, (name, rank)
         assert la.n_data == int(g["n_data"]) and ld.n_data == int(g["n_data"])
+        # last-layer full GGN: every rank's sample slices accumulate pair-major, ONE in-place all-reduce of the pair
+        # buffers, one placement; compared with the single-call result of the whole training set
+        ll = lg.Laplace(model, "classification", "last_layer", "full")
+        ll.fit(loader)
+        eng = model.engine
+        p_ll = ll.n_params
+        Href = torch.zeros(p_ll, p_ll, device="cuda")
+        lref = torch.zeros(1, device="cuda")
+        eng.lastlayer_full_accumulate(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(), Href, lref)
+        assert rel(ll.H.cpu().numpy(), Href.cpu().numpy()) < 1e-5, (name, rank)
+        assert abs(float(ll.loss) - float(lref)) < 1e-5 * abs(float(lref))
+        ll.fit(loader, override=False)  # the earlier, already reduced H must not pass through the all-reduce again
+        assert rel(ll.H.cpu().numpy(), 2 * Href.cpu().numpy()) < 1e-5, (name, rank)
+        # empirical Fisher backend: whole batches round-robin through backend.kron
+        le = lg.Laplace(model, "classification", "all", "kron", backend=lg.HipEF)
+        le.fit(loader)
+        le1 = lg.KronLaplace(model, "classification", backend=lg.HipEF)
+        le1.fit(loader, process_group=dist.new_group([rank]))  # a one-rank group: the single-process fit
+        for Fa, Fb in zip(le.H_facs.kfacs, le1.H_facs.kfacs):
+            for a_, b_ in zip(Fa, Fb):
+                assert rel(a_.cpu().numpy(), b_.cpu().numpy()) < 1e-5, (name, rank, "ef")
+        if "adjgrad_vals" in g:  # gradient w.r.t. the adjacency: batches dealt round-robin, one all-reduce of the accumulators
+            lp = lg.KronLaplace(model, "classification", prior_precision=float(g["adjgrad_prior"]))
+            lp.fit(loader)
+            cand = torch.from_numpy(np.stack([g["adjgrad_ne_row"], g["adjgrad_ne_col"]])).cuda()
+            val, ei, grad, gc = lp.neg_marglik_adj_grad(loader, candidates=cand)
+            assert rel(grad.cpu().numpy(), g["adjgrad_vals"]) < 1e-3 and rel(gc.cpu().numpy(), g["adjgrad_ne_val"]) < 1e-3
         model.engine.check_async_errors()
     dist.barrier()
     if rank == 0:
