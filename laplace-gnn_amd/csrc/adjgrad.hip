@@ -80,6 +80,73 @@ int launch_sddmm(const Csr& m, int64_t nrows, const int32_t* rows, const int32_t
   return 0;
 }
 
+// The two consumers of g0bar's rows in ONE pass over the entries of the active rows a of P (they gather the same rows):
+//     out[(a, b)] += sum_c <u_c[a], R_c[b]>                      (the SDDMM of the step g0 = P^T u)
+//     U_c[a]       = dact[a] * sum_b P[a, b] R_c[b]               (ubar: the SpMM of the step behind it; overwrites u)
+// One wave per row; PC planes at a time: the row's u_c and the running sums stay in registers, every gathered row of R
+// is used for both.  Halves the gather traffic of the two steps and skips the 42 % of rows whose u is zero.
+template <int PC>
+__global__ __launch_bounds__(256) void sddmm_spmm_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                         const float* __restrict__ val, const int32_t* __restrict__ rows,
+                                                         const int32_t* __restrict__ nrows_dev, float* __restrict__ U,
+                                                         const float* __restrict__ R, int64_t N, int64_t width,
+                                                         int64_t nplanes, const float* __restrict__ dact,
+                                                         float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int c0 = lane * 4;
+  const bool col_ok = c0 < width;  // width % 4 == 0, <= 256 (launcher)
+  const int64_t total = rows ? int64_t(*nrows_dev) : N;
+  const int64_t plane = N * width;
+  for (int64_t w = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); w < total; w += int64_t(gridDim.x) * 4) {
+    const int64_t a = rows ? int64_t(rows[w]) : w;
+    const int32_t s = rowptr[a], e = rowptr[a + 1];
+    float4 dm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col_ok) dm = *reinterpret_cast<const float4*>(dact + a * width + c0);
+    for (int64_t pc0 = 0; pc0 < nplanes; pc0 += PC) {
+      float4 u[PC], acc[PC];
+#pragma unroll
+      for (int c = 0; c < PC; ++c) {
+        acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        u[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col_ok && pc0 + c < nplanes) u[c] = *reinterpret_cast<const float4*>(U + (pc0 + c) * plane + a * width + c0);
+      }
+      for (int32_t p = s; p < e; ++p) {
+        const int64_t b = col[p];
+        const float v = val[p];
+        float4 x[PC];
+#pragma unroll
+        for (int c = 0; c < PC; ++c) {
+          x[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (col_ok && pc0 + c < nplanes) x[c] = *reinterpret_cast<const float4*>(R + (pc0 + c) * plane + b * width + c0);
+        }
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < PC; ++c) {
+          acc[c].x = fmaf(v, x[c].x, acc[c].x); acc[c].y = fmaf(v, x[c].y, acc[c].y);
+          acc[c].z = fmaf(v, x[c].z, acc[c].z); acc[c].w = fmaf(v, x[c].w, acc[c].w);
+          d += u[c].x * x[c].x + u[c].y * x[c].y + u[c].z * x[c].z + u[c].w * x[c].w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        if (lane == 0) out[p] += d;
+      }
+#pragma unroll
+      for (int c = 0; c < PC; ++c)
+        if (col_ok && pc0 + c < nplanes)
+          *reinterpret_cast<float4*>(U + (pc0 + c) * plane + a * width + c0) =
+              make_float4(dm.x * acc[c].x, dm.y * acc[c].y, dm.z * acc[c].z, dm.w * acc[c].w);
+    }
+  }
+}
+// rows that are not active: ubar = 0 there (u was zero and stays zero: nothing to do; the planes were written in full by
+// the GEMM, whose inactive rows are zeros already)
+
+__global__ void mask_values_by_flag_kernel(const int32_t* __restrict__ col, const float* __restrict__ val, int64_t nnz,
+                                           const uint8_t* __restrict__ active, float* __restrict__ out) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; p < nnz; p += stride) out[p] = active[col[p]] ? val[p] : 0.f;
+}
+
 // The same contraction on an arbitrary list of (a, b) pairs (candidate edges that are NOT stored: the reference's dense
 // adj.grad has an entry for every pair, which is how its structure learning proposes new edges).
 template <int LPR>
@@ -413,7 +480,7 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   LGNN_REQUIRE(K == 0 || (cand_a && cand_b && grad_cand), "candidate pairs without their buffers");
   LGNN_CALL(check_model(h));
   LGNN_REQUIRE(M > 0 && idx && y && gamma_B0 && gamma_B1 && grad_P && out_bar, "empty batch or null pointers");
-  LGNN_CALL(forward_ensure(h, s));
+  LGNN_CALL(forward_ensure_aux(h, s));  // act'(h_1) is part of the auxiliary forward products
   const int64_t N = h->N, C = h->dims[2], H = h->dims[1], CC = C * C;
   const bool fork_exact = (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0;
   LGNN_CALL(batch_prologue(h, idx, y, M, true, fork_exact, nullptr, s));
@@ -431,6 +498,12 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
                           h->ws.select_tmp, s));
   LGNN_CALL(h->ws.jac.reserve(size_t(M) * CC * 4));  // Vbar [M][C][C]
   float* vbar = h->ws.jac.as<float>();
+  // values of P^T with the columns of inactive (all-zero) source rows removed
+  LGNN_CALL(h->ws.val_act.reserve(size_t(std::max<int64_t>(h->nnz, 1)) * 4));
+  float* val_act = h->ws.val_act.as<float>();
+  hipLaunchKernelGGL(mask_values_by_flag_kernel, dim3(unsigned(std::min<int64_t>(cdiv(std::max<int64_t>(h->nnz, 1), 256), 4096))),
+                     dim3(256), 0, s, h->PT.col, h->PT.val, h->nnz, h->ws.active.as<uint8_t>(), val_act);
+  LGNN_HIP_CHECK(hipGetLastError());
 
   // class chunks: three [cc][N][H] plane buffers (u / ubar, g0, g0bar) + g1bar [cc][N][C] under the workspace cap
   const int64_t per_class = N * (3 * H + C) * 4;
@@ -449,25 +522,34 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
     GemmEpilogue ep;
     ep.hact = h->fc.hact_p[0]; ep.hact_ld = h->fc.hact_ld[0]; ep.act = h->act; ep.hact_row_mod = N;
     LGNN_CALL(launch_gemm(g1c, C, h->W[1], H, U, H, cc * N, C, H, ep, s));
-    // g0 = P^T u
+    // g0 = P^T u  (source rows with u = 0 are not gathered: their values are zeroed)
     SpmmArgs sa{};
-    sa.rowptr = h->PT.rowptr; sa.col = h->PT.col; sa.val = h->PT.val; sa.nrows = N;
+    sa.rowptr = h->PT.rowptr; sa.col = h->PT.col; sa.val = val_act; sa.nrows = N;
     sa.in = U; sa.in_ld = H; sa.in_plane_stride = N * H; sa.out = G0; sa.out_ld = H; sa.out_plane_stride = N * H;
     sa.width = H; sa.out_act = -1;
     LGNN_CALL(launch_spmm_ex(sa, cc, s));
     // g0bar = 2 g0 Gamma_B0
     LGNN_CALL(sgemm_rm(s, cc * N, H, H, 2.f, G0, H, gamma_B0, H, 0.f, G0B, H));
-    // gradP[(a,b)] += sum_c <u_c[a], g0bar_c[b]>; u is zero outside the active rows
-    LGNN_CALL(launch_sddmm(h->P, N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(), U, H, N * H, G0B, H, N * H,
-                           H, cc, grad_P, s));
+    // gradP[(a,b)] += sum_c <u_c[a], g0bar_c[b]> and ubar = mask * (P g0bar) (overwrites u), both over the active rows only
+    // (u, hence ubar's consumers, vanish elsewhere); candidates first: they read u before it is overwritten
     LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, U, H, N * H, G0B, H, N * H, H, cc, h->ws.active.as<uint8_t>(), grad_cand, s));
-    // ubar = mask * (P g0bar)  (overwrites u)
-    SpmmArgs sb{};
-    sb.rowptr = h->P.rowptr; sb.col = h->P.col; sb.val = h->P.val; sb.nrows = N;
-    sb.in = G0B; sb.in_ld = H; sb.in_plane_stride = N * H; sb.out = U; sb.out_ld = H; sb.out_plane_stride = N * H;
-    sb.width = H; sb.out_act = -1;
-    sb.hact = h->fc.hact_p[0]; sb.hact_ld = h->fc.hact_ld[0]; sb.act = h->act;
-    LGNN_CALL(launch_spmm_ex(sb, cc, s));
+    if (H % 4 == 0 && H <= 256) {
+      // (candidate pairs reach g1bar at arbitrary rows, so ubar is then needed everywhere, not on the active rows only)
+      const int32_t* rows = K > 0 ? nullptr : h->ws.act_list.as<int32_t>();
+      hipLaunchKernelGGL(sddmm_spmm_kernel<8>, dim3(unsigned(std::min<int64_t>(cdiv(N, 4), 8192))), dim3(256), 0, s, h->P.rowptr,
+                         h->P.col, h->P.val, rows, h->ws.act_count.as<int32_t>(), U, G0B, N, H, cc, h->fc.dact0.as<float>(),
+                         grad_P);
+      LGNN_HIP_CHECK(hipGetLastError());
+    } else {
+      LGNN_CALL(launch_sddmm(h->P, N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(), U, H, N * H, G0B, H, N * H,
+                             H, cc, grad_P, s));
+      SpmmArgs sb{};
+      sb.rowptr = h->P.rowptr; sb.col = h->P.col; sb.val = h->P.val; sb.nrows = N;
+      sb.in = G0B; sb.in_ld = H; sb.in_plane_stride = N * H; sb.out = U; sb.out_ld = H; sb.out_plane_stride = N * H;
+      sb.width = H; sb.out_act = -1;
+      sb.hact = h->fc.hact_p[0]; sb.hact_ld = h->fc.hact_ld[0]; sb.act = h->act;
+      LGNN_CALL(launch_spmm_ex(sb, cc, s));
+    }
     // g1bar = ubar W1^T + 2 g1 Gamma_B1     [cc * N, C]
     LGNN_CALL(sgemm_rm(s, cc * N, C, H, 1.f, U, H, h->Wt[1].as<float>(), C, 0.f, G1B, C));
     LGNN_CALL(sgemm_rm(s, cc * N, C, C, 2.f, g1c, C, gamma_B1, C, 1.f, G1B, C));
