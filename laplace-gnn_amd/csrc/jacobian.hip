@@ -90,8 +90,91 @@ int gram_rows_sgemm(const float* G, int64_t rows, int64_t P, float scale, float*
   return 0;
 }
 
+// Closed-form Jacobians of 1- and 2-layer models: no planes over all N nodes, no GEMM with K = N.  With a = idx[m],
+// E[v] = [what the first Linear multiplies at node v | 1-column] and d_v = act'(h_1[v]):
+//   last layer   d f_c / d W_last = e_c (x) phi_a,   d f_c / d b_last = s_a e_c            (phi, s: feat_views of diag.hip)
+//   first layer  GCN      : d f_c / d W_0[h, :] = w_c[h] sum_u P[a,u] d_u[h] (P X)[u, :],  bias: ... rowsum(P)[u]
+//                GraphSAGE: d f_c / d W_0[h, :] = ws_c[h] d_a[h] cat_0[a, :] + wn_c[h] sum_u P[a,u] d_u[h] cat_0[u, :],  bias: ... 1
+// One workgroup per sample: T_self / T_neigh [H x (in_0 + 1)] tiles are built once from the ~15 neighbours and every
+// class row of J is a row scaling of them -- the kernel is bound by writing J (M * C * P floats, like the reference's).
+__global__ __launch_bounds__(256) void jac_closed_form_kernel(
+    const int64_t* __restrict__ idx, int64_t M, int64_t N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ val, int L, int sage, int64_t in0, int64_t H, int64_t C,
+    const float* __restrict__ E0, int64_t e0_ld, const float* __restrict__ e0_bias /* null: 1 */,
+    const float* __restrict__ dact, const float* __restrict__ W1, int64_t w1_ld,
+    const float* __restrict__ PhiL, int64_t phil_ld, int64_t phil_w, const float* __restrict__ phil_bias /* null: 1 */,
+    int64_t P, float* __restrict__ J, int* __restrict__ bad) {
+  const int64_t m = blockIdx.x;
+  const int64_t a = idx[m];
+  float* __restrict__ Jm = J + m * C * P;
+  const int64_t t0 = int64_t(blockIdx.y) * blockDim.x + threadIdx.x, tstep = int64_t(gridDim.y) * blockDim.x;
+  if (a < 0 || a >= N) {
+    if (t0 == 0) bad[1] = 1;
+    for (int64_t t = t0; t < C * P; t += tstep) Jm[t] = 0.f;
+    return;
+  }
+  const int64_t in_last = phil_w;  // columns of the last weight
+  const int64_t off_last = L == 2 ? H * in0 + H : 0;
+  // last layer: row c of J holds phi_a in its own block, zeros in the other classes' blocks, s_a at its bias entry
+  for (int64_t t = t0; t < C * (C * in_last + C); t += tstep) {
+    const int64_t c = t / (C * in_last + C), q = t - c * (C * in_last + C);
+    float v = 0.f;
+    if (q < C * in_last) { if (q / in_last == c) v = PhiL[a * phil_ld + (q - c * in_last)]; }
+    else if (q - C * in_last == c) v = phil_bias ? phil_bias[a] : 1.f;
+    Jm[c * P + off_last + q] = v;
+  }
+  if (L == 1) return;
+  // first layer: element (h, i) with i <= in0 (i == in0: the bias entry of unit h)
+  const int32_t ps = rowptr[a], pe = rowptr[a + 1];
+  const int64_t in1 = in0 + 1;
+  for (int64_t t = t0; t < H * in1; t += tstep) {
+    const int64_t hh = t / in1, i = t - hh * in1;
+    float tn = 0.f;
+    for (int32_t p = ps; p < pe; ++p) {
+      const int64_t u = col[p];
+      const float e = i < in0 ? E0[u * e0_ld + i] : (e0_bias ? e0_bias[u] : 1.f);
+      tn = fmaf(val[p] * dact[u * H + hh], e, tn);
+    }
+    float ts = 0.f;
+    if (sage) ts = dact[a * H + hh] * (i < in0 ? E0[a * e0_ld + i] : 1.f);
+    const int64_t dst = i < in0 ? hh * in0 + i : H * in0 + hh;
+    for (int64_t c = 0; c < C; ++c) {
+      const float v = sage ? W1[c * w1_ld + hh] * ts + W1[c * w1_ld + H + hh] * tn : W1[c * w1_ld + hh] * tn;
+      Jm[c * P + dst] = v;
+    }
+  }
+}
+
+static int jacobians_closed_form(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out, hipStream_t s) {
+  LGNN_CALL(forward_ensure_aux(h, s));
+  const int L = h->L;
+  const int64_t N = h->N, C = h->dims[L], H = L == 2 ? h->dims[1] : 0, in0 = h->in_dim[0], P = h->n_params;
+  const bool sage = h->kind == LGNN_KIND_SAGE;
+  int* bad = h->ws.flags.as<int>();
+  if (f_out) LGNN_CALL(launch_gather_rows(h->fc.out.as<float>(), C, N, idx, M, C, f_out, bad + 2, s));
+  // first-layer feature rows: GCN (P X)[u] with the bias entry rowsum(P)[u]; GraphSAGE cat_0[u] with 1
+  const float* E0 = sage ? h->fc.lin_in_p[0] : h->fc.prop_in[0].as<float>();
+  const int64_t e0_ld = sage ? h->fc.lin_in_ld[0] : h->fc.prop_ld[0];
+  const float* e0_bias = sage ? nullptr : h->fc.rowsum.as<float>();
+  // last-layer feature row seen from the batch node
+  const float* PhiL = sage ? h->fc.lin_in_p[L - 1] : h->fc.prop_in[L - 1].as<float>();
+  const int64_t phil_ld = sage ? h->fc.lin_in_ld[L - 1] : h->fc.prop_ld[L - 1];
+  const float* phil_bias = sage ? nullptr : h->fc.rowsum.as<float>();
+  LGNN_REQUIRE(M < (int64_t(1) << 31), "too many samples");
+  // enough workgroups per sample to fill the chip at small M
+  const unsigned per = unsigned(std::max<int64_t>(1, std::min<int64_t>(cdiv(std::max<int64_t>(H * (in0 + 1), C * (C * h->in_dim[L - 1] + C)), 256), cdiv(2048, M))));
+  hipLaunchKernelGGL(jac_closed_form_kernel, dim3(unsigned(M), per), dim3(256), 0, s, idx, M, N, h->P.rowptr, h->P.col, h->P.val, L,
+                     sage ? 1 : 0, in0, H, C, E0, e0_ld, e0_bias, L == 2 ? h->fc.dact0.as<float>() : nullptr,
+                     L == 2 ? h->W[1] : nullptr, L == 2 ? h->in_dim[1] : 0, PhiL, phil_ld, h->in_dim[L - 1], phil_bias, P, J, bad);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out, hipStream_t s) {
   LGNN_REQUIRE(h->L > 0, "no model bound");
+  // 1- and 2-layer models: closed form (LGNN_JAC_PLANES=1 forces the generic plane route, which deeper models use)
+  const bool force_planes = getenv("LGNN_JAC_PLANES") != nullptr;
+  if (h->L <= 2 && !force_planes) return jacobians_closed_form(h, idx, M, J, f_out, s);
   LGNN_CALL(forward_ensure(h, s));
   const int64_t N = h->N;
   const int L = h->L;

@@ -1,6 +1,8 @@
 """GPU parity beyond the golden sizes: (a) seeded mid-size graphs against the CPU oracle, incl. edge
 cases the domain has (skewed degrees, empty edge list, single-sample batch, ragged last batch,
 3-layer models); (b) BASELINE-size (arxiv-shaped) runs checked through size-independent properties."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -378,6 +380,13 @@ def test_diag_lastlayer_jacobians_random_configurations_vs_oracle(seed):
     Js, f = eng.jacobians(idx.cuda())
     oJ, of = O.jacobians_batch(om, idx.numpy())
     assert close(Js.cpu().numpy(), oJ) and close(f.cpu().numpy(), of), ("jacobians", cfg)
+    if L <= 2:  # the closed form served that call; the generic plane route (what deeper models use) must agree
+        os.environ["LGNN_JAC_PLANES"] = "1"
+        try:
+            Jp, _ = eng.jacobians(idx.cuda())
+        finally:
+            del os.environ["LGNN_JAC_PLANES"]
+        assert close(Jp.cpu().numpy(), oJ), ("jacobians, plane route", cfg)
     if L <= 2 and kind == "gcn":
         Hd = torch.zeros(eng.n_params, device="cuda")
         loss = torch.zeros(1, device="cuda")
