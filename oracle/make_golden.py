@@ -297,13 +297,18 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
             Mn.sample = orig_sample
         out["ggnmc_labels_diag"], out["ggnmc_labels_full"] = np.stack(first), np.stack(second)
 
-    if kind == "gcn" and layers == 2:
+    if layers == 2:
         # 8(f)-4: what the GNN driver differentiates (gnn/marglik_training.py:197-216): -log marglik of a KronLaplace fit
         # w.r.t. the dense adjacency parameter of the STE model (gnn/models/models.py:65-118), same weights (same seed,
         # same construction order), prior precision 0.7.  Stored: the gradient on the stored entries of the 0/1
         # adjacency (row-major = adj_nz_row / adj_nz_col order) and on 200 random non-edges.
+        # GraphSAGE: STEGraphSAGE (gnn/models/models.py:121-183), mean aggregation over the binarised matrix itself.
         torch.manual_seed(seed)
-        ste = ns.gnn_models.STEGCN(f, h, c, layers, X, adj0.clone(), dropout_p=0.5, threshold=0.5, symmetric=symmetric)
+        if kind == "gcn":
+            ste = ns.gnn_models.STEGCN(f, h, c, layers, X, adj0.clone(), dropout_p=0.5, threshold=0.5, symmetric=symmetric)
+        else:
+            ste = ns.gnn_models.STEGraphSAGE(f, h, c, layers, X, adj0.clone(), num_sampled_nodes_per_hop=None,
+                                             dropout_p=0.5, threshold=0.5, symmetric=symmetric)
         ste.eval()
         for a, b in zip(ste.convs, model.convs):
             assert torch.equal(a.lin.weight, b.lin.weight) and torch.equal(a.lin.bias, b.lin.bias)
@@ -387,6 +392,8 @@ def main():
     make_case(ns, torch, "sage_small_3batch_s1", "sage", **small, n_train=33, batch_size=12,
               seed=1, isolated=4)
     make_case(ns, torch, "sage_mid_2batch_s2", "sage", **mid, n_train=150, batch_size=100, seed=2)
+    make_case(ns, torch, "sage_small_3batch_sym_s3", "sage", **small, n_train=33, batch_size=12, seed=3, symmetric=True,
+              isolated=2)
     # three layers: the reference only builds them once the live breakpoint at gnn/models/base_gnn.py:109 is a no-op
     # (ref_loader installs one); kron / diag / full GGN / Jacobians all come from the reference's own code
     small3 = dict(n=64, f=12, h=8, c=3, layers=3, n_edges=150)
