@@ -19,6 +19,17 @@
 //                    normalize_adj backward: P[a,b] = d_a A[b,a] d_b, d = rowsum(A)^-1/2; diagonal -> 0 (overwritten
 //                    by fill_diagonal_(1) after the STE); symmetric models average (i,j) and (j,i)
 // The dense GEMMs with the (small) Gamma / weight matrices are plain library calls (rocBLAS).
+//
+// GraphSAGE (STEGraphSAGE, gnn/models/models.py:121-183; mean aggregation P = A / rowsum, gnn/models/layers.py:18-24): the
+// top layer is not propagated, so everything per batch lives on the batch rows and their neighbours -- sample-major rows
+// r = (m, c) instead of planes over all N nodes:
+//   per batch:       DCAT = S W1 [M C, 2H] (S = the seed blocks)     dh[v] = DCAT_self[v] + sum_{u in batch} P[u,v] DCAT_neigh[u]
+//                    g0 = mask * dh on the ACTIVE rows (batch + neighbours, compacted)         g0bar = 2 g0 Gamma_B0
+//                    gradP[(a,b)] += <DCAT_neigh[a], mask_b * g0bar[b]>,  dcatbar[a] = [mask_a g0bar[a] | sum_b P[a,b] mask_b g0bar[b]]
+//                    g1bar = dcatbar W1^T + 2 S Gamma_B1 = Vbar                                   (then as above)
+//   once per fit:    T1 = outbar W1 + 2 (T/N) cat1 Gamma_A1;  gradP += <T1_neigh[a], H1[b]>;  Z0bar = mask * (T1_self + P^T T1_neigh)
+//                    XNbar = Z0bar W0_neigh + 2 (T/N) (cat0 Gamma_A0)_neigh;  gradP += <XNbar[a], X[b]>
+//                    mean_agg backward: gA[a,b] = (gradP[a,b] - sum_j gradP[a,j] P[a,j]) / max(rowsum_a, 1)
 #include <rocblas/rocblas.h>
 
 #include "device_utils.h"
@@ -465,10 +476,344 @@ int sgemm_rm(hipStream_t s, int64_t R, int64_t Nout, int64_t K, float alpha, con
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// GraphSAGE
+// ---------------------------------------------------------------------------------------------------------------------------
+// active[v] = 1 for the batch nodes and every column of their P rows (the rows where dh can be non-zero)
+__global__ void sage_mark_active_kernel(const int64_t* __restrict__ idx, int64_t M, int64_t N, const int32_t* __restrict__ rowptr,
+                                        const int32_t* __restrict__ col, uint8_t* __restrict__ active) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int64_t a = idx[m];
+  if (a < 0 || a >= N) return;
+  if (lane == 0) active[a] = 1;
+  for (int32_t p = rowptr[a] + lane; p < rowptr[a + 1]; p += 64) active[col[p]] = 1;
+}
+
+__global__ void sage_index_active_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ count,
+                                         int32_t* __restrict__ widx) {
+  const int64_t w = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (w < *count) widx[list[w]] = int32_t(w);
+}
+
+// G0[(w, c)] = act'(h_1[v]) * (DCAT[(pos[v], c), :H] + sum_{u in row v of P^T, u in batch} P^T[v,u] DCAT[(pos[u], c), H:]),
+// v = list[w], classes c0 <= c < c0 + cc.  One wave per active node, PC classes at a time in registers; H % 4 == 0, <= 256.
+template <int PC>
+__global__ __launch_bounds__(256) void sage_dh_kernel(const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_col,
+                                                      const float* __restrict__ t_val, const int32_t* __restrict__ list,
+                                                      const int32_t* __restrict__ count, const int32_t* __restrict__ pos,
+                                                      const float* __restrict__ dcat, const float* __restrict__ dact,
+                                                      int64_t C, int64_t H, int64_t c0, int64_t cc, float* __restrict__ G0) {
+  const int lane = threadIdx.x & 63;
+  const int k4 = lane * 4;
+  const bool col_ok = k4 < H;
+  const int64_t total = *count;
+  for (int64_t w = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); w < total; w += int64_t(gridDim.x) * 4) {
+    const int64_t v = list[w];
+    const int32_t mv = pos[v];
+    const int32_t s = t_rowptr[v], e = t_rowptr[v + 1];
+    float4 dm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col_ok) dm = *reinterpret_cast<const float4*>(dact + v * H + k4);
+    for (int64_t pc0 = 0; pc0 < cc; pc0 += PC) {
+      float4 acc[PC];
+#pragma unroll
+      for (int c = 0; c < PC; ++c) {
+        acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col_ok && pc0 + c < cc && mv != INT32_MAX)
+          acc[c] = *reinterpret_cast<const float4*>(dcat + (int64_t(mv) * C + c0 + pc0 + c) * 2 * H + k4);
+      }
+      for (int32_t p = s; p < e; ++p) {
+        const int32_t mu = pos[t_col[p]];
+        if (mu == INT32_MAX) continue;  // wave-uniform
+        const float a = t_val[p];
+#pragma unroll
+        for (int c = 0; c < PC; ++c) {
+          if (col_ok && pc0 + c < cc) {
+            const float4 x = *reinterpret_cast<const float4*>(dcat + (int64_t(mu) * C + c0 + pc0 + c) * 2 * H + H + k4);
+            acc[c].x = fmaf(a, x.x, acc[c].x); acc[c].y = fmaf(a, x.y, acc[c].y);
+            acc[c].z = fmaf(a, x.z, acc[c].z); acc[c].w = fmaf(a, x.w, acc[c].w);
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < PC; ++c)
+        if (col_ok && pc0 + c < cc)
+          *reinterpret_cast<float4*>(G0 + (w * cc + pc0 + c) * H + k4) =
+              make_float4(dm.x * acc[c].x, dm.y * acc[c].y, dm.z * acc[c].z, dm.w * acc[c].w);
+    }
+  }
+}
+
+// For the first occurrence m of every batch node a = idx[m] and the classes of the chunk, in one pass over row a of P:
+//     out[(a, b)]        += sum_c <DCAT[(m, c), H:], x_c[b]>,     x_c[b] = act'(h_1[b]) * G0B[(widx[b], c)]
+//     DCATB[(m, c), H:]   = sum_b P[a, b] x_c[b]                    DCATB[(m, c), :H] = x_c[a]
+// (later occurrences of a node: zero rows -- their seed rows are zero and Vbar is read at the first occurrence.)
+template <int PC>
+__global__ __launch_bounds__(256) void sage_sddmm_spmm_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                              const float* __restrict__ val, const int64_t* __restrict__ idx,
+                                                              int64_t M, int64_t N, const int32_t* __restrict__ pos,
+                                                              const int32_t* __restrict__ widx, const float* __restrict__ dcat,
+                                                              const float* __restrict__ G0B, const float* __restrict__ dact,
+                                                              int64_t C, int64_t H, int64_t c0, int64_t cc,
+                                                              float* __restrict__ dcatb, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int k4 = lane * 4;
+  const bool col_ok = k4 < H;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t m = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); m < M; m += int64_t(gridDim.x) * 4) {
+    const int64_t a = idx[m];
+    const bool first = a >= 0 && a < N && pos[a] == m;
+    if (!first) {
+      for (int64_t c = 0; c < cc; ++c)
+        if (col_ok) {
+          float* __restrict__ r = dcatb + (m * C + c0 + c) * 2 * H;
+          *reinterpret_cast<float4*>(r + k4) = zero4;
+          *reinterpret_cast<float4*>(r + H + k4) = zero4;
+        }
+      continue;
+    }
+    const int32_t s = rowptr[a], e = rowptr[a + 1];
+    const int64_t wa = widx[a];
+    float4 da = zero4;
+    if (col_ok) da = *reinterpret_cast<const float4*>(dact + a * H + k4);
+    for (int64_t pc0 = 0; pc0 < cc; pc0 += PC) {
+      float4 D[PC], acc[PC];
+#pragma unroll
+      for (int c = 0; c < PC; ++c) {
+        acc[c] = zero4;
+        D[c] = zero4;
+        if (col_ok && pc0 + c < cc) D[c] = *reinterpret_cast<const float4*>(dcat + (m * C + c0 + pc0 + c) * 2 * H + H + k4);
+      }
+      for (int32_t p = s; p < e; ++p) {
+        const int64_t b = col[p];
+        const int64_t wb = widx[b];
+        const float v = val[p];
+        float4 db = zero4;
+        if (col_ok) db = *reinterpret_cast<const float4*>(dact + b * H + k4);
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < PC; ++c) {
+          if (col_ok && pc0 + c < cc) {
+            float4 x = *reinterpret_cast<const float4*>(G0B + (wb * cc + pc0 + c) * H + k4);
+            x.x *= db.x; x.y *= db.y; x.z *= db.z; x.w *= db.w;
+            acc[c].x = fmaf(v, x.x, acc[c].x); acc[c].y = fmaf(v, x.y, acc[c].y);
+            acc[c].z = fmaf(v, x.z, acc[c].z); acc[c].w = fmaf(v, x.w, acc[c].w);
+            d += D[c].x * x.x + D[c].y * x.y + D[c].z * x.z + D[c].w * x.w;
+          }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        if (lane == 0) out[p] += d;  // one wave owns row a (first occurrence): a single writer per entry inside a launch
+      }
+#pragma unroll
+      for (int c = 0; c < PC; ++c)
+        if (col_ok && pc0 + c < cc) {
+          float* __restrict__ r = dcatb + (m * C + c0 + pc0 + c) * 2 * H;
+          const float4 x = *reinterpret_cast<const float4*>(G0B + (wa * cc + pc0 + c) * H + k4);
+          *reinterpret_cast<float4*>(r + k4) = make_float4(da.x * x.x, da.y * x.y, da.z * x.z, da.w * x.w);
+          *reinterpret_cast<float4*>(r + H + k4) = acc[c];
+        }
+    }
+  }
+}
+
+// candidate pairs (a, b): only a in the batch and b active contribute
+__global__ __launch_bounds__(256) void sage_cand_kernel(const int32_t* __restrict__ ca, const int32_t* __restrict__ cb, int64_t K,
+                                                        const int32_t* __restrict__ pos, const int32_t* __restrict__ widx,
+                                                        const float* __restrict__ dcat, const float* __restrict__ G0B,
+                                                        const float* __restrict__ dact, int64_t C, int64_t H, int64_t c0,
+                                                        int64_t cc, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t k = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (k >= K) return;
+  const int64_t a = ca[k], b = cb[k];
+  const int32_t m = pos[a];
+  const int32_t wb = widx[b];
+  if (m == INT32_MAX || wb < 0) return;
+  float acc = 0.f;
+  for (int64_t c = 0; c < cc; ++c) {
+    const float* __restrict__ D = dcat + (int64_t(m) * C + c0 + c) * 2 * H + H;
+    const float* __restrict__ x = G0B + (int64_t(wb) * cc + c) * H;
+    for (int64_t q = lane; q < H; q += 64) acc += D[q] * dact[b * H + q] * x[q];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) out[k] += acc;
+}
+
+// Vbar[m][c][k] = g1bar[(first occurrence of idx[m], c)][k]   (every sample, duplicates included)
+__global__ void sage_vbar_kernel(const int64_t* __restrict__ idx, int64_t M, int64_t N, int64_t CC,
+                                 const int32_t* __restrict__ pos, const float* __restrict__ g1bar, float* __restrict__ vbar) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= M * CC) return;
+  const int64_t m = t / CC, q = t - m * CC;
+  const int64_t a = idx[m];
+  if (a < 0 || a >= N) return;
+  vbar[t] = g1bar[int64_t(pos[a]) * CC + q];
+}
+
+// mean_agg backward: rowdot[a] = sum_j gP[a,j] P[a,j];  gA[(a,b)] = (gP[(a,b)] - rowdot[a]) / rowsum_a  (stored rows: rowsum >= 1)
+__global__ void sage_adj_grad_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ val,
+                                     const float* __restrict__ gP, int64_t N, float* __restrict__ rowdot,
+                                     float* __restrict__ gA) {
+  const int64_t a = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  const int32_t s = rowptr[a], e = rowptr[a + 1];
+  float acc = 0.f;
+  for (int32_t p = s; p < e; ++p) acc += gP[p] * val[p];
+  rowdot[a] = acc;
+  for (int32_t p = s; p < e; ++p) gA[p] = (gP[p] - acc) * val[p];
+}
+// candidate (a, b) = entry (a, b) of A; an empty row's divisor is the constant 1 (layers.py:20) and carries no row term
+__global__ void sage_cand_adj_grad_kernel(const int32_t* __restrict__ ca, int64_t K, const int32_t* __restrict__ rowptr,
+                                          const float* __restrict__ gPc, const float* __restrict__ rowdot,
+                                          float* __restrict__ out) {
+  const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const int64_t a = ca[k];
+  const int32_t deg = rowptr[a + 1] - rowptr[a];
+  out[k] = deg > 0 ? (gPc[k] - rowdot[a]) / float(deg) : gPc[k];
+}
+
+__global__ void relu_mask_ld_kernel(float* __restrict__ x, const float* __restrict__ dact, int64_t n) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < n; q += stride) x[q] *= dact[q];
+}
+
 int check_model(const lgnn_ctx* h) {
-  LGNN_REQUIRE(h->L == 2 && h->kind == LGNN_KIND_GCN, "adjacency gradient: 2-layer GCN models (first slice of SURVEY.md 8(f)-4)");
+  LGNN_REQUIRE(h->L == 2, "adjacency gradient: 2-layer models (SURVEY.md 8(f)-4)");
   LGNN_REQUIRE(h->act == LGNN_ACT_RELU && h->lik == LGNN_LIK_CLASSIFICATION, "adjacency gradient: ReLU, classification");
   LGNN_REQUIRE(h->dims[2] <= 256, "adjacency gradient: at most 256 classes");
+  LGNN_REQUIRE(h->kind == LGNN_KIND_GCN || (h->dims[1] % 4 == 0 && h->dims[1] <= 256),
+               "adjacency gradient, GraphSAGE: hidden width a multiple of 4, at most 256");
+  return 0;
+}
+
+int sage_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bool fork_exact, const float* gamma_B0,
+                       const float* gamma_B1, float loss_scale, float* grad_P, float* out_bar, const int32_t* cand_a,
+                       const int32_t* cand_b, int64_t K, float* grad_cand, hipStream_t s) {
+  const int64_t N = h->N, C = h->dims[2], H = h->dims[1], CC = C * C;
+  LGNN_CALL(batch_prologue(h, idx, y, M, true, fork_exact, nullptr, s));
+  const float* S = h->ws.seeds.as<float>();  // [M][C][C]: row (m, c) = column c of the seed block, zero for later occurrences
+  LGNN_REQUIRE(M * C < (int64_t(1) << 31), "adjacency gradient: batch too large");
+  // DCAT / DCATB [M C, 2H], g1bar [M C, C], Vbar [M][C][C]
+  LGNN_CALL(h->ws.top.reserve(size_t(M) * C * 2 * H * 4 * 2 + size_t(M) * CC * 4 * 2));
+  float* dcat = h->ws.top.as<float>();
+  float* dcatb = dcat + M * C * 2 * H;
+  float* g1b = dcatb + M * C * 2 * H;
+  float* vbar = g1b + M * CC;
+  LGNN_CALL(sgemm_rm(s, M * C, 2 * H, C, 1.f, S, C, h->W[1], 2 * H, 0.f, dcat, 2 * H));
+  // active rows (batch + neighbours), their list and the inverse map
+  LGNN_CALL(h->ws.active.reserve(size_t(N)));
+  LGNN_HIP_CHECK(hipMemsetAsync(h->ws.active.p, 0, size_t(N), s));
+  hipLaunchKernelGGL(sage_mark_active_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, idx, M, N, h->P.rowptr, h->P.col,
+                     h->ws.active.as<uint8_t>());
+  LGNN_HIP_CHECK(hipGetLastError());
+  LGNN_CALL(h->ws.act_list.reserve(size_t(N) * 4));
+  LGNN_CALL(h->ws.act_count.reserve(64));
+  LGNN_CALL(compact_flags(h->ws.active.as<uint8_t>(), N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(),
+                          h->ws.select_tmp, s));
+  LGNN_CALL(h->ws.misc.reserve(size_t(N) * 4));
+  int32_t* widx = h->ws.misc.as<int32_t>();
+  LGNN_HIP_CHECK(hipMemsetAsync(widx, 0xFF, size_t(N) * 4, s));
+  hipLaunchKernelGGL(sage_index_active_kernel, dim3(unsigned(cdiv(N, 256))), dim3(256), 0, s, h->ws.act_list.as<int32_t>(),
+                     h->ws.act_count.as<int32_t>(), widx);
+  LGNN_HIP_CHECK(hipGetLastError());
+  int32_t na = 0;  // the GEMM over the active rows needs its row count on the host: one small synchronous copy per batch
+  LGNN_HIP_CHECK(hipMemcpyAsync(&na, h->ws.act_count.p, 4, hipMemcpyDeviceToHost, s));
+  LGNN_HIP_CHECK(hipStreamSynchronize(s));
+  if (na > 0) {
+    // class chunks: G0 and g0bar [na * cc, H] under the workspace cap
+    const int64_t per_class = int64_t(na) * H * 4 * 2;
+    const int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(C, h->ws_limit / std::max<int64_t>(per_class, 1)));
+    LGNN_REQUIRE(int64_t(na) * cc_max < (int64_t(1) << 31), "adjacency gradient: too many active rows per chunk");
+    LGNN_CALL(h->ws.planes_a.reserve(size_t(na) * cc_max * H * 4));
+    LGNN_CALL(h->ws.planes_b.reserve(size_t(na) * cc_max * H * 4));
+    h->ws.planes_a_zero_ptr = nullptr;
+    float* G0 = h->ws.planes_a.as<float>();
+    float* G0B = h->ws.planes_b.as<float>();
+    const float* dact = h->fc.dact0.as<float>();
+    for (int64_t c0 = 0; c0 < C; c0 += cc_max) {
+      const int64_t cc = std::min(cc_max, C - c0);
+      hipLaunchKernelGGL(sage_dh_kernel<8>, dim3(unsigned(std::min<int64_t>(cdiv(na, 4), 16384))), dim3(256), 0, s,
+                         h->PT.rowptr, h->PT.col, h->PT.val, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(),
+                         h->ws.pos.as<int32_t>(), dcat, dact, C, H, c0, cc, G0);
+      LGNN_HIP_CHECK(hipGetLastError());
+      LGNN_CALL(sgemm_rm(s, int64_t(na) * cc, H, H, 2.f, G0, H, gamma_B0, H, 0.f, G0B, H));
+      if (K > 0)
+        hipLaunchKernelGGL(sage_cand_kernel, dim3(unsigned(cdiv(K, 4))), dim3(256), 0, s, cand_a, cand_b, K,
+                           h->ws.pos.as<int32_t>(), widx, dcat, G0B, dact, C, H, c0, cc, grad_cand);
+      hipLaunchKernelGGL(sage_sddmm_spmm_kernel<8>, dim3(unsigned(std::min<int64_t>(cdiv(M, 4), 16384))), dim3(256), 0, s,
+                         h->P.rowptr, h->P.col, h->P.val, idx, M, N, h->ws.pos.as<int32_t>(), widx, dcat, G0B, dact, C, H, c0,
+                         cc, dcatb, grad_P);
+      LGNN_HIP_CHECK(hipGetLastError());
+    }
+    // g1bar = dcatbar W1^T + 2 S Gamma_B1     [M C, C]
+    LGNN_CALL(sgemm_rm(s, M * C, C, 2 * H, 1.f, dcatb, 2 * H, h->Wt[1].as<float>(), C, 0.f, g1b, C));
+    LGNN_CALL(sgemm_rm(s, M * C, C, C, 2.f, S, C, gamma_B1, C, 1.f, g1b, C));
+    hipLaunchKernelGGL(sage_vbar_kernel, dim3(unsigned(cdiv(M * CC, 256))), dim3(256), 0, s, idx, M, N, CC,
+                       h->ws.pos.as<int32_t>(), g1b, vbar);
+    LGNN_HIP_CHECK(hipGetLastError());
+  } else {
+    LGNN_HIP_CHECK(hipMemsetAsync(vbar, 0, size_t(M) * CC * 4, s));  // every index was out of range (flagged)
+  }
+  LGNN_REQUIRE(size_t(4) * 8 * C * 4 <= 64 * 1024, "too many classes for the seed adjoint kernel");
+  hipLaunchKernelGGL(seed_adjoint_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), size_t(4) * 8 * C * 4, s,
+                     h->fc.out.as<float>(), h->ws.probs.as<float>(), idx, static_cast<const int64_t*>(y), M, N, C, vbar,
+                     fork_exact ? 1 : 0, loss_scale, out_bar);
+  LGNN_HIP_CHECK(hipGetLastError());
+  LGNN_CALL(batch_epilogue(h, idx, M, s));
+  return 0;
+}
+
+int sage_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0, const float* gamma_A1, float a_scale,
+                        float* grad_P, float* grad_adj, const int32_t* cand_a, const int32_t* cand_b, int64_t K,
+                        float* grad_cand, float* grad_cand_adj, hipStream_t s) {
+  const int64_t N = h->N, C = h->dims[2], H = h->dims[1], F = h->dims[0];
+  LGNN_CALL(forward_ensure_aux(h, s));
+  const float* cat0 = h->fc.lin_in_p[0];  // [N, 2F]: X | P X
+  const float* cat1 = h->fc.lin_in_p[1];  // [N, 2H]: H1 | P H1
+  LGNN_REQUIRE(h->fc.lin_in_ld[0] == 2 * F && h->fc.lin_in_ld[1] == 2 * H, "internal: unexpected cat row stride");
+  LGNN_CALL(h->ws.planes_a.reserve(size_t(N) * (2 * H + H + F) * 4));
+  h->ws.planes_a_zero_ptr = nullptr;
+  float* T1 = h->ws.planes_a.as<float>();  // [N, 2H]
+  float* Z0b = T1 + N * 2 * H;              // [N, H]
+  float* XNb = Z0b + N * H;                 // [N, F]
+  // T1 = outbar W1 + 2 a cat1 Gamma_A1: the self half feeds H1bar directly, the neighbour half is HNbar
+  LGNN_CALL(sgemm_rm(s, N, 2 * H, C, 1.f, out_bar, C, h->W[1], 2 * H, 0.f, T1, 2 * H));
+  LGNN_CALL(sgemm_rm(s, N, 2 * H, 2 * H, 2.f * a_scale, cat1, 2 * H, gamma_A1, 2 * H, 1.f, T1, 2 * H));
+  LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, T1 + H, 2 * H, 0, cat1, 2 * H, 0, H, 1, grad_P, s));
+  LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, T1 + H, 2 * H, 0, cat1, 2 * H, 0, H, 1, nullptr, grad_cand, s));
+  // Z0bar = mask * (T1_self + P^T T1_neigh)
+  SpmmArgs sa{};
+  sa.rowptr = h->PT.rowptr; sa.col = h->PT.col; sa.val = h->PT.val; sa.nrows = N;
+  sa.in = T1 + H; sa.in_ld = 2 * H; sa.in_plane_stride = 0;
+  sa.self = T1; sa.self_ld = 2 * H; sa.self_plane_stride = 0;
+  sa.out = Z0b; sa.out_ld = H; sa.out_plane_stride = 0; sa.width = H; sa.out_act = -1;
+  LGNN_CALL(launch_spmm_ex(sa, 1, s));
+  hipLaunchKernelGGL(relu_mask_ld_kernel, dim3(unsigned(std::min<int64_t>(cdiv(N * H, 256), 4096))), dim3(256), 0, s, Z0b,
+                     h->fc.dact0.as<float>(), N * H);
+  LGNN_HIP_CHECK(hipGetLastError());
+  // XNbar = Z0bar W0[:, F:] + 2 a (cat0 Gamma_A0)[:, F:]
+  LGNN_CALL(sgemm_rm(s, N, F, H, 1.f, Z0b, H, h->W[0] + F, 2 * F, 0.f, XNb, F));
+  LGNN_CALL(sgemm_rm(s, N, F, 2 * F, 2.f * a_scale, cat0, 2 * F, gamma_A0 + F, 2 * F, 1.f, XNb, F));
+  LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, XNb, F, 0, cat0, 2 * F, 0, F, 1, grad_P, s));
+  LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, XNb, F, 0, cat0, 2 * F, 0, F, 1, nullptr, grad_cand, s));
+  // mean_agg backward + the straight-through binarisation (P has the pattern and the row order of A)
+  LGNN_CALL(h->ws.misc.reserve(size_t(N) * 4 + size_t(std::max<int64_t>(h->nnz, 1)) * 4));
+  float* rowdot = h->ws.misc.as<float>();
+  float* tmp = rowdot + N;
+  float* first = h->sym ? tmp : grad_adj;
+  hipLaunchKernelGGL(sage_adj_grad_kernel, dim3(unsigned(cdiv(N, 256))), dim3(256), 0, s, h->P.rowptr, h->P.val, grad_P, N,
+                     rowdot, first);
+  if (h->sym)
+    hipLaunchKernelGGL(adj_grad_symmetrize_kernel, dim3(unsigned(cdiv(N, 256))), dim3(256), 0, s, h->P.rowptr, h->P.col, tmp, N,
+                       grad_adj);
+  if (K > 0)
+    hipLaunchKernelGGL(sage_cand_adj_grad_kernel, dim3(unsigned(cdiv(K, 256))), dim3(256), 0, s, cand_a, K, h->P.rowptr, grad_cand,
+                       rowdot, grad_cand_adj);
+  LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
@@ -483,6 +828,9 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   LGNN_CALL(forward_ensure_aux(h, s));  // act'(h_1) is part of the auxiliary forward products
   const int64_t N = h->N, C = h->dims[2], H = h->dims[1], CC = C * C;
   const bool fork_exact = (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0;
+  if (h->kind == LGNN_KIND_SAGE)
+    return sage_adjgrad_batch(h, idx, y, M, fork_exact, gamma_B0, gamma_B1, loss_scale, grad_P, out_bar, cand_a, cand_b, K,
+                              grad_cand, s);
   LGNN_CALL(batch_prologue(h, idx, y, M, true, fork_exact, nullptr, s));
 
   // top layer: g1 planes [C][N][C] over all rows + flags of the rows that are not identically zero
@@ -573,12 +921,17 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   return 0;
 }
 
-int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A1, float a1_scale, float* grad_P, float* grad_adj,
-                   const int32_t* cand_a, const int32_t* cand_b, int64_t K, float* grad_cand, float* grad_cand_adj,
-                   hipStream_t s) {
+int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0, const float* gamma_A1, float a1_scale,
+                   float* grad_P, float* grad_adj, const int32_t* cand_a, const int32_t* cand_b, int64_t K, float* grad_cand,
+                   float* grad_cand_adj, hipStream_t s) {
   LGNN_REQUIRE(K == 0 || (cand_a && cand_b && grad_cand && grad_cand_adj), "candidate pairs without their buffers");
   LGNN_CALL(check_model(h));
   LGNN_REQUIRE(out_bar && gamma_A1 && grad_P && grad_adj, "null pointers");
+  if (h->kind == LGNN_KIND_SAGE) {
+    LGNN_REQUIRE(gamma_A0 != nullptr, "GraphSAGE: the first layer's input covariance depends on the adjacency (gamma_A[0])");
+    return sage_adjgrad_finish(h, out_bar, gamma_A0, gamma_A1, a1_scale, grad_P, grad_adj, cand_a, cand_b, K, grad_cand,
+                               grad_cand_adj, s);
+  }
   LGNN_CALL(forward_ensure(h, s));
   const int64_t N = h->N, C = h->dims[2], H = h->dims[1], F = h->dims[0];
   // Z1 = H1 W1^T + b1 and Z0 = X W0^T + b0 (the forward keeps neither: one scratch serves both)
@@ -641,6 +994,6 @@ extern "C" int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const floa
                                    float* grad_P, float* grad_adj, const int32_t* cand_a, const int32_t* cand_b,
                                    int64_t num_cand, float* grad_cand, float* grad_cand_adj, void* stream) {
   if (!h || !gamma_A) { lgnn::set_error("null argument"); return 2; }
-  return lgnn::adjgrad_finish(h, out_bar, gamma_A[1], a_scale, grad_P, grad_adj, cand_a, cand_b, num_cand, grad_cand,
+  return lgnn::adjgrad_finish(h, out_bar, gamma_A[0], gamma_A[1], a_scale, grad_P, grad_adj, cand_a, cand_b, num_cand, grad_cand,
                               grad_cand_adj, static_cast<hipStream_t>(stream));
 }

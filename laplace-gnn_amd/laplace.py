@@ -583,8 +583,8 @@ class KronLaplace(ParametricLaplace):
         """``-log_marginal_likelihood()`` of this fit and its gradient w.r.t. the adjacency the model propagates with --
         what ``neg_marglik.backward()`` leaves in ``model.adj.grad`` in the reference's structure-learning loop
         (gnn/marglik_training.py:197-216), here on the stored sparsity pattern: returns ``(neg_marglik, edge_index [2, nnz],
-        grad [nnz])`` over the stored entries of the 0/1 adjacency (``model.engine.export_adj()`` order; self loops
-        carry gradient 0 like the reference's overwritten diagonal).  ``train_loader`` must be the loader of the fit
+        grad [nnz])`` over the stored entries of the 0/1 adjacency (``model.engine.export_adj()`` order; a GCN's self loops
+        carry gradient 0 like the reference's overwritten diagonal).  2-layer GCN (STEGCN) and GraphSAGE (STEGraphSAGE).  ``train_loader`` must be the loader of the fit
         (same batch boundaries: the B factors depend on them).  Inside a ``torch.distributed`` job whole batches are
         dealt round-robin and the accumulators are all-reduced once.
 
@@ -610,8 +610,10 @@ class KronLaplace(ParametricLaplace):
             ci, cj = candidates[0].to(eng.device), candidates[1].to(eng.device)
             if sym:  # (adj + adj^T) / 2 feeds the model: both orientations are needed
                 ci, cj = torch.cat([ci, cj]), torch.cat([cj, ci])
-            # entry (i, j) of the adjacency is entry (a = j, b = i) of the propagation matrix D A^T D
-            cand = (cj.to(torch.int32).contiguous(), ci.to(torch.int32).contiguous(),
+            # entry (i, j) of the adjacency is entry (a = j, b = i) of the GCN propagation matrix D A^T D and entry
+            # (a = i, b = j) of GraphSAGE's A / rowsum
+            ca, cb = (cj, ci) if eng.kind == "gcn" else (ci, cj)
+            cand = (ca.to(torch.int32).contiguous(), cb.to(torch.int32).contiguous(),
                     torch.zeros(ci.shape[0], dtype=torch.float32, device=eng.device))
         for t, (X, y) in enumerate(train_loader):
             if t % world != rank:

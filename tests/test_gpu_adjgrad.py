@@ -1,5 +1,5 @@
 """SURVEY.md 8(f)-4 on the GPU: ``KronLaplace.neg_marglik_adj_grad`` (csrc/adjgrad.hip through the C ABI) against
-(a) the reference's ``model.adj.grad`` after ``(-log_marginal_likelihood()).backward()`` on its STEGCN (goldens generated
+(a) the reference's ``model.adj.grad`` after ``(-log_marginal_likelihood()).backward()`` on its STEGCN / STEGraphSAGE (goldens generated
 by oracle/make_golden.py from the reference's own autograd) and (b) the CPU oracle's hand-written reverse chain on
 seeded mid-size inputs (class chunks under a small workspace cap, repeated node ids, upstream vs fork-exact seeds).
 fp32 end to end (eigendecomposition, three chained sparse products per class plane): tolerance 1e-3 relative."""
@@ -16,7 +16,7 @@ from gpu_utils import oracle_from_arrays, rel
 from test_gpu_frontend import model_from_golden
 
 pytestmark = pytest.mark.gpu
-CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "gcn_*.npz")) if "adjgrad_vals" in np.load(p))
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "adjgrad_vals" in np.load(p))
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
@@ -34,7 +34,10 @@ def test_adjacency_gradient_matches_reference_autograd(path):
     assert abs(float(val) - float(g["adjgrad_neg_marglik"])) <= 2e-4 * abs(float(g["adjgrad_neg_marglik"]))
     assert rel(grad.cpu().numpy(), g["adjgrad_vals"]) < 1e-3
     diag = g["adj_nz_row"] == g["adj_nz_col"]
-    assert float(grad.cpu().numpy()[diag].__abs__().max()) == 0.0  # overwritten by fill_diagonal_(1) in the reference
+    if str(g["kind"]) == "gcn":
+        assert float(grad.cpu().numpy()[diag].__abs__().max()) == 0.0  # overwritten by fill_diagonal_(1) in the reference
+    else:
+        assert not diag.any()  # GraphSAGE stores no self loops (fill_diagonal_(0))
     # a second call gives the same result (accumulators are the caller's, nothing is left in the context); this one also
     # asks for candidate pairs that are NOT edges: the reference's dense adj.grad has them (that is how its structure
     # learning proposes new edges), 200 of them are in the fixture
@@ -45,8 +48,9 @@ def test_adjacency_gradient_matches_reference_autograd(path):
     model.engine.check_async_errors()
 
 
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
 @pytest.mark.parametrize("fork_exact,sym,H,C", [(True, True, 64, 10), (False, False, 32, 7), (True, False, 256, 12)])
-def test_adjacency_gradient_midsize_vs_oracle(fork_exact, sym, H, C):
+def test_adjacency_gradient_midsize_vs_oracle(fork_exact, sym, H, C, kind):
     import laplace_gnn_amd as lg
 
     N, F, E, M = 2500, 24, 9000, 500
@@ -54,7 +58,7 @@ def test_adjacency_gradient_midsize_vs_oracle(fork_exact, sym, H, C):
     ei = torch.randint(0, N, (2, E), generator=gen)
     X = torch.randn(N, F, generator=gen)
     torch.manual_seed(1)
-    model = lg.GCN(F, H, C, 2, X, ei, symmetric=sym).to("cuda").eval()
+    model = (lg.GCN if kind == "gcn" else lg.GraphSAGE)(F, H, C, 2, X, ei, symmetric=sym).to("cuda").eval()
     idx = torch.randperm(N, generator=gen)[:M]
     idx[M // 2:M // 2 + 20] = idx[:20]  # repeated node ids inside and across batches
     y = torch.randint(0, C, (M,), generator=gen)
@@ -62,26 +66,34 @@ def test_adjacency_gradient_midsize_vs_oracle(fork_exact, sym, H, C):
     model.engine.set_workspace_limit(16 << 20)  # several class chunks
     la = lg.KronLaplace(model, "classification", prior_precision=0.5, backend_kwargs=dict(fork_exact_seed=fork_exact))
     la.fit(loader)
-    val, e2, grad = la.neg_marglik_adj_grad(loader)
+    cand = torch.randint(0, N, (2, 300), generator=torch.Generator().manual_seed(5))
+    cand = cand[:, cand[0] != cand[1]]
+    val, e2, grad, gc = la.neg_marglik_adj_grad(loader, candidates=cand.cuda())
     Ws = [c.lin.weight.detach().cpu().numpy() for c in model.convs]
     bs = [c.lin.bias.detach().cpu().numpy() for c in model.convs]
-    om = oracle_from_arrays("gcn", N, ei.numpy(), X.numpy(), Ws, bs, sym)
+    om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), Ws, bs, sym)
     oval, rows, cols, og = O.kron_marglik_adj_grad(om, idx.numpy(), y.numpy(), 200, 0.5, fork_exact, sym)
     assert np.array_equal(e2[0].cpu().numpy(), rows) and np.array_equal(e2[1].cpu().numpy(), cols)
     assert abs(float(val) - oval) <= 2e-4 * abs(oval)
     assert rel(grad.cpu().numpy(), og) < 1e-3
+    # candidate pairs against the oracle's dense N x N gradient; pairs that are stored edges are not candidates
+    _, gd = O.kron_marglik_adj_grad(om, idx.numpy(), y.numpy(), 200, 0.5, fork_exact, sym, dense=True)
+    stored = set(zip(rows.tolist(), cols.tolist()))
+    keep = np.array([(int(i), int(j)) not in stored for i, j in cand.t().tolist()])
+    assert keep.sum() > 250
+    assert rel(gc.cpu().numpy()[keep], gd[cand[0].numpy()[keep], cand[1].numpy()[keep]]) < 1e-3
     model.engine.check_async_errors()
 
 
 def test_adjacency_gradient_is_refused_outside_the_first_slice():
     import laplace_gnn_amd as lg
 
-    g = np.load(os.path.join(GOLDEN, "sage_small_1batch_s0.npz"))
+    g = np.load(os.path.join(GOLDEN, "sage3_small_1batch_s0.npz"))
     model = model_from_golden(g)
     loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(), 10000)
     la = lg.KronLaplace(model, "classification")
     with pytest.raises(AttributeError):
         la.neg_marglik_adj_grad(loader)
     la.fit(loader)
-    with pytest.raises(lg._lib.HipLibraryError, match="2-layer GCN"):
+    with pytest.raises(lg._lib.HipLibraryError, match="2-layer models"):
         la.neg_marglik_adj_grad(loader)

@@ -7,7 +7,8 @@ import laplace_gnn_amd as lg
 
 w, ei, X, tri, try_ = bench.make_workload("arxiv", "cuda")
 torch.manual_seed(0)
-model = lg.GCN(w["F"], w["H"], w["C"], 2, X, ei, symmetric=True).to("cuda")
+kind = sys.argv[1] if len(sys.argv) > 1 else "gcn"
+model = (lg.GCN if kind == "gcn" else lg.GraphSAGE)(w["F"], w["H"], w["C"], 2, X, ei, symmetric=True).to("cuda")
 loader = lg.TensorBatchLoader(tri.cuda(), try_.cuda(), batch_size=w["batch"])
 la = lg.KronLaplace(model, "classification")
 la.fit(loader)
@@ -16,4 +17,4 @@ for cand in (None, torch.randint(0, w["N"], (2, 100_000), generator=torch.Genera
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = la.neg_marglik_adj_grad(loader, candidates=cand)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("candidates" if cand is not None else "stored only", f"{dt * 1e3:.1f} ms", float(out[0]), float(out[2].abs().sum()))
+    print(kind, "candidates" if cand is not None else "stored only", f"{dt * 1e3:.1f} ms", float(out[0]), float(out[2].abs().sum()))
