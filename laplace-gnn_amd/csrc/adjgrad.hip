@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void sddmm_spmm_kernel(const int32_t* __restri
   const int lane = threadIdx.x & 63;
   const int c0 = lane * 4;
   const bool col_ok = c0 < width;  // width % 4 == 0, <= 256 (launcher)
+  const bool odd = (lane & 1) != 0;
   const int64_t total = rows ? int64_t(*nrows_dev) : N;
   const int64_t plane = N * width;
   for (int64_t w = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); w < total; w += int64_t(gridDim.x) * 4) {
@@ -121,25 +122,37 @@ __global__ __launch_bounds__(256) void sddmm_spmm_kernel(const int32_t* __restri
         u[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (col_ok && pc0 + c < nplanes) u[c] = *reinterpret_cast<const float4*>(U + (pc0 + c) * plane + a * width + c0);
       }
-      for (int32_t p = s; p < e; ++p) {
-        const int64_t b = col[p];
-        const float v = val[p];
-        float4 x[PC];
+      // two entries per step: 2 * PC row slices in flight per wave, and ONE shuffle tree for both dot products (after the
+      // first exchange even lanes carry entry p, odd lanes entry p + 1)
+      for (int32_t p = s; p < e; p += 2) {
+        const bool two = p + 1 < e;
+        const int64_t b0 = col[p], b1 = two ? col[p + 1] : b0;
+        const float v0 = val[p], v1 = two ? val[p + 1] : 0.f;
+        float4 x0[PC], x1[PC];
 #pragma unroll
         for (int c = 0; c < PC; ++c) {
-          x[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (col_ok && pc0 + c < nplanes) x[c] = *reinterpret_cast<const float4*>(R + (pc0 + c) * plane + b * width + c0);
+          x0[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+          x1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (col_ok && pc0 + c < nplanes) {
+            x0[c] = *reinterpret_cast<const float4*>(R + (pc0 + c) * plane + b0 * width + c0);
+            x1[c] = *reinterpret_cast<const float4*>(R + (pc0 + c) * plane + b1 * width + c0);
+          }
         }
-        float d = 0.f;
+        float d0 = 0.f, d1 = 0.f;
 #pragma unroll
         for (int c = 0; c < PC; ++c) {
-          acc[c].x = fmaf(v, x[c].x, acc[c].x); acc[c].y = fmaf(v, x[c].y, acc[c].y);
-          acc[c].z = fmaf(v, x[c].z, acc[c].z); acc[c].w = fmaf(v, x[c].w, acc[c].w);
-          d += u[c].x * x[c].x + u[c].y * x[c].y + u[c].z * x[c].z + u[c].w * x[c].w;
+          acc[c].x = fmaf(v0, x0[c].x, acc[c].x); acc[c].y = fmaf(v0, x0[c].y, acc[c].y);
+          acc[c].z = fmaf(v0, x0[c].z, acc[c].z); acc[c].w = fmaf(v0, x0[c].w, acc[c].w);
+          acc[c].x = fmaf(v1, x1[c].x, acc[c].x); acc[c].y = fmaf(v1, x1[c].y, acc[c].y);
+          acc[c].z = fmaf(v1, x1[c].z, acc[c].z); acc[c].w = fmaf(v1, x1[c].w, acc[c].w);
+          d0 += u[c].x * x0[c].x + u[c].y * x0[c].y + u[c].z * x0[c].z + u[c].w * x0[c].w;
+          d1 += u[c].x * x1[c].x + u[c].y * x1[c].y + u[c].z * x1[c].z + u[c].w * x1[c].w;
         }
+        float d = (odd ? d1 : d0) + __shfl_xor(odd ? d0 : d1, 1);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        for (int o = 2; o < 64; o <<= 1) d += __shfl_xor(d, o);
         if (lane == 0) out[p] += d;
+        if (lane == 1 && two) out[p + 1] += d;
       }
 #pragma unroll
       for (int c = 0; c < PC; ++c)
@@ -149,6 +162,122 @@ __global__ __launch_bounds__(256) void sddmm_spmm_kernel(const int32_t* __restri
     }
   }
 }
+
+// Plane-major form of the kernel above: grid (row groups, planes), one wave per (row, plane).  The kernel above gathers
+// PC planes at once -- a working set of PC * 173 MB at the arxiv shape, far beyond the 256 MiB Infinity Cache, so its
+// gathers go to HBM (3.3 TB/s measured); here all CUs work on ONE plane at a time (blocks are dispatched x first), which
+// stays cache resident while its rows are gathered ~15 times each.  Eight entries per step; their eight dot products
+// go through one shuffle tree (three halving exchanges leave lane l with entry l % 8, three more finish it); the
+// planes' contributions to out[p] meet through float atomics.
+__global__ __launch_bounds__(256) void sddmm_spmm_pm_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                            const float* __restrict__ val, const int32_t* __restrict__ rows,
+                                                            const int32_t* __restrict__ nrows_dev, float* __restrict__ U,
+                                                            const float* __restrict__ R, int64_t N, int64_t width,
+                                                            const float* __restrict__ dact, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int c0 = lane * 4;
+  const bool col_ok = c0 < width;
+  const int64_t total = rows ? int64_t(*nrows_dev) : N;
+  const int64_t w = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (w >= total) return;
+  const int64_t a = rows ? int64_t(rows[w]) : w;
+  const int64_t plane = blockIdx.y;
+  float* __restrict__ Up = U + plane * N * width;
+  const float* __restrict__ Rp = R + plane * N * width;
+  const int32_t s = rowptr[a], e = rowptr[a + 1];
+  float4 u = make_float4(0.f, 0.f, 0.f, 0.f), dm = u, acc = u;
+  if (col_ok) {
+    u = *reinterpret_cast<const float4*>(Up + a * width + c0);
+    dm = *reinterpret_cast<const float4*>(dact + a * width + c0);
+  }
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+  for (int32_t base = s; base < e; base += 64) {
+    const int32_t p = base + lane;
+    const int32_t cj = p < e ? col[p] : int32_t(a);  // padding entries re-read the row's own slice (cached), weight 0
+    const float cv = p < e ? val[p] : 0.f;
+    const int n = min(64, int(e - base));
+    for (int u0 = 0; u0 < n; u0 += 8) {
+      float4 x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t b = __builtin_amdgcn_readlane(cj, min(u0 + k, 63));
+        x[k] = col_ok ? *reinterpret_cast<const float4*>(Rp + b * width + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float d[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), min(u0 + k, 63)));
+        acc.x = fmaf(v, x[k].x, acc.x); acc.y = fmaf(v, x[k].y, acc.y);
+        acc.z = fmaf(v, x[k].z, acc.z); acc.w = fmaf(v, x[k].w, acc.w);
+        d[k] = u.x * x[k].x + u.y * x[k].y + u.z * x[k].z + u.w * x[k].w;
+      }
+      float e4[4], f2[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e4[i] = (b0 ? d[2 * i + 1] : d[2 * i]) + __shfl_xor(b0 ? d[2 * i] : d[2 * i + 1], 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) f2[i] = (b1 ? e4[2 * i + 1] : e4[2 * i]) + __shfl_xor(b1 ? e4[2 * i] : e4[2 * i + 1], 2);
+      float g = (b2 ? f2[1] : f2[0]) + __shfl_xor(b2 ? f2[0] : f2[1], 4);
+      g += __shfl_xor(g, 8);
+      g += __shfl_xor(g, 16);
+      g += __shfl_xor(g, 32);
+      // lane l < 8 holds the dot product of entry u0 + (l & 7) = u0 + 4 b2 + 2 b1 + b0
+      if (lane < 8 && u0 + lane < n) atomicAdd(&out[base + u0 + lane], g);
+    }
+  }
+  if (col_ok)
+    *reinterpret_cast<float4*>(Up + a * width + c0) = make_float4(dm.x * acc.x, dm.y * acc.y, dm.z * acc.z, dm.w * acc.w);
+}
+
+// y[plane][r] = sum_p val[p] in[plane][col[p]] for rows of up to 256 columns, one wave per row, ENTRIES WITH A ZERO VALUE
+// ARE NOT GATHERED (the per-batch copy of P^T's values has zeros at the columns of all-zero source rows: 42 % of the entries
+// at the arxiv shape).  The plane is a buffer resource and the row a part of the vector offset: a dead slot's offset is out
+// of range, the load returns zeros without touching memory, so the loop has no branch; 8 rows in flight per wave.
+using srd_t = __amdgpu_buffer_rsrc_t;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+__global__ __launch_bounds__(256) void spmm256_skip_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                           const float* __restrict__ val, int64_t N, const float* __restrict__ in,
+                                                           int64_t width, float* __restrict__ out) {
+  constexpr int UNR = 8;
+  constexpr uint32_t kDead = 0xfffff000u;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int64_t plane = blockIdx.y;
+  const uint32_t plane_bytes = uint32_t(N * width * 4);
+  const srd_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + plane * N * width), 0, plane_bytes, 0x00020000);
+  const uint32_t lane_off = lane * 4 < width ? uint32_t(lane) * 16u : kDead;
+  const uint32_t row_bytes = uint32_t(width) * 4u;
+  const int32_t s = rowptr[row], e = rowptr[row + 1];
+  float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int32_t base = s; base < e; base += 64) {
+    const int32_t p = base + lane;
+    float cv = 0.f;
+    uint32_t cj = kDead;
+    if (p < e) {
+      cv = val[p];
+      if (cv != 0.f) cj = uint32_t(col[p]) * row_bytes;
+    }
+    const int n = min(64, int(e - base));
+    for (int u0 = 0; u0 < n; u0 += UNR) {
+      float4 x[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t so = uint32_t(__builtin_amdgcn_readlane(int(cj), min(u0 + u, 63)));
+        // (a dead slot or a dead lane: kDead + anything below 4 KiB stays out of range of a < 4 GiB - 8 KiB plane)
+        const uint32_t voff = so == kDead || lane_off == kDead ? kDead : so + lane_off;
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(srd, int(voff), 0, 0);
+        x[u] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), min(u0 + u, 63)));
+        y.x = fmaf(v, x[u].x, y.x); y.y = fmaf(v, x[u].y, y.y); y.z = fmaf(v, x[u].z, y.z); y.w = fmaf(v, x[u].w, y.w);
+      }
+    }
+  }
+  if (lane * 4 < width) *reinterpret_cast<float4*>(out + (plane * N + row) * width + lane * 4) = y;
+}
+
 // rows that are not active: ubar = 0 there (u was zero and stays zero: nothing to do; the planes were written in full by
 // the GEMM, whose inactive rows are zeros already)
 
@@ -875,7 +1004,13 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
     sa.rowptr = h->PT.rowptr; sa.col = h->PT.col; sa.val = val_act; sa.nrows = N;
     sa.in = U; sa.in_ld = H; sa.in_plane_stride = N * H; sa.out = G0; sa.out_ld = H; sa.out_plane_stride = N * H;
     sa.width = H; sa.out_act = -1;
-    LGNN_CALL(launch_spmm_ex(sa, cc, s));
+    if (H % 4 == 0 && H <= 256 && N * H * 4 < (int64_t(1) << 32) - (int64_t(1) << 14) && cc < 65536) {
+      hipLaunchKernelGGL(spmm256_skip_kernel, dim3(unsigned(cdiv(N, 4)), unsigned(cc)), dim3(256), 0, s, h->PT.rowptr, h->PT.col,
+                         val_act, N, U, H, G0);
+      LGNN_HIP_CHECK(hipGetLastError());
+    } else {
+      LGNN_CALL(launch_spmm_ex(sa, cc, s));
+    }
     // g0bar = 2 g0 Gamma_B0
     LGNN_CALL(sgemm_rm(s, cc * N, H, H, 2.f, G0, H, gamma_B0, H, 0.f, G0B, H));
     // gradP[(a,b)] += sum_c <u_c[a], g0bar_c[b]> and ubar = mask * (P g0bar) (overwrites u), both over the active rows only
@@ -884,9 +1019,14 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
     if (H % 4 == 0 && H <= 256) {
       // (candidate pairs reach g1bar at arbitrary rows, so ubar is then needed everywhere, not on the active rows only)
       const int32_t* rows = K > 0 ? nullptr : h->ws.act_list.as<int32_t>();
-      hipLaunchKernelGGL(sddmm_spmm_kernel<8>, dim3(unsigned(std::min<int64_t>(cdiv(N, 4), 8192))), dim3(256), 0, s, h->P.rowptr,
-                         h->P.col, h->P.val, rows, h->ws.act_count.as<int32_t>(), U, G0B, N, H, cc, h->fc.dact0.as<float>(),
-                         grad_P);
+      static const bool chunked = getenv("LGNN_ADJ_CHUNKED") != nullptr;  // dev: the 8-planes-per-wave kernel
+      if (!chunked && cc < 65536)
+        hipLaunchKernelGGL(sddmm_spmm_pm_kernel, dim3(unsigned(cdiv(N, 4)), unsigned(cc)), dim3(256), 0, s, h->P.rowptr, h->P.col,
+                           h->P.val, rows, h->ws.act_count.as<int32_t>(), U, G0B, N, H, h->fc.dact0.as<float>(), grad_P);
+      else
+        hipLaunchKernelGGL(sddmm_spmm_kernel<8>, dim3(unsigned(std::min<int64_t>(cdiv(N, 4), 8192))), dim3(256), 0, s,
+                           h->P.rowptr, h->P.col, h->P.val, rows, h->ws.act_count.as<int32_t>(), U, G0B, N, H, cc,
+                           h->fc.dact0.as<float>(), grad_P);
       LGNN_HIP_CHECK(hipGetLastError());
     } else {
       LGNN_CALL(launch_sddmm(h->P, N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(), U, H, N * H, G0B, H, N * H,
