@@ -121,7 +121,8 @@ class HipCurvatureInterface:
         for A, B in views:
             kfacs.append([B * f2 if self.factor != 1.0 else B.clone(), A * f2 if self.factor != 1.0 else A.clone()])
             kfacs.append([B * self.factor if self.factor != 1.0 else B.clone()])
-        return _kron_class()(kfacs)
+        # factor == 1: a bias block's B is its weight block's B (clones of the same view)
+        return _kron_class()(kfacs, tied=range(1, len(kfacs), 2) if self.factor == 1.0 else None)
 
     # Fisher type of the KFAC factors: "type2" (GGN), "mc" (stochastic=True), "empirical" (HipEF)
     @property

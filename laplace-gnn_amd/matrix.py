@@ -70,33 +70,44 @@ def symeig(M: torch.Tensor):
 
 
 class Kron:
-    def __init__(self, kfacs: list):
+    def __init__(self, kfacs: list, tied=None):
         self.kfacs = kfacs
+        # blocks i whose first factor is KNOWN to equal block i-1's (a bias block repeats the B factor of its weight block,
+        # curvlinops.py:64-66): ``decompose`` then skips comparing the tensors, which would synchronise the stream while
+        # the accumulation is still queued.  A hint only: blocks not listed are compared.
+        self._tied = frozenset(tied or ())
 
     @classmethod
     def init_from_model(cls, model: nn.Module | Iterable[nn.Parameter], device) -> "Kron":
         params = model.parameters() if isinstance(model, nn.Module) else model
-        kfacs = []
+        kfacs, tied, prev_out = [], [], None
         for p in params:
             if p.ndim == 1:
+                if prev_out == p.size(0):
+                    tied.append(len(kfacs))  # zeros equal zeros
                 kfacs.append([torch.zeros(p.size(0), p.size(0), device=device)])
+                prev_out = None
             elif p.ndim == 2:
                 o, i = p.size()
                 kfacs.append([torch.zeros(o, o, device=device), torch.zeros(i, i, device=device)])
+                prev_out = o
             else:
                 raise ValueError("Invalid parameter shape in network.")
-        return cls(kfacs)
+        return cls(kfacs, tied=tied)
 
     def __add__(self, other: "Kron") -> "Kron":
         if not isinstance(other, Kron):
             raise ValueError("Can only add Kron to Kron.")
-        return Kron([[Hi.add(Hj) for Hi, Hj in zip(Fi, Fj)] for Fi, Fj in zip(self.kfacs, other.kfacs)])
+        return Kron([[Hi.add(Hj) for Hi, Hj in zip(Fi, Fj)] for Fi, Fj in zip(self.kfacs, other.kfacs)],
+                    tied=getattr(self, "_tied", frozenset()) & getattr(other, "_tied", frozenset()))
 
     def __mul__(self, scalar) -> "Kron":
         if not isinstance(scalar, (int, float)) and not (torch.is_tensor(scalar) and scalar.numel() == 1):
             raise ValueError("Input not valid python or torch scalar.")
         scalar = float(scalar)
-        return Kron([[pow(scalar, 1 / len(F)) * Hi for Hi in F] for F in self.kfacs])
+        # (a weight block's B takes sqrt(scalar), its bias block's B takes scalar: equal only for scalar == 1)
+        return Kron([[pow(scalar, 1 / len(F)) * Hi for Hi in F] for F in self.kfacs],
+                    tied=getattr(self, "_tied", frozenset()) if scalar == 1.0 else None)
 
     __radd__ = __add__
     __rmul__ = __mul__
@@ -130,10 +141,11 @@ class Kron:
     def _distinct_factors(self):
         distinct, where = [], []  # where[i][k] = index into `distinct`
         prev = None
-        for F in self.kfacs:
+        tied = getattr(self, "_tied", frozenset())
+        for i, F in enumerate(self.kfacs):
             idxs = []
             for k, Hi in enumerate(F):
-                if k == 0 and prev is not None and prev[0].shape == Hi.shape and torch.equal(prev[0], Hi):
+                if k == 0 and prev is not None and prev[0].shape == Hi.shape and (i in tied or torch.equal(prev[0], Hi)):
                     idxs.append(prev[1])
                 else:
                     distinct.append(Hi)
