@@ -68,6 +68,31 @@ __global__ void q_kernel(const float* __restrict__ probs, int64_t M, int64_t C, 
   }
 }
 
+// Empirical Fisher: the per-sample gradient of the first layer is diag(rho_n) T_n (+ diag(rho_s) S_n), rho[j] = sum_k r_k w_kj,
+// so its square has the GGN kernel's form with q(neigh,neigh) = scale rho_n^2, q(self,neigh) = scale rho_s rho_n,
+// q(self,self) = scale rho_s^2; the last layer's weights are scale r_k^2.
+__global__ void q_ef_kernel(const float* __restrict__ r, int64_t M, int64_t C, const float* __restrict__ W1, int64_t ldw,
+                            int64_t d, int64_t off_self, int64_t off_neigh, int has_self, float scale, float* __restrict__ q) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= M * d) return;
+  const int64_t m = t / d, j = t - m * d;
+  float rn = 0.f, rs = 0.f;
+  for (int64_t k = 0; k < C; ++k) {
+    const float rk = r[m * C + k];
+    rn += rk * W1[k * ldw + off_neigh + j];
+    if (has_self) rs += rk * W1[k * ldw + off_self + j];
+  }
+  q[t] = scale * rn * rn;
+  if (has_self) {
+    q[M * d + t] = scale * rs * rn;
+    q[2 * M * d + t] = scale * rs * rs;
+  }
+}
+__global__ void ef_last_weights_kernel(const float* __restrict__ r, int64_t n, float scale, float* __restrict__ w) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t < n) w[t] = scale * r[t] * r[t];
+}
+
 constexpr int JPT = 16;  // hidden units per thread
 constexpr int DCH = 32;  // (sample, neighbour) entries staged per chunk
 
@@ -192,19 +217,21 @@ __global__ __launch_bounds__(256) void diag_first_layer_kernel(
   }
 }
 
-// grid (i-chunks of 256, C, slabs): diag(W)[k,i] += sum_n p_k(1-p_k) phi[n,i]^2 ; bias with s_n
+// grid (i-chunks of 256, C, slabs): diag(W)[k,i] += sum_n wgt[n,k] phi[n,i]^2 ; bias with s_n.
+// wgt = p_k (1 - p_k) from the probabilities (GGN), or the caller's [M, C] array (empirical Fisher: scale * r_k^2)
 __global__ void diag_last_layer_kernel(const float* __restrict__ probs, const int64_t* __restrict__ idx, int64_t M,
                                        int64_t C, int64_t slab, FeatView Phi, float* __restrict__ diag_w,
-                                       float* __restrict__ diag_b) {
+                                       float* __restrict__ diag_b, const float* __restrict__ wgt = nullptr) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t k = blockIdx.y;
   if (i > Phi.width) return;
   const int64_t m_begin = int64_t(blockIdx.z) * slab, m_end = min(M, m_begin + slab);
   float acc = 0.f;
   for (int64_t m = m_begin; m < m_end; ++m) {
-    const float p = probs[m * C + k];
+    const float p = wgt ? 0.f : probs[m * C + k];
+    const float wt = wgt ? wgt[m * C + k] : p * (1.f - p);
     const float ph = feat(Phi, idx[m], i);
-    acc += p * (1.f - p) * ph * ph;
+    acc += wt * ph * ph;
   }
   if (i < Phi.width) atomicAdd(&diag_w[k * Phi.width + i], acc);
   else atomicAdd(&diag_b[k], acc);
@@ -514,6 +541,50 @@ int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const voi
   LGNN_CALL(forward_ensure(h, s));
   const int64_t C = h->dims[h->L], P = h->n_params, N = h->N;
   LGNN_CALL(batch_prologue(h, idx, y_loss ? y_loss : y_seed, M, false, false, y_loss ? loss_out : nullptr, s));
+  if (diag_out && !full_out && !grads_out && h->L <= 2 && getenv("LGNN_JAC_PLANES") == nullptr) {
+    // diagonal only, <= 2 layers: the closed form of the diagonal GGN with other weights -- no Jacobians at all
+    LGNN_CALL(forward_ensure_aux(h, s));
+    const int L = h->L;
+    const int64_t H = L == 2 ? h->dims[1] : 0;
+    LGNN_CALL(h->ws.misc.reserve(size_t(3) * M * std::max<int64_t>(H, 1) * 4 + size_t(2) * M * C * 4));
+    float* q = h->ws.misc.as<float>();
+    float* r = q + 3 * M * std::max<int64_t>(H, 1);
+    float* wl = r + M * C;
+    hipLaunchKernelGGL(ef_resid_kernel, dim3(unsigned(cdiv(M * C, 256))), dim3(256), 0, s, h->ws.probs.as<float>(),
+                       h->fc.out.as<float>(), idx, y_seed, M, C, N, h->lik == LGNN_LIK_REGRESSION ? 1 : 0, resid_scale, r,
+                       h->ws.flags.as<int>());
+    hipLaunchKernelGGL(ef_last_weights_kernel, dim3(unsigned(cdiv(M * C, 256))), dim3(256), 0, s, r, M * C, scale, wl);
+    LGNN_HIP_CHECK(hipGetLastError());
+    int64_t tiles = 1;
+    if (L == 2) tiles = cdiv(h->in_dim[0] + 1, 64) * cdiv(H, 64);
+    const int64_t slab = std::max<int64_t>(8, std::min<int64_t>(64, cdiv(M * tiles, 2048)));
+    const unsigned nslab = unsigned(cdiv(M, slab));
+    int64_t off = 0;
+    if (L == 2) {
+      const int64_t in0 = h->in_dim[0];
+      const int has_self = h->kind == LGNN_KIND_SAGE ? 1 : 0;
+      hipLaunchKernelGGL(q_ef_kernel, dim3(unsigned(cdiv(M * H, 256))), dim3(256), 0, s, r, M, C, h->W[1], h->in_dim[1], H,
+                         int64_t(0), has_self ? H : int64_t(0), has_self, scale, q);
+      FeatView E;
+      feat_views(h, 0, E);
+      const dim3 grid{unsigned(cdiv(E.width + 1, 64)), unsigned(cdiv(H, 64)), nslab};
+      if (has_self)
+        hipLaunchKernelGGL(diag_first_layer_kernel<1>, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab, E,
+                           h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
+      else
+        hipLaunchKernelGGL(diag_first_layer_kernel<0>, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab, E,
+                           h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
+      LGNN_HIP_CHECK(hipGetLastError());
+      off = H * in0 + H;
+    }
+    FeatView Phi;
+    feat_views(h, L - 1, Phi);
+    hipLaunchKernelGGL(diag_last_layer_kernel, dim3(unsigned(cdiv(Phi.width + 1, 256)), unsigned(C), nslab), dim3(256), 0, s,
+                       h->ws.probs.as<float>(), idx, M, C, slab, Phi, diag_out + off, diag_out + off + C * Phi.width, wl);
+    LGNN_HIP_CHECK(hipGetLastError());
+    LGNN_CALL(batch_epilogue(h, idx, M, s));
+    return 0;
+  }
   const int64_t mc_max = std::max<int64_t>(1, std::min<int64_t>(M, (h->ws_limit / 4) / std::max<int64_t>((C + 1) * P * 4, 1)));
   LGNN_CALL(h->ws.jac.reserve(size_t(mc_max) * (C + 1) * P * 4 + size_t(mc_max) * C * 4));
   float* J = h->ws.jac.as<float>();
