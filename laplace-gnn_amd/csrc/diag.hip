@@ -49,6 +49,20 @@ __global__ void q_kernel(const float* __restrict__ probs, int64_t M, int64_t C, 
   if (t >= M * d) return;
   const int64_t m = t / d, j = t - m * d;
   float snn = 0.f, sn = 0.f, sss = 0.f, ss = 0.f, ssn = 0.f;
+  if (!probs) {  // regression: Lambda = I (laplace/curvature/curvature.py:429-430), q = sum_k w_kj u_kj
+    for (int64_t k = 0; k < C; ++k) {
+      const float wn = W1[k * ldw + off_neigh + j];
+      snn += wn * wn;
+      if (has_self) {
+        const float ws = W1[k * ldw + off_self + j];
+        sss += ws * ws;
+        ssn += ws * wn;
+      }
+    }
+    q[t] = snn;
+    if (has_self) { q[M * d + t] = ssn; q[2 * M * d + t] = sss; }
+    return;
+  }
   for (int64_t k = 0; k < C; ++k) {
     const float p = probs[m * C + k];
     const float wn = W1[k * ldw + off_neigh + j];
@@ -430,9 +444,10 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
   LGNN_REQUIRE(h->L >= 1, "no model bound");
   const int L = h->L;
   const int64_t C = h->dims[L];
-  if (L > 2 || h->lik == LGNN_LIK_REGRESSION) {
-    // deeper models (the reference builds them once the breakpoint at gnn/models/base_gnn.py:109 is removed) and the
-    // regression likelihood: per-sample Jacobians in chunks + the contraction with Lambda; no closed form
+  const bool regression = h->lik == LGNN_LIK_REGRESSION;
+  if (L > 2 || getenv("LGNN_JAC_PLANES") != nullptr) {
+    // deeper models (the reference builds them once the breakpoint at gnn/models/base_gnn.py:109 is removed): per-sample
+    // Jacobians in chunks + the contraction with Lambda; no closed form
     LGNN_CALL(forward_ensure(h, s));
     LGNN_CALL(batch_prologue(h, idx, y, M, false, false, loss_out, s));
     LGNN_CALL(diag_from_jacobians(h, idx, M, diag_out, s));
@@ -441,7 +456,8 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
   }
   LGNN_CALL(forward_ensure_aux(h, s));
   LGNN_CALL(batch_prologue(h, idx, y, M, false, false, loss_out, s));
-  const float* probs = h->ws.probs.as<float>();
+  // regression: Lambda = I, i.e. q = sum_k w_kj^2 and unit weights in the last layer (the interface's factor is the caller's)
+  const float* probs = regression ? nullptr : h->ws.probs.as<float>();
   // Samples per workgroup slab.  A thread walks its slab's samples and their neighbours one after the other (dependent
   // loads: a latency chain), so small problems want short slabs -- Cora shape: 0.42 -> 0.2 ms with 16 instead of 64 --
   // while every slab costs one atomic per output element: aim for ~2048 workgroups.
@@ -456,7 +472,7 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
   if (L == 2) {
     const int64_t H = h->dims[1], in0 = h->in_dim[0];
     const int has_self = h->kind == LGNN_KIND_SAGE ? 1 : 0;
-    LGNN_CALL(h->ws.misc.reserve(size_t(3) * M * H * 4));
+    LGNN_CALL(h->ws.misc.reserve(size_t(3) * M * H * 4 + size_t(M) * C * 4));
     float* q = h->ws.misc.as<float>();
     hipLaunchKernelGGL(q_kernel, dim3(unsigned(cdiv(M * H, 256))), dim3(256), 0, s, probs, M, C, h->W[1],
                        h->in_dim[1], H, int64_t(0), has_self ? H : int64_t(0), has_self, q);
@@ -478,8 +494,16 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
     FeatView Phi;
     feat_views(h, L - 1, Phi);
     const dim3 grid{unsigned(cdiv(Phi.width + 1, 256)), unsigned(C), nslab};
-    hipLaunchKernelGGL(diag_last_layer_kernel, grid, dim3(256), 0, s, probs, idx, M, C, slab, Phi, diag_out + off,
-                       diag_out + off + C * Phi.width);
+    const float* wgt = nullptr;
+    if (regression) {
+      const int64_t Hq = L == 2 ? h->dims[1] : 0;
+      LGNN_CALL(h->ws.misc.reserve(size_t(3) * M * Hq * 4 + size_t(M) * C * 4));
+      float* ones = h->ws.misc.as<float>() + 3 * M * Hq;
+      LGNN_CALL(launch_fill_i32(reinterpret_cast<int32_t*>(ones), M * C, 0x3f800000, s));  // 1.0f
+      wgt = ones;
+    }
+    hipLaunchKernelGGL(diag_last_layer_kernel, grid, dim3(256), 0, s, h->ws.probs.as<float>(), idx, M, C, slab, Phi,
+                       diag_out + off, diag_out + off + C * Phi.width, wgt);
     LGNN_HIP_CHECK(hipGetLastError());
   }
   LGNN_CALL(batch_epilogue(h, idx, M, s));
