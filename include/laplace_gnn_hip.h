@@ -255,14 +255,16 @@ LGNN_API int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float*
 
 /* ---- matrix-free GLM predictive ("next" row 8(f)-3 at scale) -------------------------------------------------------
  * Replaces the Jacobian route of the default la(x) (laplace/baselaplace.py:1123-1158 + laplace/utils/matrix.py:396-451 resp.
- * baselaplace.py:1901-1903) for 2-layer GCN models: f_mu [M, C] = logits and f_var_diag [M, C] = diag(J P^-1 J^T) per
+ * baselaplace.py:1901-1903) for 2-layer GCN and GraphSAGE models: f_mu [M, C] = logits and f_var_diag [M, C] = diag(J P^-1 J^T) per
  * evaluation node from the closed-form Jacobian, nothing of size M * C * P is formed.  The probit link (the default,
  * baselaplace.py:610-616) needs exactly this diagonal.
  *   Kronecker posterior: QA0 [F, F], QB0 [H, H], QA1 [H, H] = eigenvectors (columns) of A_0, B_0, A_1;
  *     S0 [H, F + 1]: 1 / (f lB0_i lA0_j + delta_W0), column F: 1 / (f lB0_i + delta_b0);  S1 [C, H]: 1 / (f lB1_i lA1_j + delta_W1);
  *     QB1sq [C, C] = Q_B1[c, i]^2;  kappa [C] = sum_i Q_B1[c, i]^2 / (f lB1_i + delta_b1)      (bias blocks share Q_B)
  *   diagonal posterior: QA0 = QB0 = QA1 = QB1sq = NULL; S0 [H, F + 1] = 1 / precision of (W_0 | b_0), S1 [C, H] of W_1,
- *     kappa [C] of b_1.                                                                                         */
+ *     kappa [C] of b_1.
+ *   GraphSAGE: F and the H of QA1 / S1's second dimension read as the widths of what the two Linear layers multiply
+ *     (2 F and 2 H: cat = [h | P h], gnn/models/layers.py:26-29).                                                */
 LGNN_API int lgnn_glm_variance(lgnn_ctx* h, const int64_t* idx, int64_t M, const float* QA0, const float* QB0, const float* S0,
                       const float* QA1, const float* S1, const float* QB1sq, const float* kappa, float* f_mu,
                       float* f_var_diag, void* stream);

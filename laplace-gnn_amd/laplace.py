@@ -274,10 +274,10 @@ class ParametricLaplace(BaseLaplace):
         return None
 
     def _glm_variance_matrix_free(self, x):
-        """(f_mu [M, C], diag f_var [M, C]) without Jacobians (csrc/predictive.hip), or None: 2-layer GCN models with a
-        ReLU, hidden width <= 256, classification, Kronecker or diagonal posterior over all weights."""
+        """(f_mu [M, C], diag f_var [M, C]) without Jacobians (csrc/predictive.hip), or None: 2-layer GCN / GraphSAGE models
+        with a ReLU, hidden width <= 256, classification, Kronecker or diagonal posterior over all weights."""
         eng = getattr(self.backend, "engine", None)
-        if (eng is None or not hasattr(eng, "glm_variance") or getattr(eng, "kind", None) != "gcn" or len(eng.dims) != 3
+        if (eng is None or not hasattr(eng, "glm_variance") or getattr(eng, "kind", None) not in ("gcn", "sage") or len(eng.dims) != 3
                 or eng.dims[1] > 256 or getattr(eng, "_bind_opts", ("relu",))[0] != "relu" or self.likelihood != "classification"):
             return None
         ops = self._matrix_free_operands()
@@ -694,12 +694,12 @@ class DiagLaplace(ParametricLaplace):
         shapes = [tuple(p.shape) for p in self.params]
         if len(shapes) != 4:
             return None
-        (Hd, F), _, (C, _), _ = shapes
+        (Hd, F), _, (C, D1), _ = shapes  # (GraphSAGE: F and D1 are the widths of the concatenations)
         inv = 1.0 / self.posterior_precision
         o = 0
         w0 = inv[o:o + Hd * F].view(Hd, F); o += Hd * F
         b0 = inv[o:o + Hd].view(Hd, 1); o += Hd
-        w1 = inv[o:o + C * Hd].view(C, Hd); o += C * Hd
+        w1 = inv[o:o + C * D1].view(C, D1); o += C * D1
         return dict(S0=torch.cat([w0, b0], dim=1), S1=w1, kappa=inv[o:o + C])
 
     def _scale_samples(self, eps):  # laplace/baselaplace.py:1912-1919: samples * posterior_scale

@@ -412,7 +412,8 @@ def test_invalid_labels_and_indices_are_reported_at_the_end_of_fit():
 
 
 @pytest.mark.parametrize("name", ["gcn_small_1batch_s0", "gcn_small_3batch_s1", "gcn_mid_1batch_s0", "gcn_mid_3batch_sym_s1",
-                                  "gcn_small_isolated_s0"])
+                                  "gcn_small_isolated_s0", "sage_small_1batch_s0", "sage_small_3batch_s1", "sage_mid_2batch_s2",
+                                  "sage_small_3batch_sym_s3"])
 def test_matrix_free_glm_variance_matches_the_jacobian_route_and_the_reference(name):
     """csrc/predictive.hip: diag(J P^-1 J^T) per node without Jacobians, Kronecker (scalar and per-block prior) and diagonal
     posterior, against (a) this package's Jacobian route (KronDecomposed.inv_square_form / the diagonal einsum) and (b) the
