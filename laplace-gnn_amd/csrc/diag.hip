@@ -511,6 +511,7 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
 }
 
 int gram_rows_sgemm(const float* G, int64_t rows, int64_t P, float scale, float* out, hipStream_t s);  // jacobian.hip
+int ef_grads_closed_form(lgnn_ctx* h, const int64_t* idx, int64_t M, const float* r, float* G, hipStream_t s);  // jacobian.hip
 
 // Full GGN over all weights (GGNInterface.full, laplace/curvature/curvature.py:374-410; the reference's default backend
 // applies a matrix-free GGN to the P columns of the identity, curvlinops/ggn.py:44-75 via laplace/curvature/
@@ -609,20 +610,24 @@ int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const voi
     LGNN_CALL(batch_epilogue(h, idx, M, s));
     return 0;
   }
-  const int64_t mc_max = std::max<int64_t>(1, std::min<int64_t>(M, (h->ws_limit / 4) / std::max<int64_t>((C + 1) * P * 4, 1)));
-  LGNN_CALL(h->ws.jac.reserve(size_t(mc_max) * (C + 1) * P * 4 + size_t(mc_max) * C * 4));
+  // <= 2 layers: the gradients come straight from the closed form (M * P floats); deeper models contract Jacobians
+  const bool closed = h->L <= 2 && getenv("LGNN_JAC_PLANES") == nullptr;
+  const int64_t jrows = closed ? 0 : C;
+  const int64_t mc_max = std::max<int64_t>(1, std::min<int64_t>(M, (h->ws_limit / 4) / std::max<int64_t>((jrows + 1) * P * 4, 1)));
+  LGNN_CALL(h->ws.jac.reserve(size_t(mc_max) * (jrows + 1) * P * 4 + size_t(mc_max) * C * 4));
   float* J = h->ws.jac.as<float>();
-  float* G = J + mc_max * C * P;
+  float* G = J + mc_max * jrows * P;
   float* r = G + mc_max * P;
   for (int64_t m0 = 0; m0 < M; m0 += mc_max) {
     const int64_t mc = std::min(mc_max, M - m0);
-    LGNN_CALL(jacobians(h, idx + m0, mc, J, nullptr, s));
+    if (!closed) LGNN_CALL(jacobians(h, idx + m0, mc, J, nullptr, s));
     const void* ys = h->lik == LGNN_LIK_REGRESSION ? static_cast<const void*>(static_cast<const float*>(y_seed) + m0 * C)
                                                    : static_cast<const void*>(static_cast<const int64_t*>(y_seed) + m0);
     hipLaunchKernelGGL(ef_resid_kernel, dim3(unsigned(cdiv(mc * C, 256))), dim3(256), 0, s, h->ws.probs.as<float>() + m0 * C,
                        h->fc.out.as<float>(), idx + m0, ys, mc, C, N, h->lik == LGNN_LIK_REGRESSION ? 1 : 0, resid_scale, r,
                        h->ws.flags.as<int>());
-    hipLaunchKernelGGL(grads_from_jac_kernel, dim3(unsigned(cdiv(P, 256)), unsigned(mc)), dim3(256), 0, s, J, r, mc, C, P, G);
+    if (closed) LGNN_CALL(ef_grads_closed_form(h, idx + m0, mc, r, G, s));
+    else hipLaunchKernelGGL(grads_from_jac_kernel, dim3(unsigned(cdiv(P, 256)), unsigned(mc)), dim3(256), 0, s, J, r, mc, C, P, G);
     LGNN_HIP_CHECK(hipGetLastError());
     if (grads_out) LGNN_HIP_CHECK(hipMemcpyAsync(grads_out + m0 * P, G, size_t(mc) * P * 4, hipMemcpyDeviceToDevice, s));
     if (diag_out)

@@ -170,6 +170,77 @@ static int jacobians_closed_form(lgnn_ctx* h, const int64_t* idx, int64_t M, flo
   return 0;
 }
 
+// Per-sample loss gradients G[m, :] = sum_c r[m, c] J[m, c, :] of 1- and 2-layer models straight from the closed form (the
+// empirical / MC Fisher's rows, laplace/curvature/curvature.py:169-210): with rho_s[h] = sum_c r_c ws_c[h], rho_n[h] =
+// sum_c r_c wn_c[h] the first layer's gradient is rho_s[h] T_self[h, :] + rho_n[h] T_neigh[h, :], the last layer's is
+// r (x) phi_a -- M * P floats instead of the M * C * P of the Jacobians.
+__global__ __launch_bounds__(256) void ef_grads_closed_form_kernel(
+    const int64_t* __restrict__ idx, int64_t M, int64_t N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ val, int L, int sage, int64_t in0, int64_t H, int64_t C,
+    const float* __restrict__ E0, int64_t e0_ld, const float* __restrict__ e0_bias /* null: 1 */,
+    const float* __restrict__ dact, const float* __restrict__ W1, int64_t w1_ld,
+    const float* __restrict__ PhiL, int64_t phil_ld, int64_t phil_w, const float* __restrict__ phil_bias /* null: 1 */,
+    const float* __restrict__ r, int64_t P, float* __restrict__ G) {
+  const int64_t m = blockIdx.x;
+  const int64_t a = idx[m];
+  float* __restrict__ Gm = G + m * P;
+  const float* __restrict__ rm = r + m * C;
+  const int64_t t0 = int64_t(blockIdx.y) * blockDim.x + threadIdx.x, tstep = int64_t(gridDim.y) * blockDim.x;
+  if (a < 0 || a >= N) {  // flagged by the batch prologue
+    for (int64_t t = t0; t < P; t += tstep) Gm[t] = 0.f;
+    return;
+  }
+  const int64_t in_last = phil_w;
+  const int64_t off_last = L == 2 ? H * in0 + H : 0;
+  for (int64_t t = t0; t < C * in_last + C; t += tstep) {
+    float v;
+    if (t < C * in_last) { const int64_t k = t / in_last; v = rm[k] * PhiL[a * phil_ld + (t - k * in_last)]; }
+    else v = rm[t - C * in_last] * (phil_bias ? phil_bias[a] : 1.f);
+    Gm[off_last + t] = v;
+  }
+  if (L == 1) return;
+  const int32_t ps = rowptr[a], pe = rowptr[a + 1];
+  const int64_t in1 = in0 + 1;
+  for (int64_t t = t0; t < H * in1; t += tstep) {
+    const int64_t hh = t / in1, i = t - hh * in1;
+    float rs = 0.f, rn = 0.f;
+    for (int64_t c = 0; c < C; ++c) {
+      const float rc = rm[c];
+      if (sage) { rs = fmaf(rc, W1[c * w1_ld + hh], rs); rn = fmaf(rc, W1[c * w1_ld + H + hh], rn); }
+      else rn = fmaf(rc, W1[c * w1_ld + hh], rn);
+    }
+    float tn = 0.f;
+    for (int32_t p = ps; p < pe; ++p) {
+      const int64_t u = col[p];
+      const float e = i < in0 ? E0[u * e0_ld + i] : (e0_bias ? e0_bias[u] : 1.f);
+      tn = fmaf(val[p] * dact[u * H + hh], e, tn);
+    }
+    float v = rn * tn;
+    if (sage) v = fmaf(rs, dact[a * H + hh] * (i < in0 ? E0[a * e0_ld + i] : 1.f), v);
+    Gm[i < in0 ? hh * in0 + i : H * in0 + hh] = v;
+  }
+}
+
+int ef_grads_closed_form(lgnn_ctx* h, const int64_t* idx, int64_t M, const float* r, float* G, hipStream_t s) {
+  LGNN_REQUIRE(h->L >= 1 && h->L <= 2, "closed-form gradients: 1- and 2-layer models");
+  LGNN_CALL(forward_ensure_aux(h, s));
+  const int L = h->L;
+  const int64_t N = h->N, C = h->dims[L], H = L == 2 ? h->dims[1] : 0, in0 = h->in_dim[0], P = h->n_params;
+  const bool sage = h->kind == LGNN_KIND_SAGE;
+  const float* E0 = sage ? h->fc.lin_in_p[0] : h->fc.prop_in[0].as<float>();
+  const int64_t e0_ld = sage ? h->fc.lin_in_ld[0] : h->fc.prop_ld[0];
+  const float* bias_col = sage ? nullptr : h->fc.rowsum.as<float>();
+  const float* PhiL = sage ? h->fc.lin_in_p[L - 1] : h->fc.prop_in[L - 1].as<float>();
+  const int64_t phil_ld = sage ? h->fc.lin_in_ld[L - 1] : h->fc.prop_ld[L - 1];
+  LGNN_REQUIRE(M < (int64_t(1) << 31), "too many samples");
+  const unsigned per = unsigned(std::max<int64_t>(1, std::min<int64_t>(cdiv(std::max<int64_t>(H * (in0 + 1), C * h->in_dim[L - 1] + C), 256), cdiv(4096, M))));
+  hipLaunchKernelGGL(ef_grads_closed_form_kernel, dim3(unsigned(M), per), dim3(256), 0, s, idx, M, N, h->P.rowptr, h->P.col,
+                     h->P.val, L, sage ? 1 : 0, in0, H, C, E0, e0_ld, bias_col, L == 2 ? h->fc.dact0.as<float>() : nullptr,
+                     L == 2 ? h->W[1] : nullptr, L == 2 ? h->in_dim[1] : 0, PhiL, phil_ld, h->in_dim[L - 1], bias_col, r, P, G);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out, hipStream_t s) {
   LGNN_REQUIRE(h->L > 0, "no model bound");
   // 1- and 2-layer models: closed form (LGNN_JAC_PLANES=1 forces the generic plane route, which deeper models use)

@@ -144,6 +144,29 @@ def test_kron_init_from_model_layout():
     assert [tuple(h.shape) for F in k.kfacs for h in F] == [(3, 3), (5, 5), (3, 3)]
 
 
+def test_kron_tied_hint_follows_the_arithmetic(monkeypatch):
+    """A bias block repeats its weight block's B factor; ``decompose`` may skip comparing the tensors (a device sync on the
+    GPU) only where the container KNOWS they are equal: zero init, sums of hinted containers, scaling by exactly 1."""
+    l0, l1 = torch.nn.Linear(5, 3), torch.nn.Linear(3, 2)
+    params = [l0.weight, l0.bias, l1.weight, l1.bias]
+    z = lg.Kron.init_from_model(params, "cpu")
+    assert z._tied == {1, 3}
+    B0, B1 = torch.eye(3) * 2, torch.eye(2) * 3
+    hinted = lg.Kron([[B0.clone(), torch.eye(5)], [B0.clone()], [B1.clone(), torch.eye(3)], [B1.clone()]], tied=[1, 3])
+    plain = lg.Kron([[B0.clone(), torch.eye(5)], [B0.clone()], [B1.clone(), torch.eye(3)], [B1.clone()]])
+    assert (z + hinted)._tied == {1, 3} and (z + plain)._tied == frozenset() and (hinted + plain)._tied == frozenset()
+    assert (hinted * 1.0)._tied == {1, 3} and (hinted * 0.5)._tied == frozenset()  # sqrt(0.5) B vs 0.5 B
+    calls = []
+    real_equal = torch.equal
+    monkeypatch.setattr(torch, "equal", lambda a, b: calls.append(1) or real_equal(a, b))
+    d_h, w_h = (z + hinted)._distinct_factors()
+    assert not calls and len(d_h) == 4 and w_h == [[0, 1], [0], [2, 3], [2]]
+    d_p, w_p = plain._distinct_factors()
+    assert len(calls) == 2 and len(d_p) == 4 and w_p == w_h  # equal contents are still found, by comparison
+    kd = (z + hinted).decompose()
+    assert torch.allclose(kd.to_matrix(), plain.to_matrix(), atol=1e-5)
+
+
 # ---- loaders ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,bs", [(33, 12), (10, 10), (7, 100), (25, 1)])
 def test_tensor_batch_loader_has_dataloader_boundaries(n, bs):
