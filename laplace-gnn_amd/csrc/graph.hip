@@ -153,6 +153,8 @@ int sort_keys(uint64_t* in, uint64_t* out, int64_t n, int end_bit, DevBuf& tmp, 
   return 0;
 }
 
+}  // namespace
+
 int exclusive_scan_i32(int32_t* in, int32_t* out, int64_t n, DevBuf& tmp, hipStream_t s) {
   size_t bytes = 0;
   LGNN_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, int32_t(0), size_t(n), rocprim::plus<int32_t>(), s));
@@ -160,6 +162,8 @@ int exclusive_scan_i32(int32_t* in, int32_t* out, int64_t n, DevBuf& tmp, hipStr
   LGNN_HIP_CHECK(rocprim::exclusive_scan(tmp.p, bytes, in, out, int32_t(0), size_t(n), rocprim::plus<int32_t>(), s));
   return 0;
 }
+
+namespace {
 
 // keys (sorted, unique, no sentinel) -> CSR arrays
 int keys_to_csr(const uint64_t* keys, int64_t nnz, int64_t N, DevBuf& rowptr, DevBuf& col, DevBuf& tmp, DevBuf& cnt,

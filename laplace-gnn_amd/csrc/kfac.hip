@@ -249,7 +249,12 @@ __global__ __launch_bounds__(1024) void seed_spmm_gram_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val, int64_t N, int C,
     const int32_t* __restrict__ pos, const float* __restrict__ probs, const float* __restrict__ logits,
     const int32_t* __restrict__ mult, int fork_exact, float* __restrict__ g, const int32_t* __restrict__ act_list,
-    const int32_t* __restrict__ act_count, int cb, int ce, float* __restrict__ scratch, int ldb, int debug_arg) {
+    const int32_t* __restrict__ act_count, int cb, int ce, float* __restrict__ scratch, int ldb, int debug_arg,
+    // hub rows cut into slices (see top_tasks_* below).  mode 0: act_list holds node ids, a node's task is its whole row;
+    // mode 1: act_list holds (node or -1 - node, begin, end) triples -- a negative node marks a SLICE of a hub row, whose
+    // partial tile is added to hub_tiles[long_slot[node]] instead of being finished here; mode 2: act_list holds the ids of
+    // the sliced hubs, their summed tiles are read back from hub_tiles and finished (planes + Gram)
+    int mode, const int32_t* __restrict__ long_slot, float* __restrict__ hub_tiles, const uint8_t* __restrict__ active) {
 #ifdef LGNN_DEV  // ablation switches exist in `make DEV=1` builds only
   const int debug = debug_arg;
 #else
@@ -292,9 +297,15 @@ __global__ __launch_bounds__(1024) void seed_spmm_gram_kernel(
     const int cn = min(64, cnt - c0);
     int32_t n_l = 0, s_l = 0, e_l = 0;
     if (lane < cn) {
-      n_l = act_list[gw + int64_t(c0 + lane) * S];
-      s_l = rowptr[n_l];
-      e_l = rowptr[n_l + 1];
+      const int64_t t = gw + int64_t(c0 + lane) * S;
+      if (mode == 1) {
+        n_l = act_list[3 * t];
+        s_l = act_list[3 * t + 1];
+        e_l = act_list[3 * t + 2];
+      } else {
+        n_l = act_list[t];
+        if (mode == 0) { s_l = rowptr[n_l]; e_l = rowptr[n_l + 1]; }  // mode 2: no entries, the tile comes from hub_tiles
+      }
     }
     auto load_entries = [&](int j, int32_t& cj, float& vj) {
       const int jj = min(j, 63);
@@ -310,9 +321,18 @@ __global__ __launch_bounds__(1024) void seed_spmm_gram_kernel(
     for (int j = 0; j < cn; ++j) {
       mpB = cB >= 0 ? pos[cB] : INT32_MAX;  // node j + 1
       load_entries(j + 2, cC, vC);           // node j + 2
-      const int64_t n = __builtin_amdgcn_readlane(n_l, j);
+      const int32_t n_enc = __builtin_amdgcn_readlane(n_l, j);
+      const bool slice = n_enc < 0;  // a slice of a hub row: its partial tile goes to hub_tiles
+      const int64_t n = slice ? -1 - int64_t(n_enc) : int64_t(n_enc);
       const int32_t s = __builtin_amdgcn_readlane(s_l, j), e = __builtin_amdgcn_readlane(e_l, j);
       bool any = false;
+      if (mode == 2) {  // the summed tile of a sliced hub
+        any = active[n] != 0;
+        if (any) {
+          const float* __restrict__ src = hub_tiles + int64_t(long_slot[n]) * nrows * C;
+          for (int q = lane; q < nrows * C; q += 64) buf[(q / C) * ldb + (q % C)] = src[q];
+        }
+      }
       for (int32_t base = s; base < e; base += 64) {
         int32_t mp = mpA, cu = cA;
         float v = vA;
@@ -379,11 +399,18 @@ __global__ __launch_bounds__(1024) void seed_spmm_gram_kernel(
         }
       }
       mpA = mpB; cA = cB; vA = vB; cB = cC; vB = vC;
-      if (!any) continue;  // cannot happen for a listed node; keeps the tile well defined regardless
+      if (!any) continue;  // a slice without batch neighbours, an inactive hub; cannot happen for a listed whole node
       // the other lanes' LDS writes are read below: same wave, LDS executes a wave's operations in order
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (slice) {
+        float* __restrict__ dst = hub_tiles + int64_t(long_slot[n]) * nrows * C;
+        for (int q = lane; q < nrows * C; q += 64) atomicAdd(&dst[q], buf[(q / C) * ldb + (q % C)]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the next task overwrites the tile
+        continue;
+      }
       if (g && debug != 1) {
         int r = r0, k = k0;
         float* __restrict__ gn = g + (int64_t(cb) * N + n) * C;
@@ -455,6 +482,45 @@ __global__ __launch_bounds__(1024) void seed_spmm_gram_kernel(
   }
 }
 
+// Hub rows of the top layer.  A node's cost in seed_spmm_gram_kernel is its number of batch neighbours, walked by ONE wave
+// (~2 us of issue-bound SIMD time per pair): on a power-law graph the largest hub (arxiv_powerlaw: 5 474 entries, ~330 in a
+// batch) finishes alone long after the other waves (0.70 ms per batch against 0.29 ms on the uniform graph).  Rows with
+// more than kTopSlice entries are therefore cut into slices that different waves take; a slice adds its partial tile to the
+// hub's tile in global memory (float atomics) and a second, small launch finishes the summed tiles (planes + Gram).
+// Per batch: one count / scan / fill pass over the active list builds the task triples.
+__global__ void top_tasks_count_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ count,
+                                       const int32_t* __restrict__ rowptr, int64_t N, int32_t* __restrict__ cnt) {
+  const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  int32_t c = 0;
+  if (k < *count) {
+    const int32_t n = list[k];
+    const int32_t deg = rowptr[n + 1] - rowptr[n];
+    c = deg > kTopSlice ? (deg + kTopSlice - 1) / kTopSlice : 1;
+  }
+  cnt[k] = c;
+}
+__global__ void top_tasks_fill_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ count,
+                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cnt,
+                                      const int32_t* __restrict__ offs, int32_t* __restrict__ tasks,
+                                      int32_t* __restrict__ task_count) {
+  const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int32_t total = *count;
+  if (k >= total) return;
+  const int32_t n = list[k], c = cnt[k], o = offs[k];
+  const int32_t rs = rowptr[n], re = rowptr[n + 1];
+  if (c == 1) {
+    tasks[3 * o] = n; tasks[3 * o + 1] = rs; tasks[3 * o + 2] = re;
+  } else {
+    for (int32_t i = 0; i < c; ++i) {
+      tasks[3 * (o + i)] = -1 - n;
+      tasks[3 * (o + i) + 1] = rs + i * kTopSlice;
+      tasks[3 * (o + i) + 2] = min(rs + (i + 1) * kTopSlice, re);
+    }
+  }
+  if (k == total - 1) *task_count = o + c;
+}
+
 template <int NBLK>
 int seed_spmm_gram_launch(lgnn_ctx* h, bool fork_exact, float* g, int64_t cb, int64_t ce, float* scratch,
                           hipStream_t s) {
@@ -478,11 +544,46 @@ int seed_spmm_gram_launch(lgnn_ctx* h, bool fork_exact, float* g, int64_t cb, in
 #ifdef LGNN_DEV  // make DEV=1: ablation switches (1 no plane stores, 2 no MFMA, 3 no global atomics)
   if (const char* dbg = getenv("LGNN_SEED_DEBUG")) debug = atoi(dbg);
 #endif
+  const int fe = h->lik == LGNN_LIK_REGRESSION ? 2 : (fork_exact ? 1 : 0);
+  LGNN_CALL(long_rows_ensure(h, s));
+  static const bool no_slices = getenv("LGNN_TOP_NO_SLICES") != nullptr;  // dev: A/B of the sliced hubs
+  if (h->n_top_multi <= 0 || no_slices) {
+    hipLaunchKernelGGL(seed_spmm_gram_kernel<NBLK>, dim3(unsigned(256 * per_cu)), dim3(64 * waves), smem, s, h->PT.rowptr,
+                       h->PT.col, h->PT.val, h->N, C, h->ws.pos.as<int32_t>(), h->ws.probs.as<float>(),
+                       h->fc.out.as<float>(), h->ws.mult.as<int32_t>(), fe, g, h->ws.act_list.as<int32_t>(),
+                       h->ws.act_count.as<int32_t>(), int(cb), int(ce), scratch, ldb, debug, 0,
+                       static_cast<const int32_t*>(nullptr), static_cast<float*>(nullptr), static_cast<const uint8_t*>(nullptr));
+    LGNN_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
+  // sliced hubs: task triples of this batch's active nodes, partial tiles, then the finishing launch over the sliced hubs
+  const int64_t N = h->N, nrows = ce - cb;
+  const int64_t cap = N + h->n_top_slices;
+  LGNN_CALL(h->top_cnt.reserve(size_t(N) * 4));
+  LGNN_CALL(h->top_offs.reserve(size_t(N) * 4));
+  LGNN_CALL(h->top_tasks.reserve(size_t(cap) * 12));
+  LGNN_CALL(h->top_task_count.reserve(64));
+  LGNN_CALL(h->top_hub_tiles.reserve(size_t(h->n_long) * nrows * C * 4));
+  LGNN_HIP_CHECK(hipMemsetAsync(h->top_task_count.p, 0, 4, s));
+  LGNN_HIP_CHECK(hipMemsetAsync(h->top_hub_tiles.p, 0, size_t(h->n_long) * nrows * C * 4, s));
+  hipLaunchKernelGGL(top_tasks_count_kernel, dim3(unsigned(cdiv(N, 256))), dim3(256), 0, s, h->ws.act_list.as<int32_t>(),
+                     h->ws.act_count.as<int32_t>(), h->PT.rowptr, N, h->top_cnt.as<int32_t>());
+  LGNN_CALL(exclusive_scan_i32(h->top_cnt.as<int32_t>(), h->top_offs.as<int32_t>(), N, h->ws.select_tmp, s));
+  hipLaunchKernelGGL(top_tasks_fill_kernel, dim3(unsigned(cdiv(N, 256))), dim3(256), 0, s, h->ws.act_list.as<int32_t>(),
+                     h->ws.act_count.as<int32_t>(), h->PT.rowptr, h->top_cnt.as<int32_t>(), h->top_offs.as<int32_t>(),
+                     h->top_tasks.as<int32_t>(), h->top_task_count.as<int32_t>());
   hipLaunchKernelGGL(seed_spmm_gram_kernel<NBLK>, dim3(unsigned(256 * per_cu)), dim3(64 * waves), smem, s, h->PT.rowptr,
                      h->PT.col, h->PT.val, h->N, C, h->ws.pos.as<int32_t>(), h->ws.probs.as<float>(),
-                     h->fc.out.as<float>(), h->ws.mult.as<int32_t>(),
-                     h->lik == LGNN_LIK_REGRESSION ? 2 : (fork_exact ? 1 : 0), g,
-                     h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(), int(cb), int(ce), scratch, ldb, debug);
+                     h->fc.out.as<float>(), h->ws.mult.as<int32_t>(), fe, g, h->top_tasks.as<int32_t>(),
+                     h->top_task_count.as<int32_t>(), int(cb), int(ce), scratch, ldb, debug, 1, h->long_slot.as<int32_t>(),
+                     h->top_hub_tiles.as<float>(), h->ws.active.as<uint8_t>());
+  // finishing launch: one wave per sliced hub (its count is a property of the graph: a constant in device memory)
+  const unsigned fin_blocks = unsigned(std::min<int64_t>(cdiv(h->n_top_multi, waves), 256 * per_cu));
+  hipLaunchKernelGGL(seed_spmm_gram_kernel<NBLK>, dim3(fin_blocks), dim3(64 * waves), smem, s, h->PT.rowptr, h->PT.col,
+                     h->PT.val, h->N, C, h->ws.pos.as<int32_t>(), h->ws.probs.as<float>(), h->fc.out.as<float>(),
+                     h->ws.mult.as<int32_t>(), fe, g, h->top_multi.as<int32_t>(), h->top_multi.as<int32_t>() + h->n_top_multi, int(cb), int(ce),
+                     scratch, ldb, debug, 2, h->long_slot.as<int32_t>(), h->top_hub_tiles.as<float>(),
+                     h->ws.active.as<uint8_t>());
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -133,6 +133,10 @@ struct lgnn_ctx {
   int64_t n_long = -1;             // -1: not looked at yet
   int64_t n_long_tasks = 0;
   lgnn::DevBuf long_rows, long_slot, long_tasks, hub;
+  // top-layer kernel (kfac.hip): hubs with more than kTopSlice entries are cut into slices; their node ids, count, and the
+  // number of slices over all of them (host copies); per-batch task list and partial tiles
+  lgnn::DevBuf top_multi, top_tasks, top_task_count, top_cnt, top_offs, top_hub_tiles;
+  int64_t n_top_multi = 0, n_top_slices = 0;
   // the same list for the forward matrix P (the forward SpMMs)
   int64_t n_long_fwd = -1;
   lgnn::DevBuf long_rows_fwd;
@@ -206,6 +210,7 @@ int launch_backgemm(const BackGemmArgs& g, hipStream_t s);
 int launch_relu_mask_bits(const float* h, int64_t ld, int64_t N, int64_t H, uint32_t* bits, hipStream_t s);
 // out[0:count) = sorted indices i with flags[i] != 0; *count_dev = count   (graph.hip, rocPRIM select)
 int compact_flags(const uint8_t* flags, int64_t n, int32_t* out, int32_t* count_dev, DevBuf& tmp, hipStream_t s);
+int exclusive_scan_i32(int32_t* in, int32_t* out, int64_t n, DevBuf& tmp, hipStream_t s);  // graph.hip, rocPRIM
 
 // ---- graph.hip -----------------------------------------------------------------------
 int graph_build(lgnn_ctx* h, const int64_t* edge_index, int64_t E, hipStream_t s);
@@ -262,7 +267,8 @@ int launch_gather_rows(const float* in, int64_t ld, int64_t nrows_in, const int6
                        float* out, int* bad_flag, hipStream_t s);
 
 // ---- longrows.hip -----------------------------------------------------------------------
-constexpr int kLongRow = 64;  // rows of P^T with more stored entries leave the fused kernel's per-wave gather
+constexpr int kLongRow = 64;
+constexpr int kTopSlice = 128;  // stored entries of a hub row per top-layer task  // rows of P^T with more stored entries leave the fused kernel's per-wave gather
 int long_rows_ensure(lgnn_ctx* h, hipStream_t s);  // builds h->long_* once (synchronises the stream that one time)
 int long_rows_fwd_ensure(lgnn_ctx* h, hipStream_t s);  // the list of long rows of P (forward SpMMs)
 // hub[plane][slot][0:width) = sum_j val[j] * in[plane][col[j]][0:width) for the long rows of P^T

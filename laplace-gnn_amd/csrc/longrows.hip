@@ -115,6 +115,30 @@ int long_rows_ensure(lgnn_ctx* h, hipStream_t s) {
     set_error("long rows: task upload failed");
     return done(1);
   }
+  // hubs the top-layer kernel cuts into slices of kTopSlice entries (kfac.hip)
+  std::vector<int32_t> ids(static_cast<size_t>(n)), multi;
+  if (hipMemcpyAsync(ids.data(), h->long_rows.p, size_t(n) * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) {
+    set_error("long rows: id copy failed");
+    return done(1);
+  }
+  int64_t slices = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const int32_t deg = hb[2 * i + 1] - hb[2 * i];
+    if (deg > kTopSlice) { multi.push_back(ids[i]); slices += (deg + kTopSlice - 1) / kTopSlice; }
+  }
+  const int64_t n_multi = int64_t(multi.size());
+  if (!multi.empty()) {
+    multi.push_back(int32_t(n_multi));  // the list's length behind it: the finishing launch reads its task count there
+    if (h->top_multi.reserve(multi.size() * 4)) return done(1);
+    if (hipMemcpyAsync(h->top_multi.p, multi.data(), multi.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+      set_error("long rows: hub list upload failed");
+      return done(1);
+    }
+  }
+  h->n_top_multi = n_multi;
+  h->n_top_slices = slices;
   h->n_long = n;
   h->n_long_tasks = int64_t(tasks.size() / 3);
   return done(0);

@@ -289,6 +289,17 @@ def test_long_rows_take_the_side_kernel_vs_oracle(kind, H, L):
         assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL, f"B_{l}"
         assert rel(A.cpu().numpy(), oH[2 * l][1]) < RTOL, f"A_{l}"
     assert abs(loss - float(oloss)) < RTOL * abs(float(oloss))
+    # a class range of one batch with repeated node ids (a data-parallel rank's share): the top layer's hub slices add their
+    # partial tiles for the range's rows only
+    sub = idx[:250].clone()
+    sub[200:] = sub[:50]
+    _, v2, l2 = eng.new_kfac_buffers()
+    eng.kfac_accumulate(sub.cuda(), y[:250].cuda(), 600, v2, l2, classes=(1, 4))
+    _, ok = O.kfac_batch(om, sub.numpy(), y[:250].numpy(), 600, True, (1, 4))
+    for l, (A, B) in enumerate(v2):
+        if kind == "sage" and l == L - 1:
+            continue  # GraphSAGE: the share with class 0 carries the whole (cheap) top-layer Gram
+        assert rel(B.cpu().numpy(), ok[2 * l][0]) < RTOL, f"class range, B_{l}"
     eng.check_async_errors()
     eng.close()
 
