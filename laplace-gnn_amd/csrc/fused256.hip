@@ -144,7 +144,9 @@ __device__ __forceinline__ void mfma_wave(const FusedArgs& a, const float* __res
 //      would walk thousands of neighbours while its workgroup waits at the barrier -- but arrive finished from
 //      long_rows_spmm (longrows.hip) through a.hub, fetched like MODE 1's self rows: a buffer load whose offset is out of
 //      range (no memory access) for ordinary rows, issued one row ahead of its use.
-template <int MODE, bool HUB>
+// LIST (MODE 1 only): a block is 32 rows of a.row_list instead of 32 consecutive rows; rows that are not listed have an
+//      all-zero result and are never visited (their share of the MFMA work disappears with them).
+template <int MODE, bool HUB, bool LIST = false>
 __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
   __shared__ float tile[2][KT256][256];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -154,7 +156,8 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
   // not: 4.43 -> 3.90 ms per 20-plane launch.  `wave` = role index (0-3 gather, 4-7 MFMA).
   const int hwave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = ((hwave & 2) ? 4 : 0) + (hwave & 1) + ((hwave >> 2) << 1);
-  const int64_t blocks_per_plane = (a.nrows + KT256 - 1) / KT256;
+  const int64_t nrows_eff = LIST ? int64_t(*a.row_count) : a.nrows;  // rows visited per plane
+  const int64_t blocks_per_plane = (nrows_eff + KT256 - 1) / KT256;
   const int64_t nblocks = blocks_per_plane * a.nplanes;
   const int64_t nb = nblocks > int64_t(blockIdx.x) ? (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
   // (Dealing every XCD a contiguous range of each plane's row blocks instead of this round-robin was measured and
@@ -177,25 +180,42 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
       plane = blk / blocks_per_plane;
       rb = (blk - plane * blocks_per_plane) * KT256;
     };
-    auto load_rp = [&](int64_t i) -> int32_t {
-      int32_t rp = 0;
+    // node of the block's row `lane & 31` (LIST: through the list; -1 past the end)
+    auto node_of = [&](int64_t i) -> int32_t {
+      int32_t nd = -1;
       if (i < nb) {
+        int64_t plane, rb;
+        block_coords(i, plane, rb);
+        const int64_t r = rb + (lane & 31);
+        if (r < nrows_eff) nd = LIST ? a.row_list[r] : int32_t(r);
+      }
+      return nd;
+    };
+    // row pointers of block i: consecutive rows -> one load, lane r holds rowptr[rb + r] (the end of row r is lane r + 1's);
+    // LIST -> lane r holds the begin of its listed row, re (by reference) its end
+    auto load_rp = [&](int64_t i, int32_t& re) -> int32_t {
+      int32_t rp = 0;
+      re = 0;
+      if constexpr (LIST) {
+        const int32_t nd = node_of(i);
+        if (nd >= 0 && lane < KT256) { rp = rowptr[nd]; re = rowptr[nd + 1]; }
+      } else if (i < nb) {
         int64_t plane, rb;
         block_coords(i, plane, rb);
         if (lane <= KT256 && rb + lane <= a.nrows) rp = rowptr[rb + lane];
       }
       return rp;
     };
-    auto load_block_entries = [&](int64_t i, int32_t rp, int32_t sl, RowEntries (&ent)[RPWB]) {
+    auto load_block_entries = [&](int64_t i, int32_t rp, int32_t re, int32_t sl, RowEntries (&ent)[RPWB]) {
       int64_t plane = 0, rb = 0;
       if (i < nb) block_coords(i, plane, rb);
 #pragma unroll
       for (int it = 0; it < RPWB; ++it) {
         const int r = it * 4 + wave;
         int32_t s = 0, e = 0;
-        if (i < nb && rb + r < a.nrows) {
+        if (i < nb && rb + r < nrows_eff) {
           s = __builtin_amdgcn_readlane(rp, r);
-          e = __builtin_amdgcn_readlane(rp, r + 1);
+          e = LIST ? __builtin_amdgcn_readlane(re, r) : __builtin_amdgcn_readlane(rp, r + 1);
           if constexpr (HUB) {
             if (__builtin_amdgcn_readlane(sl, r) >= 0) e = s;  // a long row: nothing to gather, it comes from a.hub
           }
@@ -208,10 +228,8 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
       int32_t sl = -1;
       if constexpr (HUB) {
         if (i < nb) {
-          int64_t plane, rb;
-          block_coords(i, plane, rb);
-          const int64_t r = rb + (lane & 31);
-          if (r < a.nrows) sl = a.long_slot[r];
+          const int32_t nd = node_of(i);
+          if (nd >= 0) sl = a.long_slot[nd];
         }
       }
       return sl;
@@ -219,17 +237,23 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
     // MODE 1: self-row flags of the block's 32 rows, one per lane, fetched with the row pointers
     auto load_fl = [&](int64_t i) -> int32_t {
       if constexpr (MODE != 1) return 0;
+      if constexpr (LIST) {
+        const int32_t nd = node_of(i);
+        return nd >= 0 ? int32_t(a.self_rows[nd]) : 0;
+      }
       int64_t plane = 0, rb = 0;
       block_coords(i < nb ? i : (nb > 0 ? nb - 1 : 0), plane, rb);
       const int64_t r = rb + (lane & 31);
       return a.self_rows[r < a.nrows ? r : a.nrows - 1];
     };
     RowEntries ent[RPWB], ent_next[RPWB];
-    int32_t rp_next = load_rp(0);
+    int32_t re_next = 0;
+    int32_t rp_next = load_rp(0, re_next);
     int32_t fl_cur = load_fl(0), fl_next = 0;
+    int32_t nd_cur = LIST ? node_of(0) : 0, nd_next = 0;  // LIST: the nodes of the block's rows, one per lane
     int32_t sl_cur = load_slot(0), sl_next = load_slot(1);
-    load_block_entries(0, rp_next, sl_cur, ent);
-    rp_next = load_rp(1);
+    load_block_entries(0, rp_next, re_next, sl_cur, ent);
+    rp_next = load_rp(1, re_next);
     for (int64_t i = 0; i <= nb; ++i) {
       if (i < nb && LGNN_DBG(a) != 2 && LGNN_DBG(a) != 4) {
         int64_t plane, rb;
@@ -251,12 +275,13 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
         auto fetch_self_mask = [&](int itn) {
           if constexpr (MODE == 1) {
             const int rn = itn * 4 + wave;
-            const int64_t rown = rb + rn;
-            const bool have = rown < a.nrows && __builtin_amdgcn_readlane(fl_cur, rn) != 0;
+            const bool exists = rb + rn < nrows_eff;
+            const int64_t rown = LIST ? int64_t(__builtin_amdgcn_readlane(nd_cur, rn)) : rb + rn;  // (-1 past the list's end)
+            const bool have = exists && __builtin_amdgcn_readlane(fl_cur, rn) != 0;
             const int32_t soff = have ? int32_t(uint32_t(rown) * uint32_t(a.self_ld * 4)) : int32_t(0xfffffff0u);
             const u32x4 tq = __builtin_amdgcn_raw_buffer_load_b128(srd_self, voff, soff, 0);
             q_nx = make_float4(__uint_as_float(tq.x), __uint_as_float(tq.y), __uint_as_float(tq.z), __uint_as_float(tq.w));
-            const int64_t rc = rown < a.nrows ? rown : a.nrows - 1;
+            const int64_t rc = exists ? rown : (LIST ? 0 : a.nrows - 1);
             mw_nx = a.mask_bits[rc * a.mask_words + (c0 < int(a.width) ? (c0 >> 5) : 0)];
           }
         };
@@ -289,16 +314,18 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
           if (it + DEPTH - 1 < RPWB)
             issue_gathers<true>(ent[it + DEPTH - 1], 0, srd, voff, x[(it + DEPTH - 1) % DEPTH]);
           if (it + DEPTH - 1 == RPWB - 1) {  // all gathers of this block are issued: fetch the next block's rows
-            load_block_entries(i + 1, rp_next, sl_next, ent_next);
-            rp_next = load_rp(i + 2);
+            load_block_entries(i + 1, rp_next, re_next, sl_next, ent_next);
+            rp_next = load_rp(i + 2, re_next);
             fl_next = load_fl(i + 1);
+            if constexpr (LIST) nd_next = node_of(i + 1);
           }
           float4 y = hub_row;  // zeros unless HUB and the row is a long one
           accumulate<true>(y, ent[it], 0, x[it % DEPTH]);
           if (ent[it].nlive > UNR || ent[it].e - ent[it].s > 64)
             gather_rest(y, ent[it], colp, valp, srd, voff, row_bytes, lane);
           const int r = it * 4 + wave;
-          const int64_t row = rb + r;
+          // LIST: `row` is the listed node (where stores go); a row past the list's end is made invalid through a.nrows
+          const int64_t row = LIST ? (rb + r < nrows_eff ? int64_t(__builtin_amdgcn_readlane(nd_cur, r)) : a.nrows) : rb + r;
           if constexpr (MODE == 1) {
             // self row and mask word of THIS row were issued one row ahead (q_nx / mw_nx); issue the next row's now
             const float4 q = q_nx;
@@ -332,6 +359,7 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
 #pragma unroll
         for (int it = 0; it < RPWB; ++it) ent[it] = ent_next[it];
         fl_cur = fl_next;
+        if constexpr (LIST) nd_cur = nd_next;
         if constexpr (HUB) { sl_cur = sl_next; sl_next = load_slot(i + 2); }
       }
       if (LGNN_DBG(a) != 4) __syncthreads();
@@ -363,7 +391,11 @@ int launch_spmm_gram256(const FusedArgs& a_in, hipStream_t s) {
   if (a.self && a.self_rows && a.mask_bits) {
     LGNN_REQUIRE(a.nrows * a.self_ld * 4 < (int64_t(1) << 32) - 4096, "self plane too large for 32-bit buffer offsets");
     LGNN_REQUIRE(a.mask_words * 32 >= a.width, "mask words do not cover the plane width");
-    if (hub) hipLaunchKernelGGL((spmm_gram256_kernel<1, true>), dim3(grid), dim3(512), 0, s, a);
+    if (a.row_list) {  // only the listed rows; their number is on the device: one persistent workgroup per CU
+      LGNN_REQUIRE(a.row_count != nullptr && a.store == nullptr, "row list: needs its count, and no stored planes");
+      if (hub) hipLaunchKernelGGL((spmm_gram256_kernel<1, true, true>), dim3(256), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((spmm_gram256_kernel<1, false, true>), dim3(256), dim3(512), 0, s, a);
+    } else if (hub) hipLaunchKernelGGL((spmm_gram256_kernel<1, true>), dim3(grid), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((spmm_gram256_kernel<1, false>), dim3(grid), dim3(512), 0, s, a);
   } else {
     if (hub) hipLaunchKernelGGL((spmm_gram256_kernel<0, true>), dim3(grid), dim3(512), 0, s, a);

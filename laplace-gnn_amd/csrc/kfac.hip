@@ -951,6 +951,24 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
             a.self_rows = h->ws.active.as<uint8_t>();
             a.mask_bits = h->fc.mask_bits[l - 1].as<uint32_t>();
             a.mask_words = int(cdiv(d, 32));
+            static const bool no_list = getenv("LGNN_SAGE_NO_ROW_LIST") != nullptr;  // dev: A/B of the row list
+            if (!store && plan.fuse[l] && !no_list) {
+              // g_{l-1} = act' * (dcat_self + P^T dcat_neigh) can be non-zero on the batch nodes and their neighbours only
+              // (the columns of the batch nodes' P rows): the fused kernel visits just those rows
+              LGNN_CALL(h->ws.out_flags.reserve(size_t(N)));
+              LGNN_CALL(h->ws.out_list.reserve(size_t(N) * 4));
+              LGNN_CALL(h->ws.out_count.reserve(64));
+              LGNN_HIP_CHECK(hipMemsetAsync(h->ws.out_flags.p, 0, size_t(N), s));
+              hipLaunchKernelGGL(mark_active_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, idx, M, N, h->P.rowptr,
+                                 h->P.col, h->ws.out_flags.as<uint8_t>());
+              hipLaunchKernelGGL(mark_batch_flags_kernel, dim3(unsigned(cdiv(M, 256))), dim3(256), 0, s, idx, M, N,
+                                 h->ws.out_flags.as<uint8_t>());
+              LGNN_HIP_CHECK(hipGetLastError());
+              LGNN_CALL(compact_flags(h->ws.out_flags.as<uint8_t>(), N, h->ws.out_list.as<int32_t>(),
+                                      h->ws.out_count.as<int32_t>(), h->ws.select_tmp, s));
+              a.row_list = h->ws.out_list.as<int32_t>();
+              a.row_count = h->ws.out_count.as<int32_t>();
+            }
           }
           LGNN_REQUIRE(!store || pong != nullptr, "internal: stored planes without a buffer");
           a.store = store ? pong : nullptr; a.store_ld = d; a.store_plane_stride = N * d;

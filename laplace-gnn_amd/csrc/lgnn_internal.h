@@ -102,6 +102,7 @@ struct Workspace {
   DevBuf act_count;
   DevBuf select_tmp;
   DevBuf flags;  // 64 B of asynchronous error flags
+  DevBuf out_flags, out_list, out_count;  // GraphSAGE KFAC: rows of the first backward plane set that can be non-zero
 };
 
 }  // namespace lgnn
@@ -190,6 +191,9 @@ struct FusedArgs {
   // 256-wide kernel: rows with more than 64 stored entries arrive finished from long_rows_spmm (longrows.hip):
   // long_slot[row] = slot in hub (-1: ordinary row), hub [plane][n_long][width]
   const int32_t* long_slot; const float* hub; int64_t hub_plane_stride; int64_t n_long;
+  // 256-wide kernel, GraphSAGE fast path: only the rows listed here can be non-zero (the batch nodes and their neighbours:
+  // 58 % of the rows at the arxiv shape) -- a block is 32 LISTED rows, the others are never visited.  count on the device.
+  const int32_t* row_list; const int32_t* row_count;
 };
 
 struct BackGemmArgs {
