@@ -339,7 +339,10 @@ def main():
                             "algorithmic_GBps": bytes_ / (kern_ms * 1e-3) / 1e9,
                             "executed_frac_of_peak": ach / PEAK_MFMA_F32_TFLOPS * 36.0 / 64.0 if H > 128 else None,
                             "note": "the kernel executes the 36 of 64 symmetric 32x32 sub-tiles of the Gram; 'achieved' "
-                                    "credits the full 2*N*H^2 as SURVEY.md 8(d) prescribes"}
+                                    "credits the full 2*N*H^2 as SURVEY.md 8(d) prescribes"
+                                    + ("; GraphSAGE: it also visits only the rows that can be non-zero (batch nodes and "
+                                       "their neighbours), so frac can exceed 1 and executed_frac_of_peak overstates by the "
+                                       "share of skipped rows" if w.get("kind") == "sage" else "")}
             elif structure == "diag":
                 # dominant kernel: diag_first_layer_kernel, one launch per batch.  ALGORITHMIC bytes per launch
                 # (SURVEY.md 8(d) "Diag (C2)"): N*F*4 + nnz*8 + 2*P*4; flops 2*M*dbar*H*(F+1).  HBM bound by that count
