@@ -166,6 +166,35 @@ def test_arxiv_shape_properties(arxiv):
     assert torch.equal(v_2[0][0], v_u[0][0]) and rel(v_2[0][1].cpu().numpy(), v_u[0][1].cpu().numpy()) > 1e-3
 
 
+def test_arxiv_shape_graphsage_properties():
+    """The same sizes with GraphSAGE (the fused kernel's row-list variant: only the batch nodes and their neighbours are
+    visited): fused and unfused paths agree on every factor, class ranges add up to the batch, factors symmetric PSD."""
+    import bench
+    import laplace_gnn_amd as lg
+
+    w, ei, X, train_idx, train_y = bench.make_workload("arxiv_sage", "cuda")
+    torch.manual_seed(0)
+    model = lg.GraphSAGE(w["F"], w["H"], w["C"], 2, X, ei, symmetric=True).to("cuda").eval()
+    eng = model.engine
+    idx, y = train_idx.cuda()[: w["batch"]], train_y.cuda()[: w["batch"]]
+    idx[-50:] = idx[:50]  # repeated node ids
+    _, v_f, l_f = eng.new_kfac_buffers()
+    eng.kfac_accumulate(idx, y, w["n_train"], v_f, l_f, fuse=True)
+    _, v_u, l_u = eng.new_kfac_buffers()
+    eng.kfac_accumulate(idx, y, w["n_train"], v_u, l_u, fuse=False)
+    _, v_p, l_p = eng.new_kfac_buffers()
+    for r in ((0, 7), (7, 40)):
+        eng.kfac_accumulate(idx, y, w["n_train"], v_p, l_p, classes=r)
+    torch.cuda.synchronize()
+    for (Af, Bf), (Au, Bu), (Ap, Bp) in zip(v_f, v_u, v_p):
+        assert rel(Bf.cpu().numpy(), Bu.cpu().numpy()) < 1e-5 and rel(Bp.cpu().numpy(), Bf.cpu().numpy()) < 1e-5
+        assert torch.equal(Af, Au) and torch.equal(Bf, Bf.T)
+        ev = torch.linalg.eigvalsh(Bf.double())
+        assert float(ev.min()) > -1e-5 * float(ev.max())
+    assert abs(float(l_f) - float(l_u)) < 1e-6 * abs(float(l_u))
+    eng.check_async_errors()
+
+
 def test_arxiv_shape_sampled_oracle_check(arxiv):
     """B_1 (40 x 40) of one full-size batch against the oracle's sparse backward restricted to the top
     layer (cheap on the CPU: no 256-wide planes)."""
