@@ -154,6 +154,9 @@ __global__ __launch_bounds__(512, 2) void spmm_gram256_kernel(FusedArgs a) {
   // {0,1,4,5} (SIMD 0/1) gather and {2,3,6,7} (SIMD 2/3) run the MFMAs.  A gather wave and an fp32-MFMA wave on
   // the SAME SIMD compete for its issue slot (every gather VALU instruction then costs twice); apart they do
   // not: 4.43 -> 3.90 ms per 20-plane launch.  `wave` = role index (0-3 gather, 4-7 MFMA).
+  // (LIST / GraphSAGE, where the gather is light and the kernel MFMA bound: ONE MFMA wave and one gather wave per SIMD was
+  //  measured -- 57.1 -> 69.8 ms per arxiv-shaped fit: a single fp32-MFMA wave does not keep its SIMD's matrix pipe busy,
+  //  two per SIMD do.)
   const int hwave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = ((hwave & 2) ? 4 : 0) + (hwave & 1) + ((hwave >> 2) << 1);
   const int64_t nrows_eff = LIST ? int64_t(*a.row_count) : a.nrows;  // rows visited per plane
