@@ -1,4 +1,5 @@
-// Register-resident 256 x 256 fp32 Gram accumulator shared by 4 waves (one per SIMD).
+// Register-resident 256 x 256 fp32 Gram accumulator shared by the 4 MFMA waves of a workgroup (two on each of two SIMDs:
+// one fp32-MFMA wave alone does not keep a SIMD's matrix pipe busy, see fused256.hip).
 //
 // The 36 upper-triangular 32x32 sub-tiles of the factor are split 9 per wave so that every wave
 // touches at most 6 of the 8 column blocks of a staged row block:
