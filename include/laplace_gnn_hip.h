@@ -271,10 +271,12 @@ LGNN_API int lgnn_glm_variance(lgnn_ctx* h, const int64_t* idx, int64_t M, const
 
 /* ---- decomposition of the fitted factors ("next" row: KronLaplace.fit -> Kron.decompose) ----------
  * Replaces the per-factor torch.linalg.eigh calls of laplace/utils/matrix.py:118-145 (symeig,
- * laplace/utils/utils.py:193-226) by ONE strided-batched rocSOLVER syevd over all factors.
- * A: device fp32 [batch][n][n], symmetric (upper triangle read), overwritten with the eigenvectors: ROW j of
- * matrix b is the unit eigenvector of eigenvalue W[b][j]; W: device fp32 [batch][n], ascending;
- * info: device int32 [batch] (0 = converged).  Asynchronous on `stream`; no graph handle involved.    */
+ * laplace/utils/utils.py:193-226) by one call for all factors: n <= 256 -- a one-workgroup Householder tridiagonalisation
+ * per factor (all factors side by side), rocSOLVER's divide and conquer on the tridiagonal matrices (one chain per factor on
+ * side streams joined back into `stream`), a back-transformation kernel; larger n -- ONE strided-batched rocSOLVER syevd.
+ * A: device fp32 [batch][n][n], symmetric, overwritten with the eigenvectors: ROW j of matrix b is the unit eigenvector of
+ * eigenvalue W[b][j]; W: device fp32 [batch][n], ascending; info: device int32 [batch] (0 = converged).  Asynchronous on
+ * `stream`; no graph handle involved.    */
 LGNN_API int lgnn_symeig_batched(float* A, int64_t n, int64_t batch, float* W, int32_t* info, void* stream);
 
 #ifdef __cplusplus
