@@ -14,15 +14,29 @@ import torch
 from torch import nn
 
 
-def symeig_batched_hip(mats: list) -> list:
-    """Eigendecompose several symmetric PSD factors on the GPU with ONE strided-batched rocSOLVER call
-    (``lgnn_symeig_batched``): per-factor ``torch.linalg.eigh`` is a serial chain of ~100 single-workgroup
-    kernels (3.3 ms per 256 x 256 factor); batched, all factors cost what the largest one costs.
+# Factors larger than the hand-written path's 256 take the library's syevd: 30 ms for the 1 433 x 1 433 input covariance of a
+# Cora-shaped GCN, 100 ms for GraphSAGE's 2 866 x 2 866 -- the whole fit otherwise costs 3 ms.  A GCN's first input covariance is
+# (batches / N_train) X^T X: it depends on neither the weights nor the adjacency, so in the fork's structure-learning loop
+# (gnn/marglik_training.py:197-216: fit, marglik, gradient step on the adjacency, repeat) every fit after the first asks for the
+# decomposition of the same matrix.  The last few large decompositions are kept and reused when the new factor equals the
+# cached one to fp32 rounding (max |dH| <= 1e-6 max |H|: the Gram kernel's atomics reorder sums between engines).
+_LARGE_EIG_CACHE: list = []  # [(H, lam, Q)], most recent last
+_LARGE_EIG_KEEP = 4
+_SMALL_EIG = 256  # lgnn_symeig_batched's one-workgroup path
 
-    A factor H (n x n) smaller than the largest (m x m) is embedded as blockdiag(H, -mean_eig(H) I): the blocks never couple (Householder reflectors and the divide and
-    conquer splits keep exact zeros), D's eigenpairs sort first, H's are the last n rows restricted to the
-    first n columns.  Returns [(eigenvalues, eigenvectors)] with ``symeig``'s conventions (ascending, clamped
-    at 0, NaNs zeroed, eigenvectors in columns); non-convergence falls back to ``symeig`` for that factor."""
+
+def _cached_large_symeig(H: torch.Tensor):
+    for k, (Hc, lam, Q) in enumerate(_LARGE_EIG_CACHE):
+        if Hc.shape == H.shape and Hc.device == H.device:
+            scale = Hc.abs().max()
+            if bool((H - Hc).abs().max() <= 1e-6 * scale):
+                _LARGE_EIG_CACHE.append(_LARGE_EIG_CACHE.pop(k))
+                return lam.clone(), Q.clone()
+    return None
+
+
+def _symeig_group_hip(mats: list) -> list:
+    """ONE ``lgnn_symeig_batched`` call over factors padded to their common size."""
     from . import _lib
     lib = _lib.load()
     dev = mats[0].device
@@ -52,6 +66,34 @@ def symeig_batched_hip(mats: list) -> list:
         lam = torch.nan_to_num(W[b, m - n:].clamp(min=0.0))
         Q = torch.nan_to_num(A[b, m - n:, :n].T.contiguous())
         out.append((lam, Q))
+    return out
+
+
+def symeig_batched_hip(mats: list) -> list:
+    """Eigendecompose several symmetric PSD factors on the GPU (``lgnn_symeig_batched``): per-factor ``torch.linalg.eigh`` is
+    a serial chain of ~100 single-workgroup kernels (3.3 ms per 256 x 256 factor).  Factors of up to 256 rows go through ONE
+    call (hand-written tridiagonalisation, all factors side by side: the four arxiv factors in 2 ms), larger ones one call
+    each (padding a 64 x 64 factor to 1 433 would cost a second large decomposition), reusing a cached result where the
+    same matrix was decomposed before.
+
+    A factor H (n x n) smaller than the largest of its call (m x m) is embedded as blockdiag(H, -mean_eig(H) I): the blocks never couple (Householder reflectors and the divide and
+    conquer splits keep exact zeros), D's eigenpairs sort first, H's are the last n rows restricted to the
+    first n columns.  Returns [(eigenvalues, eigenvectors)] with ``symeig``'s conventions (ascending, clamped
+    at 0, NaNs zeroed, eigenvectors in columns); non-convergence falls back to ``symeig`` for that factor."""
+    out = [None] * len(mats)
+    small = [b for b, H in enumerate(mats) if H.shape[0] <= _SMALL_EIG]
+    if small:
+        for b, pair in zip(small, _symeig_group_hip([mats[b] for b in small])):
+            out[b] = pair
+    for b, H in enumerate(mats):
+        if out[b] is not None:
+            continue
+        hit = _cached_large_symeig(H)
+        if hit is None:
+            hit = _symeig_group_hip([H])[0]
+            _LARGE_EIG_CACHE.append((H.detach().clone(), hit[0].clone(), hit[1].clone()))
+            del _LARGE_EIG_CACHE[:-_LARGE_EIG_KEEP]
+        out[b] = hit
     return out
 
 

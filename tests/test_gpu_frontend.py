@@ -445,6 +445,33 @@ def test_matrix_free_glm_variance_matches_the_jacobian_route_and_the_reference(n
     model.engine.check_async_errors()
 
 
+def test_decomposition_groups_small_factors_and_caches_large_ones():
+    """Kron.decompose on the GPU: factors of up to 256 rows share one call of the hand-written path, larger ones (a
+    Cora-shaped model's 1 433 x 1 433 input covariance) get a call of their own and are served from the cache the second
+    time; every eigenpair against fp64."""
+    from laplace_gnn_amd import matrix as mx
+
+    g = torch.Generator().manual_seed(1)
+    mats = []
+    for n, rank in ((300, 300), (64, 64), (7, 6), (257, 200), (256, 256)):
+        G = torch.randn(700, n, generator=g, dtype=torch.float64)
+        if rank < n:
+            G[:, rank:] = G[:, : n - rank] + G[:, 1: n - rank + 1]
+        mats.append((G.T @ G / 700).float().cuda())
+    mx._LARGE_EIG_CACHE.clear()
+    first = mx.symeig_batched_hip(mats)
+    assert len(mx._LARGE_EIG_CACHE) == 2  # the 300 and the 257
+    second = mx.symeig_batched_hip(mats)
+    for H, (lam, Q), (lam2, Q2) in zip(mats, first, second):
+        ref = torch.linalg.eigvalsh(H.double()).clamp(min=0)
+        assert float((lam.double() - ref).abs().max()) <= 2e-6 * float(ref.max())
+        assert float(((Q * lam) @ Q.T - H).norm() / H.norm()) < 1e-5
+        assert float((Q.T @ Q - torch.eye(H.shape[0], device="cuda")).abs().max()) < 1e-4
+        if H.shape[0] > 256:
+            assert torch.equal(lam, lam2) and torch.equal(Q, Q2)  # served from the cache
+    mx._LARGE_EIG_CACHE.clear()
+
+
 def test_rccl_backend_initialises_and_reduces_on_this_box():
     """The N > 1 path uses ``dist.init_process_group("nccl", device_id=...)`` (RCCL) and one flat all-reduce.  The pool has
     one GPU per box and RCCL refuses two ranks on one device, so the collective itself can only be exercised at world

@@ -167,6 +167,26 @@ def test_kron_tied_hint_follows_the_arithmetic(monkeypatch):
     assert torch.allclose(kd.to_matrix(), plain.to_matrix(), atol=1e-5)
 
 
+def test_large_factor_decomposition_cache_hits_only_within_rounding():
+    """matrix._cached_large_symeig: the decomposition of a large factor (a GCN's X^T X: independent of weights and adjacency)
+    is reused when the new factor equals a cached one to fp32 rounding, never for a genuinely different matrix."""
+    from laplace_gnn_amd import matrix as mx
+
+    g = torch.Generator().manual_seed(0)
+    G = torch.randn(500, 300, generator=g)
+    H = G.T @ G / 500
+    lam, Q = mx.symeig(H)
+    saved = list(mx._LARGE_EIG_CACHE)
+    try:
+        mx._LARGE_EIG_CACHE[:] = [(H.clone(), lam, Q)]
+        hit = mx._cached_large_symeig(H + 1e-8 * torch.randn(300, 300, generator=g))
+        assert hit is not None and torch.equal(hit[0], lam) and hit[0] is not lam
+        assert mx._cached_large_symeig(H * 1.001) is None
+        assert mx._cached_large_symeig(H[:200, :200]) is None
+    finally:
+        mx._LARGE_EIG_CACHE[:] = saved
+
+
 # ---- loaders ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,bs", [(33, 12), (10, 10), (7, 100), (25, 1)])
 def test_tensor_batch_loader_has_dataloader_boundaries(n, bs):

@@ -5,15 +5,16 @@ import torch
 import bench
 import laplace_gnn_amd as lg
 
-w, ei, X, tri, try_ = bench.make_workload("arxiv", "cuda")
+w, ei, X, tri, try_ = bench.make_workload(sys.argv[2] if len(sys.argv) > 2 else "arxiv", "cuda")
 torch.manual_seed(0)
 kind = sys.argv[1] if len(sys.argv) > 1 else "gcn"
 model = (lg.GCN if kind == "gcn" else lg.GraphSAGE)(w["F"], w["H"], w["C"], 2, X, ei, symmetric=True).to("cuda")
 loader = lg.TensorBatchLoader(tri.cuda(), try_.cuda(), batch_size=w["batch"])
 la = lg.KronLaplace(model, "classification")
 la.fit(loader)
+t0 = time.perf_counter(); la.fit(loader); torch.cuda.synchronize(); print(kind, f"fit {(time.perf_counter() - t0) * 1e3:.2f} ms")
 for cand in (None, torch.randint(0, w["N"], (2, 100_000), generator=torch.Generator().manual_seed(1)).cuda()):
-    for rep in range(3):
+    for rep in range(5):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = la.neg_marglik_adj_grad(loader, candidates=cand)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
