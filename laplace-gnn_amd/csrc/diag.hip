@@ -63,22 +63,27 @@ __global__ void q_kernel(const float* __restrict__ probs, int64_t M, int64_t C, 
     if (has_self) { q[M * d + t] = ssn; q[2 * M * d + t] = sss; }
     return;
   }
+  // centred form: q = sum_k p_k (w_k - wbar)(u_k - ubar), wbar = sum_k p_k w_k -- no cancellation between two large sums
+  // (and exactly zero for a single class, where softmax is 1 and Lambda vanishes)
   for (int64_t k = 0; k < C; ++k) {
     const float p = probs[m * C + k];
-    const float wn = W1[k * ldw + off_neigh + j];
-    snn += p * wn * wn;
-    sn += p * wn;
+    sn += p * W1[k * ldw + off_neigh + j];
+    if (has_self) ss += p * W1[k * ldw + off_self + j];
+  }
+  for (int64_t k = 0; k < C; ++k) {
+    const float p = probs[m * C + k];
+    const float dn = W1[k * ldw + off_neigh + j] - sn;
+    snn += p * dn * dn;
     if (has_self) {
-      const float ws = W1[k * ldw + off_self + j];
-      sss += p * ws * ws;
-      ss += p * ws;
-      ssn += p * ws * wn;
+      const float dsf = W1[k * ldw + off_self + j] - ss;
+      sss += p * dsf * dsf;
+      ssn += p * dsf * dn;
     }
   }
-  q[t] = snn - sn * sn;
+  q[t] = snn;
   if (has_self) {
-    q[M * d + t] = ssn - ss * sn;
-    q[2 * M * d + t] = sss - ss * ss;
+    q[M * d + t] = ssn;
+    q[2 * M * d + t] = sss;
   }
 }
 
