@@ -470,6 +470,15 @@ def test_decomposition_groups_small_factors_and_caches_large_ones():
         if H.shape[0] > 256:
             assert torch.equal(lam, lam2) and torch.equal(Q, Q2)  # served from the cache
     mx._LARGE_EIG_CACHE.clear()
+    # more factors than side streams (8), sizes 1 and 2 included
+    many = []
+    for i, n in enumerate((1, 2, 3, 5, 17, 40, 64, 100, 128, 200, 255, 256)):
+        G = torch.randn(300, n, generator=g, dtype=torch.float64)
+        many.append((G.T @ G / 300).float().cuda())
+    for H, (lam, Q) in zip(many, mx.symeig_batched_hip(many)):
+        ref = torch.linalg.eigvalsh(H.double()).clamp(min=0)
+        assert float((lam.double() - ref).abs().max()) <= 2e-6 * float(ref.max()), H.shape
+        assert float(((Q * lam) @ Q.T - H).norm() / H.norm()) < 1e-5, H.shape
 
 
 def test_rccl_backend_initialises_and_reduces_on_this_box():

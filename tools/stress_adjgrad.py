@@ -1,0 +1,55 @@
+"""dev: KronLaplace.neg_marglik_adj_grad on random small configurations (both model families, isolated nodes, repeated node
+ids, symmetric parameter, candidates) against the oracle's reverse chain (usage: python tools/stress_adjgrad.py FIRST LAST)."""
+import os, sys, traceback
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import gnn_laplace_oracle as O
+import laplace_gnn_amd as lg
+from gpu_utils import oracle_from_arrays, rel
+
+first, last = int(sys.argv[1]), int(sys.argv[2])
+bad = []
+for seed in range(first, last):
+    r = np.random.default_rng(seed)
+    kind = "gcn" if r.random() < 0.5 else "sage"
+    N = int(r.integers(30, 500)); F = int(r.integers(2, 40)); H = int(r.choice([4, 8, 16, 32, 64, 128, 256]))
+    C = int(r.integers(2, 12)); E = int(r.integers(0, 5 * N)); M = int(r.integers(2, min(N, 200)))
+    bs = int(r.choice([M, max(1, M // 2), max(1, M // 3 + 1)])); sym = bool(r.random() < 0.5); fe = bool(r.random() < 0.8)
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, N, (2, E), generator=g) if E else torch.zeros(2, 0, dtype=torch.int64)
+    X = torch.randn(N, F, generator=g)
+    torch.manual_seed(seed)
+    try:
+        model = (lg.GCN if kind == "gcn" else lg.GraphSAGE)(F, H, C, 2, X, ei, symmetric=sym).to("cuda").eval()
+        idx = torch.randint(0, N, (M,), generator=g)  # with repeats
+        y = torch.randint(0, C, (M,), generator=g)
+        loader = lg.TensorBatchLoader(idx.cuda(), y.cuda(), batch_size=bs)
+        if seed % 3 == 0:
+            model.engine.set_workspace_limit(1 << 20)
+        la = lg.KronLaplace(model, "classification", prior_precision=0.6, backend_kwargs=dict(fork_exact_seed=fe))
+        la.fit(loader)
+        cand = torch.randint(0, N, (2, 50), generator=g)
+        cand = cand[:, cand[0] != cand[1]]
+        val, e2, grad, gc = la.neg_marglik_adj_grad(loader, candidates=cand.cuda())
+        Ws = [c.lin.weight.detach().cpu().numpy() for c in model.convs]
+        bsn = [c.lin.bias.detach().cpu().numpy() for c in model.convs]
+        om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), Ws, bsn, sym)
+        oval, rows, cols, og = O.kron_marglik_adj_grad(om, idx.numpy(), y.numpy(), bs, 0.6, fe, sym)
+        _, gd = O.kron_marglik_adj_grad(om, idx.numpy(), y.numpy(), bs, 0.6, fe, sym, dense=True)
+        stored = set(zip(rows.tolist(), cols.tolist()))
+        keep = np.array([(int(i), int(j)) not in stored for i, j in cand.t().tolist()], dtype=bool)
+        e_val = abs(float(val) - oval) / abs(oval)
+        e_g = rel(grad.cpu().numpy(), og) if len(og) else 0.0
+        e_c = rel(gc.cpu().numpy()[keep], gd[cand[0].numpy()[keep], cand[1].numpy()[keep]]) if keep.any() else 0.0
+        model.engine.check_async_errors()
+        if not (e_val < 5e-4 and e_g < 2e-3 and e_c < 2e-3):
+            bad.append((seed, kind, N, F, H, C, E, M, bs, sym, fe, e_val, e_g, e_c))
+            print("MISMATCH", bad[-1], flush=True)
+    except Exception as e:  # noqa: BLE001
+        bad.append((seed, kind, N, F, H, C, E, M, bs, sym, fe, repr(e)[:200]))
+        traceback.print_exc()
+    if seed % 20 == 0:
+        print("seed", seed, "failures so far", len(bad), flush=True)
+print("FAILURES", bad)
