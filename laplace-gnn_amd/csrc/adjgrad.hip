@@ -172,8 +172,9 @@ __global__ __launch_bounds__(256) void sddmm_spmm_kernel(const int32_t* __restri
 __global__ __launch_bounds__(256) void sddmm_spmm_pm_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                             const float* __restrict__ val, const int32_t* __restrict__ rows,
                                                             const int32_t* __restrict__ nrows_dev, float* __restrict__ U,
-                                                            const float* __restrict__ R, int64_t N, int64_t width,
-                                                            const float* __restrict__ dact, float* __restrict__ out) {
+                                                            int64_t u_plane_stride, const float* __restrict__ R, int64_t N,
+                                                            int64_t width, const float* __restrict__ dact,
+                                                            float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int c0 = lane * 4;
   const bool col_ok = c0 < width;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void sddmm_spmm_pm_kernel(const int32_t* __res
   if (w >= total) return;
   const int64_t a = rows ? int64_t(rows[w]) : w;
   const int64_t plane = blockIdx.y;
-  float* __restrict__ Up = U + plane * N * width;
+  float* __restrict__ Up = U + plane * u_plane_stride;
   const float* __restrict__ Rp = R + plane * N * width;
   const int32_t s = rowptr[a], e = rowptr[a + 1];
   float4 u = make_float4(0.f, 0.f, 0.f, 0.f), dm = u, acc = u;
@@ -236,7 +237,7 @@ using srd_t = __amdgpu_buffer_rsrc_t;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 __global__ __launch_bounds__(256) void spmm256_skip_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                            const float* __restrict__ val, int64_t N, const float* __restrict__ in,
-                                                           int64_t width, float* __restrict__ out) {
+                                                           int64_t in_plane_stride, int64_t width, float* __restrict__ out) {
   constexpr int UNR = 8;
   constexpr uint32_t kDead = 0xfffff000u;
   const int lane = threadIdx.x & 63;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void spmm256_skip_kernel(const int32_t* __rest
   if (row >= N) return;
   const int64_t plane = blockIdx.y;
   const uint32_t plane_bytes = uint32_t(N * width * 4);
-  const srd_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + plane * N * width), 0, plane_bytes, 0x00020000);
+  const srd_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + plane * in_plane_stride), 0, plane_bytes, 0x00020000);
   const uint32_t lane_off = lane * 4 < width ? uint32_t(lane) * 16u : kDead;
   const uint32_t row_bytes = uint32_t(width) * 4u;
   const int32_t s = rowptr[row], e = rowptr[row + 1];
@@ -962,17 +963,29 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
                               grad_cand, s);
   LGNN_CALL(batch_prologue(h, idx, y, M, true, fork_exact, nullptr, s));
 
-  // top layer: g1 planes [C][N][C] over all rows + flags of the rows that are not identically zero
+  // top layer: g1 planes [C][N][C] + flags / list of the rows that are not identically zero.  Without candidate pairs only
+  // ACTIVE rows are ever read below (the zero-skipping SpMM, the active-row SDDMM + SpMM, the batch rows' gathers), so the
+  // fit's own top-layer kernel writes just those rows (0.3 ms instead of 3.5 ms over all N rows) and the backward GEMM runs
+  // over the compacted list (0.9 ms instead of 4.4 ms): rows that are not active hold whatever the buffers held and are
+  // never looked at.  Candidate pairs can name any row: then everything is defined on all N rows as before.
+  const bool compact = K == 0 && H == 256 && h->fc.mask_bits[0].p != nullptr && backgemm_supported(C, H, true) &&
+                       (N + 1) * H * 4 < (int64_t(1) << 31) && getenv("LGNN_ADJ_ALL_ROWS") == nullptr &&
+                       getenv("LGNN_ADJ_CHUNKED") == nullptr;
+  const int64_t u_stride = compact ? (N + 1) * H : N * H;  // the compacted backward GEMM wants a spare row per plane
   LGNN_CALL(h->ws.top.reserve(size_t(N) * CC * 4 + 16));
   LGNN_CALL(h->ws.active.reserve(size_t(N)));
   float* g1 = h->ws.top.as<float>();
-  hipLaunchKernelGGL(seed_planes_kernel, dim3(unsigned(cdiv(N, 4))), dim3(256), 0, s, h->PT.rowptr, h->PT.col, h->PT.val, N,
-                     C, h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), g1, h->ws.active.as<uint8_t>());
-  LGNN_HIP_CHECK(hipGetLastError());
-  LGNN_CALL(h->ws.act_list.reserve(size_t(N) * 4));
-  LGNN_CALL(h->ws.act_count.reserve(64));
-  LGNN_CALL(compact_flags(h->ws.active.as<uint8_t>(), N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(),
-                          h->ws.select_tmp, s));
+  if (compact) {
+    LGNN_CALL(kfac_top_planes(h, idx, M, fork_exact, g1, s));
+  } else {
+    hipLaunchKernelGGL(seed_planes_kernel, dim3(unsigned(cdiv(N, 4))), dim3(256), 0, s, h->PT.rowptr, h->PT.col, h->PT.val, N,
+                       C, h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), g1, h->ws.active.as<uint8_t>());
+    LGNN_HIP_CHECK(hipGetLastError());
+    LGNN_CALL(h->ws.act_list.reserve(size_t(N) * 4));
+    LGNN_CALL(h->ws.act_count.reserve(64));
+    LGNN_CALL(compact_flags(h->ws.active.as<uint8_t>(), N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(),
+                            h->ws.select_tmp, s));
+  }
   LGNN_CALL(h->ws.jac.reserve(size_t(M) * CC * 4));  // Vbar [M][C][C]
   float* vbar = h->ws.jac.as<float>();
   // values of P^T with the columns of inactive (all-zero) source rows removed
@@ -985,28 +998,38 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   // class chunks: three [cc][N][H] plane buffers (u / ubar, g0, g0bar) + g1bar [cc][N][C] under the workspace cap
   const int64_t per_class = N * (3 * H + C) * 4;
   const int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(C, h->ws_limit / std::max<int64_t>(per_class, 1)));
-  LGNN_CALL(h->ws.planes_a.reserve(size_t(cc_max) * N * H * 4 * 2));
+  LGNN_CALL(h->ws.planes_a.reserve(size_t(cc_max) * (u_stride + N * H) * 4));
   LGNN_CALL(h->ws.planes_b.reserve(size_t(cc_max) * N * (H + C) * 4));
   h->ws.planes_a_zero_ptr = nullptr;
   for (int64_t c0 = 0; c0 < C; c0 += cc_max) {
     const int64_t cc = std::min(cc_max, C - c0);
     float* U = h->ws.planes_a.as<float>();
-    float* G0 = U + cc_max * N * H;
+    float* G0 = U + cc_max * u_stride;
     float* G0B = h->ws.planes_b.as<float>();
     float* G1B = G0B + cc_max * N * H;
     const float* g1c = g1 + c0 * N * C;
     // u = mask * (g1 W1)     [cc * N, H]
-    GemmEpilogue ep;
-    ep.hact = h->fc.hact_p[0]; ep.hact_ld = h->fc.hact_ld[0]; ep.act = h->act; ep.hact_row_mod = N;
-    LGNN_CALL(launch_gemm(g1c, C, h->W[1], H, U, H, cc * N, C, H, ep, s));
+    if (compact) {
+      // the compacted backward GEMM of the fit: active rows only (row N of every plane takes its padding stores)
+      BackGemmArgs bg{};
+      bg.G = g1c; bg.W = h->W[1]; bg.ldw = H; bg.U = U; bg.u_plane_stride = u_stride; bg.N = N; bg.K = C; bg.Nout = H;
+      bg.planes = cc;
+      bg.rows = h->ws.act_list.as<int32_t>(); bg.na_dev = h->ws.act_count.as<int32_t>();
+      bg.mask_bits = h->fc.mask_bits[0].as<uint32_t>(); bg.mask_words = cdiv(H, 32);
+      LGNN_CALL(launch_backgemm(bg, s));
+    } else {
+      GemmEpilogue ep;
+      ep.hact = h->fc.hact_p[0]; ep.hact_ld = h->fc.hact_ld[0]; ep.act = h->act; ep.hact_row_mod = N;
+      LGNN_CALL(launch_gemm(g1c, C, h->W[1], H, U, H, cc * N, C, H, ep, s));
+    }
     // g0 = P^T u  (source rows with u = 0 are not gathered: their values are zeroed)
     SpmmArgs sa{};
     sa.rowptr = h->PT.rowptr; sa.col = h->PT.col; sa.val = val_act; sa.nrows = N;
-    sa.in = U; sa.in_ld = H; sa.in_plane_stride = N * H; sa.out = G0; sa.out_ld = H; sa.out_plane_stride = N * H;
+    sa.in = U; sa.in_ld = H; sa.in_plane_stride = u_stride; sa.out = G0; sa.out_ld = H; sa.out_plane_stride = N * H;
     sa.width = H; sa.out_act = -1;
     if (H % 4 == 0 && H <= 256 && N * H * 4 < (int64_t(1) << 32) - (int64_t(1) << 14) && cc < 65536) {
       hipLaunchKernelGGL(spmm256_skip_kernel, dim3(unsigned(cdiv(N, 4)), unsigned(cc)), dim3(256), 0, s, h->PT.rowptr, h->PT.col,
-                         val_act, N, U, H, G0);
+                         val_act, N, U, u_stride, H, G0);
       LGNN_HIP_CHECK(hipGetLastError());
     } else {
       LGNN_CALL(launch_spmm_ex(sa, cc, s));
@@ -1022,7 +1045,7 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
       static const bool chunked = getenv("LGNN_ADJ_CHUNKED") != nullptr;  // dev: the 8-planes-per-wave kernel
       if (!chunked && cc < 65536)
         hipLaunchKernelGGL(sddmm_spmm_pm_kernel, dim3(unsigned(cdiv(N, 4)), unsigned(cc)), dim3(256), 0, s, h->P.rowptr, h->P.col,
-                           h->P.val, rows, h->ws.act_count.as<int32_t>(), U, G0B, N, H, h->fc.dact0.as<float>(), grad_P);
+                           h->P.val, rows, h->ws.act_count.as<int32_t>(), U, u_stride, G0B, N, H, h->fc.dact0.as<float>(), grad_P);
       else
         hipLaunchKernelGGL(sddmm_spmm_kernel<8>, dim3(unsigned(std::min<int64_t>(cdiv(N, 4), 8192))), dim3(256), 0, s,
                            h->P.rowptr, h->P.col, h->P.val, rows, h->ws.act_count.as<int32_t>(), U, G0B, N, H, cc,
@@ -1039,7 +1062,18 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
       LGNN_CALL(launch_spmm_ex(sb, cc, s));
     }
     // g1bar = ubar W1^T + 2 g1 Gamma_B1     [cc * N, C]
-    LGNN_CALL(sgemm_rm(s, cc * N, C, H, 1.f, U, H, h->Wt[1].as<float>(), C, 0.f, G1B, C));
+    if (compact) {  // planes of U are (N + 1) rows apart: one batched call, plane by plane
+      rocblas_handle blas = static_cast<rocblas_handle>(blas_handle(s));
+      LGNN_REQUIRE(blas != nullptr, "rocBLAS handle");
+      const float one = 1.f, zero = 0.f;
+      const rocblas_status st = rocblas_sgemm_strided_batched(
+          blas, rocblas_operation_none, rocblas_operation_none, rocblas_int(C), rocblas_int(N), rocblas_int(H), &one,
+          h->Wt[1].as<float>(), rocblas_int(C), 0, U, rocblas_int(H), rocblas_stride(u_stride), &zero, G1B, rocblas_int(C),
+          rocblas_stride(N * C), rocblas_int(cc));
+      if (st != rocblas_status_success) { set_error("rocblas_sgemm_strided_batched failed"); return 3; }
+    } else {
+      LGNN_CALL(sgemm_rm(s, cc * N, C, H, 1.f, U, H, h->Wt[1].as<float>(), C, 0.f, G1B, C));
+    }
     LGNN_CALL(sgemm_rm(s, cc * N, C, C, 2.f, g1c, C, gamma_B1, C, 1.f, G1B, C));
     // gradP[(a,b)] += sum_c <G_c[a], g1bar_c[b]> for the batch rows a;  Vbar = (P g1bar)[batch rows]
     hipLaunchKernelGGL(sddmm_seed_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, h->P.rowptr, h->P.col, idx, M, N, C,

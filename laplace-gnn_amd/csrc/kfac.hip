@@ -714,6 +714,33 @@ int batch_epilogue(lgnn_ctx* h, const int64_t* idx, int64_t M, hipStream_t s) {
   return 0;
 }
 
+// The GCN top layer of one batch for a caller outside the accumulate (adjgrad.hip): active rows (flags in ws.active, list in
+// ws.act_list / ws.act_count) and the class-major planes g[c][n][:] of ALL C classes for those rows -- rows that are not
+// active are NOT written.  Needs batch_prologue's probabilities / multiplicities; the Gram it also forms goes to a scratch.
+int kfac_top_planes(lgnn_ctx* h, const int64_t* idx, int64_t M, bool fork_exact, float* g, hipStream_t s) {
+  const int64_t N = h->N, C = h->dims[h->L];
+  LGNN_REQUIRE(h->kind == LGNN_KIND_GCN, "internal: top-layer planes are a GCN step");
+  LGNN_CALL(h->ws.active.reserve(size_t(N)));
+  LGNN_HIP_CHECK(hipMemsetAsync(h->ws.active.p, 0, size_t(N), s));
+  hipLaunchKernelGGL(mark_active_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, idx, M, N, h->P.rowptr, h->P.col,
+                     h->ws.active.as<uint8_t>());
+  LGNN_HIP_CHECK(hipGetLastError());
+  LGNN_CALL(h->ws.act_list.reserve(size_t(N) * 4));
+  LGNN_CALL(h->ws.act_count.reserve(64));
+  LGNN_CALL(compact_flags(h->ws.active.as<uint8_t>(), N, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(),
+                          h->ws.select_tmp, s));
+  const int l = h->L - 1;
+  LGNN_CALL(h->ws.gram_scratch[l].reserve(size_t(C) * C * 4));
+  LGNN_HIP_CHECK(hipMemsetAsync(h->ws.gram_scratch[l].p, 0, size_t(C) * C * 4, s));
+  float* sc = h->ws.gram_scratch[l].as<float>();
+  switch (int(cdiv(C, 16))) {
+    case 1: return seed_spmm_gram_launch<1>(h, fork_exact, g, 0, C, sc, s);
+    case 2: return seed_spmm_gram_launch<2>(h, fork_exact, g, 0, C, sc, s);
+    case 3: return seed_spmm_gram_launch<3>(h, fork_exact, g, 0, C, sc, s);
+    default: return seed_spmm_gram_launch<4>(h, fork_exact, g, 0, C, sc, s);
+  }
+}
+
 int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train, uint32_t flags,
                     int64_t cb, int64_t ce, float* const* A_out, float* const* B_out, float* loss_out, hipStream_t s,
                     const KfacFisherOpts* fisher) {

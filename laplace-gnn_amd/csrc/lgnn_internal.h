@@ -214,6 +214,7 @@ int launch_backgemm(const BackGemmArgs& g, hipStream_t s);
 int launch_relu_mask_bits(const float* h, int64_t ld, int64_t N, int64_t H, uint32_t* bits, hipStream_t s);
 // out[0:count) = sorted indices i with flags[i] != 0; *count_dev = count   (graph.hip, rocPRIM select)
 int compact_flags(const uint8_t* flags, int64_t n, int32_t* out, int32_t* count_dev, DevBuf& tmp, hipStream_t s);
+int kfac_top_planes(lgnn_ctx* h, const int64_t* idx, int64_t M, bool fork_exact, float* g, hipStream_t s);  // kfac.hip
 int exclusive_scan_i32(int32_t* in, int32_t* out, int64_t n, DevBuf& tmp, hipStream_t s);  // graph.hip, rocPRIM
 
 // ---- graph.hip -----------------------------------------------------------------------

@@ -68,14 +68,18 @@ def test_adjacency_gradient_midsize_vs_oracle(fork_exact, sym, H, C, kind):
     la.fit(loader)
     cand = torch.randint(0, N, (2, 300), generator=torch.Generator().manual_seed(5))
     cand = cand[:, cand[0] != cand[1]]
+    # without candidate pairs first: at H = 256 that is the path that defines the planes on the active rows only (the fit's
+    # top-layer kernel and compacted backward GEMM); with candidates everything is defined on all rows
+    val0, _, grad0 = la.neg_marglik_adj_grad(loader)
     val, e2, grad, gc = la.neg_marglik_adj_grad(loader, candidates=cand.cuda())
+    assert abs(float(val0) - float(val)) <= 1e-6 * abs(float(val)) and rel(grad0.cpu().numpy(), grad.cpu().numpy()) < 1e-5
     Ws = [c.lin.weight.detach().cpu().numpy() for c in model.convs]
     bs = [c.lin.bias.detach().cpu().numpy() for c in model.convs]
     om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), Ws, bs, sym)
     oval, rows, cols, og = O.kron_marglik_adj_grad(om, idx.numpy(), y.numpy(), 200, 0.5, fork_exact, sym)
     assert np.array_equal(e2[0].cpu().numpy(), rows) and np.array_equal(e2[1].cpu().numpy(), cols)
     assert abs(float(val) - oval) <= 2e-4 * abs(oval)
-    assert rel(grad.cpu().numpy(), og) < 1e-3
+    assert rel(grad.cpu().numpy(), og) < 1e-3 and rel(grad0.cpu().numpy(), og) < 1e-3
     # candidate pairs against the oracle's dense N x N gradient; pairs that are stored edges are not candidates
     _, gd = O.kron_marglik_adj_grad(om, idx.numpy(), y.numpy(), 200, 0.5, fork_exact, sym, dense=True)
     stored = set(zip(rows.tolist(), cols.tolist()))
