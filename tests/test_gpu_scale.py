@@ -195,6 +195,36 @@ def test_arxiv_shape_graphsage_properties():
     eng.check_async_errors()
 
 
+def test_power_law_arxiv_shape_eight_emulated_ranks_sum_to_the_single_fit():
+    """arxiv sizes with power-law degrees (hubs of thousands of neighbours: the long-row side kernel, the top layer's sliced
+    hub rows) dealt to 8 emulated ranks as (batch, class-range) units: the ranks' flat buffers add up to the single-process
+    fit -- what the RCCL all-reduce produces on a node -- on three batches."""
+    import bench
+    import laplace_gnn_amd as lg
+
+    w, ei, X, train_idx, train_y = bench.make_workload("arxiv_powerlaw", "cuda")
+    torch.manual_seed(0)
+    model = lg.GCN(w["F"], w["H"], w["C"], 2, X, ei, symmetric=True).to("cuda").eval()
+    eng = model.engine
+    n = 3 * w["batch"] - 4000  # two full batches and a ragged one
+    idx, y = train_idx.cuda()[:n], train_y.cuda()[:n]
+    loader = lg.TensorBatchLoader(idx, y, w["batch"])
+    flat1, views1, loss1 = eng.new_kfac_buffers()
+    for xb, yb in loader:
+        eng.kfac_accumulate(xb, yb, n, views1, loss1)
+    assert eng.num_long_rows > 100
+    total = None
+    batches = list(loader)
+    for rank in range(8):
+        flat, views, loss = eng.new_kfac_buffers()
+        for t, c0, c1 in lg.units_of_rank(len(batches), w["C"], rank, 8):
+            eng.kfac_accumulate(batches[t][0], batches[t][1], n, views, loss, classes=(c0, c1))
+        total = flat.clone() if total is None else total + flat
+    torch.cuda.synchronize()
+    assert rel(total.cpu().numpy(), flat1.cpu().numpy()) < 1e-5
+    eng.check_async_errors()
+
+
 def test_arxiv_shape_sampled_oracle_check(arxiv):
     """B_1 (40 x 40) of one full-size batch against the oracle's sparse backward restricted to the top
     layer (cheap on the CPU: no 256-wide planes)."""
