@@ -281,6 +281,7 @@ def main():
 
     def step(timed=False):
         eng.invalidate()  # a fresh fit: forward + input Grams are recomputed, nothing carried over
+        lg.matrix._LARGE_EIG_CACHE.clear()  # (nor a cached decomposition of a large factor: --workload cora --structure kron)
         if timed:
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             e[0].record()
