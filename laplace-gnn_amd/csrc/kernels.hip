@@ -40,10 +40,19 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a) {
       int32_t j0 = a.col[p], j1 = a.col[p + 1], j2 = a.col[p + 2], j3 = a.col[p + 3];
       float v0 = a.val[p], v1 = a.val[p + 1], v2 = a.val[p + 2], v3 = a.val[p + 3];
       if constexpr (VEC == 4) {
-        float4 x0 = *reinterpret_cast<const float4*>(in + int64_t(j0) * a.in_ld + c0);
-        float4 x1 = *reinterpret_cast<const float4*>(in + int64_t(j1) * a.in_ld + c0);
-        float4 x2 = *reinterpret_cast<const float4*>(in + int64_t(j2) * a.in_ld + c0);
-        float4 x3 = *reinterpret_cast<const float4*>(in + int64_t(j3) * a.in_ld + c0);
+        float4 x0, x1, x2, x3;
+        if (a.skip_zero) {  // (kernel argument: uniform)
+          x0 = x1 = x2 = x3 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (v0 != 0.f) x0 = *reinterpret_cast<const float4*>(in + int64_t(j0) * a.in_ld + c0);
+          if (v1 != 0.f) x1 = *reinterpret_cast<const float4*>(in + int64_t(j1) * a.in_ld + c0);
+          if (v2 != 0.f) x2 = *reinterpret_cast<const float4*>(in + int64_t(j2) * a.in_ld + c0);
+          if (v3 != 0.f) x3 = *reinterpret_cast<const float4*>(in + int64_t(j3) * a.in_ld + c0);
+        } else {
+          x0 = *reinterpret_cast<const float4*>(in + int64_t(j0) * a.in_ld + c0);
+          x1 = *reinterpret_cast<const float4*>(in + int64_t(j1) * a.in_ld + c0);
+          x2 = *reinterpret_cast<const float4*>(in + int64_t(j2) * a.in_ld + c0);
+          x3 = *reinterpret_cast<const float4*>(in + int64_t(j3) * a.in_ld + c0);
+        }
         acc[0] += v0 * x0.x; acc[1] += v0 * x0.y; acc[2] += v0 * x0.z; acc[3] += v0 * x0.w;
         acc[0] += v1 * x1.x; acc[1] += v1 * x1.y; acc[2] += v1 * x1.z; acc[3] += v1 * x1.w;
         acc[0] += v2 * x2.x; acc[1] += v2 * x2.y; acc[2] += v2 * x2.z; acc[3] += v2 * x2.w;
@@ -58,7 +67,8 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a) {
       int32_t j = a.col[p];
       float v = a.val[p];
       if constexpr (VEC == 4) {
-        float4 x = *reinterpret_cast<const float4*>(in + int64_t(j) * a.in_ld + c0);
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!a.skip_zero || v != 0.f) x = *reinterpret_cast<const float4*>(in + int64_t(j) * a.in_ld + c0);
         acc[0] += v * x.x; acc[1] += v * x.y; acc[2] += v * x.z; acc[3] += v * x.w;
       } else {
         acc[0] += v * in[int64_t(j) * a.in_ld + c0];

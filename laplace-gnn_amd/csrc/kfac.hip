@@ -937,6 +937,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
             LGNN_REQUIRE(pong != nullptr, "internal: unfused path without its output planes");
             SpmmArgs sa{};
             sa.rowptr = a.rowptr; sa.col = a.col; sa.val = a.val; sa.nrows = N;
+            sa.skip_zero = a.val != h->PT.val;  // the per-batch values: zero at the columns of all-zero source rows
             sa.in = ping; sa.in_ld = d; sa.in_plane_stride = N * d;
             sa.out = pong; sa.out_ld = d; sa.out_plane_stride = N * d; sa.width = d; sa.out_act = -1;
             LGNN_CALL(launch_spmm_ex(sa, cc, s));
@@ -968,6 +969,25 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           }
           FusedArgs a{};
           a.rowptr = h->PT.rowptr; a.col = h->PT.col; a.val = (l == L - 1) ? val_top : h->PT.val;
+          if (l == L - 2 && !no_fuse && h->nnz > 0) {
+            // second backward level of a deeper model: its source planes (dcat of g_{L-2}) are non-zero only where the level
+            // above could write, i.e. on the batch nodes and their neighbours (products shape: 20 % of the rows) -- the
+            // other columns' values are zeroed once per batch and their rows are not gathered
+            if (c0 == cb) {
+              LGNN_CALL(h->ws.out_flags.reserve(size_t(N)));
+              LGNN_CALL(h->ws.val_act2.reserve(size_t(h->nnz) * 4));
+              LGNN_HIP_CHECK(hipMemsetAsync(h->ws.out_flags.p, 0, size_t(N), s));
+              hipLaunchKernelGGL(mark_active_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, idx, M, N, h->P.rowptr,
+                                 h->P.col, h->ws.out_flags.as<uint8_t>());
+              hipLaunchKernelGGL(mark_batch_flags_kernel, dim3(unsigned(cdiv(M, 256))), dim3(256), 0, s, idx, M, N,
+                                 h->ws.out_flags.as<uint8_t>());
+              hipLaunchKernelGGL(mask_values_kernel, dim3(unsigned(std::min<int64_t>(cdiv(h->nnz, 256), 4096))), dim3(256), 0, s,
+                                 h->PT.col, h->PT.val, h->nnz, h->ws.out_flags.as<uint8_t>(), h->ws.pos.as<int32_t>(),
+                                 h->ws.val_act2.as<float>());
+              LGNN_HIP_CHECK(hipGetLastError());
+            }
+            a.val = h->ws.val_act2.as<float>();
+          }
           a.nrows = N; a.nplanes = cc;
           a.in = ping + d; a.in_ld = 2 * d; a.in_plane_stride = ping_stride;
           a.self = ping; a.self_ld = 2 * d; a.self_plane_stride = ping_stride;
@@ -1015,6 +1035,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
             LGNN_REQUIRE(pong != nullptr, "internal: unfused path without its output planes");
             SpmmArgs sa{};
             sa.rowptr = a.rowptr; sa.col = a.col; sa.val = a.val; sa.nrows = N;
+            sa.skip_zero = a.val != h->PT.val;  // the per-batch values: zero at the columns of all-zero source rows
             sa.in = a.in; sa.in_ld = a.in_ld; sa.in_plane_stride = a.in_plane_stride;
             sa.self = a.self; sa.self_ld = a.self_ld; sa.self_plane_stride = a.self_plane_stride;
             sa.hact = a.hact; sa.hact_ld = a.hact_ld; sa.act = a.act;

@@ -103,6 +103,7 @@ struct Workspace {
   DevBuf select_tmp;
   DevBuf flags;  // 64 B of asynchronous error flags
   DevBuf out_flags, out_list, out_count;  // GraphSAGE KFAC: rows of the first backward plane set that can be non-zero
+  DevBuf val_act2;  // P^T's values with the columns outside that row set zeroed (second backward level of deeper models)
 };
 
 }  // namespace lgnn
@@ -172,6 +173,9 @@ struct SpmmArgs {
   // rows with more than kLongRow stored entries (hubs), optional: the row kernel skips them and a side kernel with a
   // whole workgroup per row writes them (vector path only)
   const int32_t* long_rows; int64_t n_long;
+  // entries whose value is exactly zero are not gathered (per-batch copies of P^T's values with the columns of all-zero
+  // source rows zeroed: at the products shape 99.6 % of the first backward SpMM's entries)
+  bool skip_zero;
 };
 
 struct FusedArgs {
