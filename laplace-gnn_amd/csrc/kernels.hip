@@ -895,7 +895,10 @@ int launch_spmm_gram_ex(const FusedArgs& a, hipStream_t s) {
 bool fused_supported(int64_t width, int64_t in_ld, int64_t in_plane_stride, const void* in, int64_t rows) {
   if (!(width <= 256 && width % 4 == 0 && in_ld % 4 == 0 && in_plane_stride % 4 == 0 && aligned16(in))) return false;
   // the 256-wide kernel addresses a plane (and its self plane) through 32-bit buffer offsets
-  if (width > 128 && rows * in_ld * 4 >= (int64_t(1) << 32) - 4096) return false;
+  // (LGNN_PLANE_LIMIT, bytes: dev switch that lowers the bound so that tests reach the large-plane path at small sizes)
+  int64_t limit = (int64_t(1) << 32) - 4096;
+  if (const char* e = getenv("LGNN_PLANE_LIMIT")) limit = std::min<int64_t>(limit, atoll(e));
+  if (width > 128 && rows * in_ld * 4 >= limit) return false;
   return true;
 }
 

@@ -363,6 +363,33 @@ def test_long_rows_take_the_side_kernel_vs_oracle(kind, H, L):
     eng.close()
 
 
+@pytest.mark.parametrize("kind", ["sage", "gcn"])
+def test_large_plane_path_at_small_size_vs_oracle(kind, monkeypatch):
+    """Planes beyond the fused kernel's 4 GiB addressing (products-shaped GraphSAGE KFAC: 5 GB) take SpMM + Gram through HBM
+    with the per-batch masked values: entries whose value is zero are not gathered, and a deeper GraphSAGE model's second
+    backward level is masked with the rows the level above can write.  LGNN_PLANE_LIMIT lowers the bound so that a 3-layer,
+    256-wide model on 3 000 nodes takes exactly that path; results against the oracle."""
+    monkeypatch.setenv("LGNN_PLANE_LIMIT", "1000000")
+    N, F, H, C, E, L = 3000, 20, 256, 5, 9000, 3
+    ei, X, Ws, bs = _make(kind, N, F, H, C, E, L=L, seed=77)
+    g = torch.Generator().manual_seed(9)
+    idx = torch.randperm(N, generator=g)[:300]
+    idx[280:] = idx[:20]
+    y = torch.randint(0, C, (300,), generator=g)
+    eng = _engine(kind, N, ei, X, Ws, bs)
+    plan = eng.kfac_plan()
+    assert not any(plan["fused"][1:]), plan  # the backward steps left the fused path
+    views, loss = kfac_fit_engine(eng, idx.cuda(), y.cuda(), 128)  # 128 / 128 / 44
+    om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], True)
+    oloss, oH = O.fit_kron(om, idx.numpy(), y.numpy(), 128)
+    for l, (A, B) in enumerate(views):
+        assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL, f"B_{l}"
+        assert rel(A.cpu().numpy(), oH[2 * l][1]) < RTOL, f"A_{l}"
+    assert abs(loss - float(oloss)) < RTOL * abs(float(oloss))
+    eng.check_async_errors()
+    eng.close()
+
+
 def _random_config(seed):
     r = np.random.default_rng(seed)
     kind = "gcn" if r.random() < 0.6 else "sage"
