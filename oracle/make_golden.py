@@ -49,7 +49,7 @@ def reference_adj_to_edge_index(adj):
 
 
 def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch_size, seed,
-              symmetric=False, isolated=0, with_full=False):
+              symmetric=False, isolated=0, with_full=False, norm=None, res=False, full_only=False):
     from torch.utils.data import DataLoader, TensorDataset
 
     g = torch.Generator().manual_seed(seed)
@@ -61,13 +61,25 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
     adj0 = reference_dense_adj(torch, ei, n)
 
     torch.manual_seed(seed)
+    extras = dict(norm=norm, res=res) if (norm is not None or res) else {}  # BaseGNN kwargs (base_gnn.py:22-23)
     if kind == "gcn":
         model = ns.gnn_models.GCN(f, h, c, layers, X, adj0.clone(), dropout_p=0.5,
-                                  symmetric=symmetric)
+                                  symmetric=symmetric, **extras)
     else:
         model = ns.gnn_models.GraphSAGE(f, h, c, layers, X, adj0.clone(),
                                         num_sampled_nodes_per_hop=None, dropout_p=0.5,
-                                        symmetric=symmetric)
+                                        symmetric=symmetric, **extras)
+    if norm is not None:
+        # non-trivial norm state (a fresh LayerNorm / BatchNorm1d is gamma = 1, beta = 0, running stats 0 / 1): the harness
+        # sets it, the reference computes with it
+        gn = torch.Generator().manual_seed(seed + 1000)
+        with torch.no_grad():
+            for nm in model.norms:
+                nm.weight.copy_(0.5 + torch.rand(h, generator=gn))
+                nm.bias.copy_(0.3 * torch.randn(h, generator=gn))
+                if norm == "batch":
+                    nm.running_mean.copy_(0.2 * torch.randn(h, generator=gn))
+                    nm.running_var.copy_(0.5 + torch.rand(h, generator=gn))
     model.eval()
     perm = torch.randperm(n, generator=g)
     train_idx = perm[:n_train].clone()
@@ -84,6 +96,18 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
     for l, conv in enumerate(model.convs):
         out[f"W{l}"] = conv.lin.weight.detach().numpy().copy()
         out[f"b{l}"] = conv.lin.bias.detach().numpy().copy()
+    if extras:
+        out["norm"], out["res"] = str(norm), bool(res)
+        out["param_names"] = np.array([k for k, v in model.named_parameters()
+                                       if v.requires_grad and "adj" not in k and "norms" not in k])
+        for l, lin in enumerate(model.res):
+            out[f"Wr{l}"], out[f"br{l}"] = lin.weight.detach().numpy().copy(), lin.bias.detach().numpy().copy()
+        if norm is not None:
+            out["norm_eps"] = np.float64(model.norms[0].eps)
+            for l, nm in enumerate(model.norms):
+                out[f"norm_w{l}"], out[f"norm_b{l}"] = nm.weight.detach().numpy().copy(), nm.bias.detach().numpy().copy()
+                if norm == "batch":
+                    out[f"norm_rm{l}"], out[f"norm_rv{l}"] = nm.running_mean.numpy().copy(), nm.running_var.numpy().copy()
 
     with torch.no_grad():
         adj = model.adj.detach()
@@ -180,7 +204,7 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
     out["diag_H"] = ld.H.detach().numpy().astype(np.float32)
     out["n_data"], out["n_outputs"], out["n_params"] = ld.n_data, ld.n_outputs, ld.n_params
 
-    if with_full:
+    if with_full and not full_only:
         # regression likelihood on the same model (MSELoss, Hessian sqrt = sqrt(2) I, factor 0.5): float targets
         reg_y = torch.randn(n_train, c, generator=g)
         out["reg_y"] = reg_y.numpy()
@@ -227,7 +251,7 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
         out["fullla_glm_fvar"] = f_var.detach().numpy().astype(np.float32)
         out["fullla_glm_probit"] = lf(eval_idx, pred_type="glm", link_approx="probit").detach().numpy().astype(np.float32)
 
-    if with_full:
+    if with_full and not full_only:
         # empirical Fisher (EFInterface / CurvlinopsEF) and Monte-Carlo Fisher (stochastic=True) of the same model; the
         # labels the reference draws (curvlinops/kfac.py:698-745, curvature.py:343-364) are recorded: the device path
         # takes them as an input, a random stream cannot be reproduced across devices
@@ -297,7 +321,7 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
             Mn.sample = orig_sample
         out["ggnmc_labels_diag"], out["ggnmc_labels_full"] = np.stack(first), np.stack(second)
 
-    if layers == 2:
+    if layers == 2 and not extras:
         # 8(f)-4: what the GNN driver differentiates (gnn/marglik_training.py:197-216): -log marglik of a KronLaplace fit
         # w.r.t. the dense adjacency parameter of the STE model (gnn/models/models.py:65-118), same weights (same seed,
         # same construction order), prior precision 0.7.  Stored: the gradient on the stored entries of the 0/1
@@ -404,6 +428,28 @@ def main():
     make_case(ns, torch, "sage3_small_3batch_s1", "sage", **small3, n_train=33, batch_size=12, seed=23, isolated=3)
     make_case(ns, torch, "gcn3_mid_2batch_s0", "gcn", **mid3, n_train=120, batch_size=70, seed=24)
     make_case(ns, torch, "sage3_mid_2batch_s1", "sage", **mid3, n_train=120, batch_size=70, seed=25, symmetric=True)
+    # res=True / norm="layer"|"batch" (gnn/models/base_gnn.py:86-113, 141-149; gnn/configs/original/gcn_config.yaml:36-58 ship
+    # norm: layer + res: True): kron / diag / logits (and full GGN + Jacobians on the *_1batch cases) from the reference
+    ex = dict(with_full=True, full_only=True)
+    make_case(ns, torch, "gcn_resln_small_1batch_s0", "gcn", **small, n_train=33, batch_size=10000, seed=30, norm="layer",
+              res=True, **ex)
+    make_case(ns, torch, "gcn_resln_small_3batch_s1", "gcn", **small, n_train=33, batch_size=12, seed=31, norm="layer",
+              res=True, symmetric=True)
+    make_case(ns, torch, "sage_resln_small_1batch_s0", "sage", **small, n_train=33, batch_size=10000, seed=32,
+              norm="layer", res=True, **ex)
+    make_case(ns, torch, "sage_resln_small_3batch_s1", "sage", **small, n_train=33, batch_size=12, seed=33, norm="layer",
+              res=True, isolated=3)
+    make_case(ns, torch, "gcn_res_small_3batch_s2", "gcn", **small, n_train=33, batch_size=12, seed=34, res=True)
+    make_case(ns, torch, "gcn_bn_small_3batch_s3", "gcn", **small, n_train=33, batch_size=12, seed=35, norm="batch")
+    make_case(ns, torch, "sage_resbn_small_1batch_s4", "sage", **small, n_train=33, batch_size=10000, seed=36,
+              norm="batch", res=True)
+    make_case(ns, torch, "gcn_resln_mid_2batch_s0", "gcn", **mid, n_train=150, batch_size=100, seed=37, norm="layer",
+              res=True)
+    make_case(ns, torch, "sage_ln_mid_2batch_s1", "sage", **mid, n_train=150, batch_size=100, seed=38, norm="layer")
+    make_case(ns, torch, "gcn3_resln_small_3batch_s5", "gcn", **small3, n_train=33, batch_size=12, seed=39, norm="layer",
+              res=True)
+    make_case(ns, torch, "sage3_resln_small_1batch_s6", "sage", **small3, n_train=33, batch_size=10000, seed=40,
+              norm="layer", res=True, **ex)
     if not only or "c1_regression_mlp" in only:
         make_regression_mlp(ns, torch)
 
