@@ -47,6 +47,11 @@ extern "C" {
 #define LGNN_ACT_RELU 0
 #define LGNN_ACT_TANH 1
 
+/* normalisation between a hidden layer's convolution and its activation (gnn/models/base_gnn.py:86-95, 148) */
+#define LGNN_NORM_NONE 0  /* nn.Identity                                        */
+#define LGNN_NORM_LAYER 1 /* nn.LayerNorm(hidden): per-row statistics           */
+#define LGNN_NORM_BATCH 2 /* nn.BatchNorm1d(hidden) in eval mode: running stats */
+
 /* likelihoods (laplace/curvature/curvature.py:63-72) */
 #define LGNN_LIK_CLASSIFICATION 0 /* CrossEntropyLoss(sum), factor 1   */
 #define LGNN_LIK_REGRESSION 1     /* MSELoss(sum), factor 0.5          */
@@ -102,6 +107,21 @@ LGNN_API int lgnn_bind_model(lgnn_ctx* h, int num_layers, const int64_t* dims /*
                     const float* const* weights /* host array of L device ptrs */,
                     const float* const* biases /* host array of L device ptrs */, const float* X,
                     int activation, int likelihood);
+/* Optional pieces of BaseGNN.forward (gnn/models/base_gnn.py:86-113 construction, :141-149 forward; shipped configs
+ * gnn/configs/original/gcn_config.yaml:36-58 use norm: layer + res: True).  Call after lgnn_bind_model (which resets them):
+ *   res_weights / res_biases : host arrays of L-1 device pointers, `res.{l}.weight` [dims[l+1], dims[l]] / `res.{l}.bias`
+ *                              (NULL: res=False); x = res_l(x) + conv_l(adj, x) for every hidden layer;
+ *   norm_kind                : LGNN_NORM_*; norm_weight / norm_bias [dims[l+1]] per hidden layer (`norms.{l}.weight|bias`),
+ *                              norm_mean / norm_var = BatchNorm1d running statistics (eval mode; NULL otherwise).
+ * The `res.{l}` Linears are Laplace parameters AFTER all `convs.*` (named_parameters order; laplace/curvature/
+ * curvature.py:74-79 filters `norms.*` out): every per-parameter output grows accordingly -- A_out / B_out of the KFAC calls
+ * take 2 L - 1 pointers (convs.0 .. convs.{L-1}, res.0 .. res.{L-2}; curvlinops/kfac.py:877-916 gives every nn.Linear its
+ * block), diag / Jacobians / full GGN append the res parameters.  With extras bound the KFAC accumulate runs its unfused
+ * route (GEMM, row-local norm backward, SpMM^T, Gram as separate kernels) and the diagonal GGN / Jacobians the generic plane
+ * route; the adjacency gradient and the matrix-free GLM variance refuse such models.                                 */
+LGNN_API int lgnn_bind_extras(lgnn_ctx* h, const float* const* res_weights, const float* const* res_biases, int norm_kind,
+                     const float* const* norm_weight, const float* const* norm_bias, const float* const* norm_mean,
+                     const float* const* norm_var, float norm_eps);
 LGNN_API int lgnn_invalidate(lgnn_ctx* h);
 /* bytes currently held by the context (graph + caches + workspace).  host value. */
 LGNN_API int64_t lgnn_device_bytes(const lgnn_ctx* h);

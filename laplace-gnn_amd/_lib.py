@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("LGNN_LIB_DIR", "lib"), "liblaplac
 KIND_GCN, KIND_SAGE = 0, 1
 ACT_RELU, ACT_TANH = 0, 1
 LIK_CLASSIFICATION, LIK_REGRESSION = 0, 1
+NORM_NONE, NORM_LAYER, NORM_BATCH = 0, 1, 2
 FLAG_FORK_EXACT_SEED, FLAG_NO_FUSE = 1, 2
 
 # name -> (restype, argtypes); mirrors include/laplace_gnn_hip.h one to one
@@ -32,6 +33,7 @@ SIGNATURES = {
     "lgnn_adj_to_edge_index": (_i32, [_vp, _vp, C.POINTER(_i64), _vp]),
     "lgnn_export_propagation": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "lgnn_bind_model": (_i32, [_vp, _i32, C.POINTER(_i64), _pp, _pp, _vp, _i32, _i32]),
+    "lgnn_bind_extras": (_i32, [_vp, _pp, _pp, _i32, _pp, _pp, _pp, _pp, C.c_float]),
     "lgnn_invalidate": (_i32, [_vp]),
     "lgnn_device_bytes": (_i64, [_vp]),
     "lgnn_set_workspace_limit": (_i32, [_vp, _i64]),

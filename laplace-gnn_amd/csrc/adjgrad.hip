@@ -813,6 +813,7 @@ __global__ void relu_mask_ld_kernel(float* __restrict__ x, const float* __restri
 
 int check_model(const lgnn_ctx* h) {
   LGNN_REQUIRE(h->L == 2, "adjacency gradient: 2-layer models (SURVEY.md 8(f)-4)");
+  LGNN_REQUIRE(!h->extras(), "adjacency gradient: models without res / norm");
   LGNN_REQUIRE(h->act == LGNN_ACT_RELU && h->lik == LGNN_LIK_CLASSIFICATION, "adjacency gradient: ReLU, classification");
   LGNN_REQUIRE(h->dims[2] <= 256, "adjacency gradient: at most 256 classes");
   LGNN_REQUIRE(h->kind == LGNN_KIND_GCN || (h->dims[1] % 4 == 0 && h->dims[1] <= 256),

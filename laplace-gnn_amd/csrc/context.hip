@@ -74,9 +74,35 @@ static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
                             din, dout, ep, s));
       if (l < L - 1) {
         LGNN_CALL(fc.act_out[l].reserve(size_t(N) * dout * 4));
-        // h_{l+1} = act(A_hat Z_l)  (norm = Identity, dropout = identity in eval; base_gnn.py:141-156)
-        LGNN_CALL(launch_spmm(h->P, N, fc.tmp.as<float>(), dout, fc.act_out[l].as<float>(), dout, dout,
-                              h->act == LGNN_ACT_RELU ? 1 : 2, s, lr, nlr));
+        if (!h->extras()) {
+          // h_{l+1} = act(A_hat Z_l)  (norm = Identity, dropout = identity in eval; base_gnn.py:141-156)
+          LGNN_CALL(launch_spmm(h->P, N, fc.tmp.as<float>(), dout, fc.act_out[l].as<float>(), dout, dout,
+                                h->act == LGNN_ACT_RELU ? 1 : 2, s, lr, nlr));
+        } else {
+          // s = res_l(h_l) + A_hat Z_l (base_gnn.py:141-144); n = norms[l](s) (:148); h_{l+1} = act(n) (:151)
+          const bool nrm = h->norm != LGNN_NORM_NONE;
+          SpmmArgs a{};
+          a.rowptr = h->P.rowptr; a.col = h->P.col; a.val = h->P.val; a.nrows = N;
+          a.in = fc.tmp.as<float>(); a.in_ld = dout; a.width = dout;
+          a.long_rows = lr; a.n_long = nlr;
+          if (h->has_res) {
+            LGNN_CALL(fc.res_out.reserve(size_t(N) * maxw * 4));
+            GemmEpilogue er;
+            er.bias = h->br[l];
+            LGNN_CALL(launch_gemm(fc.lin_in_p[l], fc.lin_in_ld[l], h->Wrt[l].as<float>(), dout, fc.res_out.as<float>(), dout,
+                                  N, din, dout, er, s));
+            a.self = fc.res_out.as<float>(); a.self_ld = dout;
+          }
+          if (nrm) {
+            LGNN_CALL(fc.pre_norm.reserve(size_t(N) * maxw * 4));
+            a.out = fc.pre_norm.as<float>(); a.out_ld = dout; a.out_act = -1;
+            LGNN_CALL(launch_spmm_ex(a, 1, s));
+            LGNN_CALL(launch_norm_forward(h, l, fc.pre_norm.as<float>(), dout, fc.act_out[l].as<float>(), dout, s));
+          } else {
+            a.out = fc.act_out[l].as<float>(); a.out_ld = dout; a.out_act = h->act;
+            LGNN_CALL(launch_spmm_ex(a, 1, s));
+          }
+        }
         fc.hact_p[l] = fc.act_out[l].as<float>();
         fc.hact_ld[l] = dout;
         if (h->act == LGNN_ACT_RELU) {
@@ -110,9 +136,18 @@ static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
       GemmEpilogue ep;
       ep.bias = h->b[l];
       if (l < L - 1) {
-        ep.out_act = h->act;
         float* nxt = fc.lin_in[l + 1].as<float>();
-        LGNN_CALL(launch_gemm(cat, 2 * d, h->Wt[l].as<float>(), dout, nxt, 2 * dout, N, 2 * d, dout, ep, s));
+        // with res: Wt[l] holds (W_l + [Wr_l | 0])^T and the bias is b_l + br_l (res_l and the conv's Linear read the same
+        // rows, base_gnn.py:141-144); with a norm the activation moves behind it (:148-151)
+        if (h->has_res) ep.bias = h->bcomb[l].as<float>();
+        if (h->norm != LGNN_NORM_NONE) {
+          LGNN_CALL(fc.pre_norm.reserve(size_t(N) * maxw * 4));
+          LGNN_CALL(launch_gemm(cat, 2 * d, h->Wt[l].as<float>(), dout, fc.pre_norm.as<float>(), dout, N, 2 * d, dout, ep, s));
+          LGNN_CALL(launch_norm_forward(h, l, fc.pre_norm.as<float>(), dout, nxt, 2 * dout, s));
+        } else {
+          ep.out_act = h->act;
+          LGNN_CALL(launch_gemm(cat, 2 * d, h->Wt[l].as<float>(), dout, nxt, 2 * dout, N, 2 * d, dout, ep, s));
+        }
         fc.hact_p[l] = nxt;
         fc.hact_ld[l] = 2 * dout;
         if (h->act == LGNN_ACT_RELU) {  // bit masks of the ReLU derivative for the fused backward kernel
@@ -132,7 +167,17 @@ int forward_ensure(lgnn_ctx* h, hipStream_t s) {
   if (h->fc.valid) return 0;
   for (int l = 0; l < h->L; ++l) {
     LGNN_CALL(h->Wt[l].reserve(size_t(h->in_dim[l]) * h->dims[l + 1] * 4));
-    LGNN_CALL(launch_transpose(h->W[l], h->dims[l + 1], h->in_dim[l], h->Wt[l].as<float>(), s));
+    const float* W = h->W[l];
+    if (h->has_res && l < h->L - 1) {
+      if (h->kind == LGNN_KIND_SAGE) {
+        LGNN_CALL(build_sage_res_weights(h, l, s));
+        W = h->Wcomb[l].as<float>();
+      } else {
+        LGNN_CALL(h->Wrt[l].reserve(size_t(h->dims[l]) * h->dims[l + 1] * 4));
+        LGNN_CALL(launch_transpose(h->Wr[l], h->dims[l + 1], h->dims[l], h->Wrt[l].as<float>(), s));
+      }
+    }
+    LGNN_CALL(launch_transpose(W, h->dims[l + 1], h->in_dim[l], h->Wt[l].as<float>(), s));
   }
   LGNN_CALL(gcn_or_sage_forward(h, s));
   h->fc.valid = true;
@@ -223,12 +268,14 @@ extern "C" void lgnn_destroy(lgnn_ctx* h) {
   if (!h) return;
   (void)hipDeviceSynchronize();
   DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
-                    &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->fc.dact0, &h->fc.Xpad, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult, &h->ws.planes_a,
+                    &h->fc.out, &h->fc.tmp, &h->fc.res_out, &h->fc.pre_norm, &h->ws.planes_c, &h->fc.rowsum, &h->fc.dact0, &h->fc.Xpad, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult, &h->ws.planes_a,
                     &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->long_rows, &h->long_slot, &h->long_tasks, &h->hub, &h->long_rows_fwd, &h->top_multi, &h->top_tasks, &h->top_task_count, &h->top_cnt, &h->top_offs, &h->top_hub_tiles, &h->ws.top, &h->ws.flags, &h->ws.out_flags, &h->ws.out_list, &h->ws.out_count, &h->ws.val_act2, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (DevBuf* b : bufs) b->release();
   for (int l = 0; l < kMaxLayers; ++l) {
     h->Wt[l].release(); h->fc.lin_in[l].release(); h->fc.act_out[l].release(); h->fc.gram_raw[l].release();
     h->fc.prop_in[l].release(); h->ws.gram_scratch[l].release(); h->fc.mask_bits[l].release();
+    h->Wrt[l].release(); h->Wcomb[l].release(); h->bcomb[l].release(); h->fc.xhat[l].release(); h->fc.rstd[l].release();
+    h->ws.gram_scratch_res[l].release();
   }
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   delete h;
@@ -262,6 +309,8 @@ extern "C" int lgnn_bind_model(lgnn_ctx* h, int num_layers, const int64_t* dims,
   h->X = X;
   h->act = activation;
   h->lik = likelihood;
+  h->has_res = false;  // lgnn_bind_extras brings res / norm back
+  h->norm = LGNN_NORM_NONE;
   // the compact GraphSAGE top level keeps planes_a all zero outside the batch rows for ONE plane layout; a new
   // binding (other widths) must not inherit that claim: the old layout's spare rows hold stale backward-GEMM stores
   h->ws.planes_a_zero_ptr = nullptr;
@@ -294,12 +343,13 @@ extern "C" int64_t lgnn_device_bytes(const lgnn_ctx* h) {
   if (!h) return -1;
   size_t t = 0;
   const DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
-                          &h->fc.out, &h->fc.tmp, &h->fc.rowsum, &h->fc.dact0, &h->fc.Xpad, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult,
+                          &h->fc.out, &h->fc.tmp, &h->fc.res_out, &h->fc.pre_norm, &h->ws.planes_c, &h->fc.rowsum, &h->fc.dact0, &h->fc.Xpad, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult,
                           &h->ws.planes_a, &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->long_rows, &h->long_slot, &h->long_tasks, &h->hub, &h->long_rows_fwd, &h->top_multi, &h->top_tasks, &h->top_task_count, &h->top_cnt, &h->top_offs, &h->top_hub_tiles, &h->ws.top, &h->ws.flags, &h->ws.out_flags, &h->ws.out_list, &h->ws.out_count, &h->ws.val_act2, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (const DevBuf* b : bufs) t += b->bytes;
   for (int l = 0; l < kMaxLayers; ++l)
     t += h->Wt[l].bytes + h->fc.lin_in[l].bytes + h->fc.act_out[l].bytes + h->fc.gram_raw[l].bytes +
-         h->fc.prop_in[l].bytes + h->ws.gram_scratch[l].bytes + h->fc.mask_bits[l].bytes;
+         h->fc.prop_in[l].bytes + h->ws.gram_scratch[l].bytes + h->fc.mask_bits[l].bytes + h->Wrt[l].bytes +
+         h->Wcomb[l].bytes + h->bcomb[l].bytes + h->fc.xhat[l].bytes + h->fc.rstd[l].bytes + h->ws.gram_scratch_res[l].bytes;
   return int64_t(t);
 }
 

@@ -450,7 +450,7 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
   const int L = h->L;
   const int64_t C = h->dims[L];
   const bool regression = h->lik == LGNN_LIK_REGRESSION;
-  if (L > 2 || getenv("LGNN_JAC_PLANES") != nullptr) {
+  if (L > 2 || h->extras() || getenv("LGNN_JAC_PLANES") != nullptr) {
     // deeper models (the reference builds them once the breakpoint at gnn/models/base_gnn.py:109 is removed): per-sample
     // Jacobians in chunks + the contraction with Lambda; no closed form
     LGNN_CALL(forward_ensure(h, s));
@@ -571,7 +571,7 @@ int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const voi
   LGNN_CALL(forward_ensure(h, s));
   const int64_t C = h->dims[h->L], P = h->n_params, N = h->N;
   LGNN_CALL(batch_prologue(h, idx, y_loss ? y_loss : y_seed, M, false, false, y_loss ? loss_out : nullptr, s));
-  if (diag_out && !full_out && !grads_out && h->L <= 2 && getenv("LGNN_JAC_PLANES") == nullptr) {
+  if (diag_out && !full_out && !grads_out && h->L <= 2 && !h->extras() && getenv("LGNN_JAC_PLANES") == nullptr) {
     // diagonal only, <= 2 layers: the closed form of the diagonal GGN with other weights -- no Jacobians at all
     LGNN_CALL(forward_ensure_aux(h, s));
     const int L = h->L;
@@ -616,7 +616,7 @@ int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const voi
     return 0;
   }
   // <= 2 layers: the gradients come straight from the closed form (M * P floats); deeper models contract Jacobians
-  const bool closed = h->L <= 2 && getenv("LGNN_JAC_PLANES") == nullptr;
+  const bool closed = h->L <= 2 && !h->extras() && getenv("LGNN_JAC_PLANES") == nullptr;
   const int64_t jrows = closed ? 0 : C;
   const int64_t mc_max = std::max<int64_t>(1, std::min<int64_t>(M, (h->ws_limit / 4) / std::max<int64_t>((jrows + 1) * P * 4, 1)));
   LGNN_CALL(h->ws.jac.reserve(size_t(mc_max) * (jrows + 1) * P * 4 + size_t(mc_max) * C * 4));

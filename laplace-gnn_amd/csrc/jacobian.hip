@@ -245,17 +245,23 @@ int jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out
   LGNN_REQUIRE(h->L > 0, "no model bound");
   // 1- and 2-layer models: closed form (LGNN_JAC_PLANES=1 forces the generic plane route, which deeper models use)
   const bool force_planes = getenv("LGNN_JAC_PLANES") != nullptr;
-  if (h->L <= 2 && !force_planes) return jacobians_closed_form(h, idx, M, J, f_out, s);
+  // (models with res / norm have no closed form: the norm's row-local backward sits between the layers)
+  if (h->L <= 2 && !force_planes && !h->extras()) return jacobians_closed_form(h, idx, M, J, f_out, s);
   LGNN_CALL(forward_ensure(h, s));
   const int64_t N = h->N;
   const int L = h->L;
   const int64_t C = h->dims[L];
   const bool gcn = h->kind == LGNN_KIND_GCN;
-  int64_t off_w[kMaxLayers], off_b[kMaxLayers], P = 0;
+  int64_t off_w[kMaxLayers], off_b[kMaxLayers], off_rw[kMaxLayers], off_rb[kMaxLayers], P = 0;
   for (int l = 0; l < L; ++l) {
     off_w[l] = P; P += h->dims[l + 1] * h->in_dim[l];
     off_b[l] = P; P += h->dims[l + 1];
   }
+  for (int l = 0; h->has_res && l < L - 1; ++l) {  // res.{l}.weight|bias follow all convs.* (named_parameters order)
+    off_rw[l] = P; P += h->dims[l + 1] * h->dims[l];
+    off_rb[l] = P; P += h->dims[l + 1];
+  }
+  LGNN_REQUIRE(P == h->n_params, "internal: parameter count");
   int* bad = h->ws.flags.as<int>();
   if (f_out)
     LGNN_CALL(launch_gather_rows(h->fc.out.as<float>(), C, N, idx, M, C, f_out, bad + 2, s));
@@ -267,10 +273,24 @@ int jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out
   LGNN_REQUIRE(chunk * C < (int64_t(1) << 31) && N < (int64_t(1) << 31), "jacobians: chunk too large");
   LGNN_CALL(h->ws.planes_a.reserve(size_t(chunk) * C * N * maxw * 4));
   LGNN_CALL(h->ws.planes_b.reserve(size_t(chunk) * C * N * maxw * 4));
-  h->ws.planes_a_zero_ptr = nullptr;  // (the GraphSAGE KFAC path keeps an invariant on this buffer)
   rocblas_handle blas = static_cast<rocblas_handle>(blas_handle(s));
   LGNN_REQUIRE(blas != nullptr, "rocBLAS handle");
   const float one = 1.f, zero = 0.f;
+  const bool gcn_res = gcn && h->has_res;
+  if (gcn_res && L > 2) LGNN_CALL(h->ws.planes_c.reserve(size_t(chunk) * C * N * maxw * 4));
+  // d f / d res.{l} = u_l^T h_l, column sums of u_l (u_l = gradient at s_l; GraphSAGE: u_l = g_l)
+  auto res_block = [&](int l, const float* u, float* Jc, int64_t planes) -> int {
+    const int64_t dout = h->dims[l + 1], din = h->dims[l];
+    const rocblas_status st = rocblas_sgemm_strided_batched(
+        blas, rocblas_operation_none, rocblas_operation_transpose, rocblas_int(din), rocblas_int(dout), rocblas_int(N), &one,
+        h->fc.lin_in_p[l], rocblas_int(h->fc.lin_in_ld[l]), 0, u, rocblas_int(dout), rocblas_stride(N * dout), &zero,
+        Jc + off_rw[l], rocblas_int(din), rocblas_stride(P), rocblas_int(planes));
+    if (st != rocblas_status_success) { set_error("rocblas_sgemm_strided_batched failed"); return 3; }
+    hipLaunchKernelGGL(plane_colsum_kernel, dim3(unsigned(planes)), dim3(256), 0, s, u, N, dout, Jc + off_rb[l], P);
+    LGNN_HIP_CHECK(hipGetLastError());
+    return 0;
+  };
+  h->ws.planes_a_zero_ptr = nullptr;  // (the GraphSAGE KFAC path keeps an invariant on this buffer)
 
   for (int64_t m0 = 0; m0 < M; m0 += chunk) {
     const int64_t mc = std::min(chunk, M - m0);
@@ -296,13 +316,26 @@ int jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out
       if (st != rocblas_status_success) { set_error("rocblas_sgemm_strided_batched failed"); return 3; }
       hipLaunchKernelGGL(plane_colsum_kernel, dim3(unsigned(planes)), dim3(256), 0, s, g, N, dout, Jc + off_b[l], P);
       LGNN_HIP_CHECK(hipGetLastError());
+      if (!gcn && h->has_res && l < L - 1) LGNN_CALL(res_block(l, g, Jc, planes));  // GraphSAGE: res.{l} sees g_l too
       if (l == 0) break;
       const int64_t d = h->dims[l];
       if (gcn) {
         // up = act'(h_l) * (g W_l);  g_{l-1} = P^T up      (gnn/models/layers.py:45-46 backward)
         GemmEpilogue ep;
         ep.hact = h->fc.hact_p[l - 1]; ep.hact_ld = h->fc.hact_ld[l - 1]; ep.act = h->act; ep.hact_row_mod = N;
+        // res / norm (base_gnn.py:141-149 backwards): below the top level dh_l = g_l W_l + u_l Wr_l with u_l still in
+        // `other`; mask and the norm's row-local backward give u_{l-1}, which res.{l-1} sees and P^T propagates
+        const bool res_term = gcn_res && l < L - 1;
+        if (res_term) {
+          GemmEpilogue none;
+          LGNN_CALL(launch_gemm(other, dout, h->Wr[l], d, h->ws.planes_c.as<float>(), d, planes * N, dout, d, none, s));
+          ep = none;
+        }
         LGNN_CALL(launch_gemm(g, dout, h->W[l], d, other, d, planes * N, dout, d, ep, s));
+        if (res_term || h->norm != LGNN_NORM_NONE)
+          LGNN_CALL(launch_resnorm_backward(h, l - 1, other, d, planes * N, res_term ? h->ws.planes_c.as<float>() : nullptr,
+                                            res_term, s));
+        if (gcn_res) LGNN_CALL(res_block(l - 1, other, Jc, planes));
         SpmmArgs sa{};
         sa.rowptr = h->PT.rowptr; sa.col = h->PT.col; sa.val = h->PT.val; sa.nrows = N;
         sa.in = other; sa.in_ld = d; sa.in_plane_stride = N * d;
@@ -310,8 +343,9 @@ int jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out
         LGNN_CALL(launch_spmm_ex(sa, planes, s));
       } else {
         // dcat = g W_l [., 2d];  g_{l-1} = act'(h_l) * (dcat[:, :d] + P^T dcat[:, d:])   (layers.py:26-29 backward)
+        // (with res: W_l + [Wr_l | 0], the gradient at the Linear's output is res.{l}'s too)
         GemmEpilogue ep;
-        LGNN_CALL(launch_gemm(g, dout, h->W[l], 2 * d, other, 2 * d, planes * N, dout, 2 * d, ep, s));
+        LGNN_CALL(launch_gemm(g, dout, h->Wback(l), 2 * d, other, 2 * d, planes * N, dout, 2 * d, ep, s));
         SpmmArgs sa{};
         sa.rowptr = h->PT.rowptr; sa.col = h->PT.col; sa.val = h->PT.val; sa.nrows = N;
         sa.in = other + d; sa.in_ld = 2 * d; sa.in_plane_stride = N * 2 * d;
@@ -319,6 +353,7 @@ int jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J, float* f_out
         sa.hact = h->fc.hact_p[l - 1]; sa.hact_ld = h->fc.hact_ld[l - 1]; sa.act = h->act;
         sa.out = g; sa.out_ld = d; sa.out_plane_stride = N * d; sa.width = d; sa.out_act = -1;
         LGNN_CALL(launch_spmm_ex(sa, planes, s));
+        if (h->norm != LGNN_NORM_NONE) LGNN_CALL(launch_resnorm_backward(h, l - 1, g, d, planes * N, nullptr, false, s));
       }
     }
   }

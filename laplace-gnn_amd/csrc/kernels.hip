@@ -759,20 +759,21 @@ int launch_symmetrize_upper(float* H, int64_t D, hipStream_t s) {
 }
 
 __global__ void sym_accumulate_kernel(const float* __restrict__ scratch, int64_t D, float scale,
-                                      float* __restrict__ out) {
+                                      float* __restrict__ out, int64_t ld) {
   const int64_t n = D * D;
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
   for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < n; q += stride) {
     const int64_t i = q / D, j = q - i * D;
     const int64_t a = i < j ? i : j, b = i < j ? j : i;
-    out[q] += scale * scratch[a * D + b];
+    out[q] += scale * scratch[a * ld + b];
   }
 }
-int launch_sym_accumulate(const float* scratch, int64_t D, float scale, float* out, hipStream_t s) {
+// scratch_ld > D: the leading D x D block of a wider scratch (res.{l} of a GraphSAGE model sees the first half of cat_l)
+int launch_sym_accumulate(const float* scratch, int64_t D, float scale, float* out, hipStream_t s, int64_t scratch_ld) {
   if (D <= 0) return 0;
   const int64_t n = D * D;
   hipLaunchKernelGGL(sym_accumulate_kernel, dim3(unsigned(std::min<int64_t>(cdiv(n, 256), 2048))), dim3(256), 0, s,
-                     scratch, D, scale, out);
+                     scratch, D, scale, out, scratch_ld > 0 ? scratch_ld : D);
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -782,7 +782,9 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   const int L = h->L;
   const int64_t C = h->dims[L];
   const int64_t CC = C * C;
-  const bool no_fuse = (flags & LGNN_FLAG_NO_FUSE) != 0;
+  // models with res / norm (gnn/models/base_gnn.py:141-149) take the unfused route: GEMM, row-local norm backward,
+  // SpMM^T and Gram as separate kernels (resnorm.hip)
+  const bool no_fuse = (flags & LGNN_FLAG_NO_FUSE) != 0 || h->extras();
   LGNN_REQUIRE(M < INT32_MAX, "batch too large");
 
   const bool fork_exact = (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0;
@@ -796,11 +798,19 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   // A_l += in_l^T in_l / n_train   (kfac.py:870 divides by M, curvlinops.py:46-53 multiplies by M/N)
   for (int l = 0; once && l < L; ++l)
     LGNN_CALL(launch_sym_accumulate(h->fc.gram_raw[l].as<float>(), h->in_dim[l], 1.0f / float(n_train), A_out[l], s));
+  // res.{l} sees h_l itself: its input covariance is the conv's (GCN) resp. the leading block of cat_l's (GraphSAGE)
+  for (int l = 0; once && h->has_res && l < L - 1; ++l)
+    LGNN_CALL(launch_sym_accumulate(h->fc.gram_raw[l].as<float>(), h->dims[l], 1.0f / float(n_train), A_out[L + l], s,
+                                    h->in_dim[l]));
 
   for (int l = 0; l < L; ++l) {
     const int64_t D = h->dims[l + 1];
     LGNN_CALL(h->ws.gram_scratch[l].reserve(size_t(D) * D * 4));
     LGNN_HIP_CHECK(hipMemsetAsync(h->ws.gram_scratch[l].p, 0, size_t(D) * D * 4, s));
+    if (h->has_res && h->kind == LGNN_KIND_GCN && l < L - 1) {
+      LGNN_CALL(h->ws.gram_scratch_res[l].reserve(size_t(D) * D * 4));
+      LGNN_HIP_CHECK(hipMemsetAsync(h->ws.gram_scratch_res[l].p, 0, size_t(D) * D * 4, s));
+    }
   }
 
   // ---- top layer ---------------------------------------------------------------------------------
@@ -904,6 +914,8 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
                    "internal: activation row stride differs from the plan's");
     LGNN_CALL(h->ws.planes_a.reserve(size_t(cc_max) * (N + 1) * maxw * 4));  // + 1: the backward GEMM's spare row per plane
     if (need_pong) LGNN_CALL(h->ws.planes_b.reserve(size_t(cc_max) * N * maxw * 4));
+    const bool gcn_res_deep = h->has_res && h->kind == LGNN_KIND_GCN && L > 2;  // dh_l = g_l W_l + u_l Wr_l below the top level
+    if (gcn_res_deep) LGNN_CALL(h->ws.planes_c.reserve(size_t(cc_max) * N * maxw * 4));
     int64_t second_rows = 0;  // GraphSAGE, deeper models: rows the second backward level reads (host copy, per batch)
     for (int64_t c0 = cb; c0 < ce; c0 += cc_max) {
       const int64_t cc = std::min(cc_max, ce - c0);
@@ -924,6 +936,15 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           const bool fuse_here = plan.fuse[l];
           if (top_level && fuse_here) ep.row_active = row_active;  // inactive rows are never read below
           int64_t ping_stride = N * d;
+          // res / norm (unfused route only): below the top level the layer above has a res Linear whose gradient u_l (still
+          // in `ping` from the previous step) joins in, dh_l = g_l W_l + u_l Wr_l; then the activation mask and the norm's
+          // row-local backward turn dh_l into u_{l-1}, the gradient at s_{l-1} -- what res.{l-1} sees and what P^T propagates
+          const bool res_term = h->has_res && !top_level;
+          if (res_term) {
+            GemmEpilogue none;
+            LGNN_CALL(launch_gemm(ping, dout, h->Wr[l], d, h->ws.planes_c.as<float>(), d, cc * N, dout, d, none, s));
+            ep = none;  // the mask moves behind the sum
+          }
           // (32-bit row offsets inside a plane: beyond 2 GiB per plane the generic GEMM takes over)
           if (plan.backgemm[l]) {
             LGNN_REQUIRE(row_active != nullptr, "internal: compacted backward GEMM without its row list");
@@ -938,6 +959,11 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           } else {
             LGNN_CALL(launch_gemm(g, dout, h->W[l], d, ping, d, cc * N, dout, d, ep, s));
           }
+          if (res_term || h->norm != LGNN_NORM_NONE)
+            LGNN_CALL(launch_resnorm_backward(h, l - 1, ping, d, cc * N, res_term ? h->ws.planes_c.as<float>() : nullptr,
+                                              res_term, s));
+          if (h->has_res)  // B of res.{l-1}: the Gram of u_{l-1} before the propagation (curvlinops/kfac.py:777-817)
+            LGNN_CALL(launch_gram(ping, d, cc * N, d, h->ws.gram_scratch_res[l - 1].as<float>(), s));
           FusedArgs a{};
           a.rowptr = h->PT.rowptr; a.col = h->PT.col; a.val = (top_level && fuse_here) ? val_top : h->PT.val;
           a.nrows = N; a.nplanes = cc;
@@ -1022,7 +1048,8 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
                                  2 * d, 1);
               LGNN_HIP_CHECK(hipGetLastError());
             } else {
-              LGNN_CALL(launch_gemm(g, dout, h->W[l], 2 * d, ping, 2 * d, cc * N, dout, 2 * d, ep, s));
+              // (with res: W_l + [Wr_l | 0] -- the Linear's output gradient is also res.{l}'s, base_gnn.py:141-144)
+              LGNN_CALL(launch_gemm(g, dout, h->Wback(l), 2 * d, ping, 2 * d, cc * N, dout, 2 * d, ep, s));
             }
             h->ws.planes_a_zero_ptr = nullptr;  // every row written
           }
@@ -1082,6 +1109,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
             sa.hact = a.hact; sa.hact_ld = a.hact_ld; sa.act = a.act;
             sa.out = pong; sa.out_ld = d; sa.out_plane_stride = N * d; sa.width = d; sa.out_act = -1;
             LGNN_CALL(launch_spmm_ex(sa, cc, s));
+            if (h->norm != LGNN_NORM_NONE) LGNN_CALL(launch_resnorm_backward(h, l - 1, pong, d, cc * N, nullptr, false, s));
             LGNN_CALL(launch_gram(pong, d, cc * N, d, scratch, s));
           }
         }
@@ -1094,6 +1122,11 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
 
   for (int l = 0; l < L; ++l)
     LGNN_CALL(launch_sym_accumulate(h->ws.gram_scratch[l].as<float>(), h->dims[l + 1], b_scale, B_out[l], s));
+  // res.{l}: GCN -- the Gram of u_l taken before the propagation; GraphSAGE -- the Linear's output is not propagated, so
+  // convs.{l}.lin and res.{l} see the same gradient and share B
+  for (int l = 0; h->has_res && l < L - 1; ++l)
+    LGNN_CALL(launch_sym_accumulate((h->kind == LGNN_KIND_GCN ? h->ws.gram_scratch_res[l] : h->ws.gram_scratch[l]).as<float>(),
+                                    h->dims[l + 1], b_scale, B_out[L + l], s));
   LGNN_CALL(batch_epilogue(h, idx, M, s));
   return 0;
 }

@@ -79,6 +79,11 @@ struct ForwardCache {
   DevBuf rowsum;                     // rowsum(P) [N]
   DevBuf dact0;                      // act'(h_1) [N, dims[1]] (closed-form diagonal GGN of 2-layer models)
   DevBuf mask_bits[kMaxLayers];      // ReLU: bit j of word w of node n = (h_{l+1}[n][32w+j] > 0)
+  // models with res / norm (gnn/models/base_gnn.py:141-149): the norm's backward needs the normalised rows and 1/sigma
+  DevBuf xhat[kMaxLayers];           // [N, dims[l+1]] normalised pre-activation of hidden layer l
+  DevBuf rstd[kMaxLayers];           // LayerNorm: [N] 1/sqrt(var + eps) per row; BatchNorm (eval): [dims[l+1]] per channel
+  DevBuf res_out;                    // [N, max width] res_l(h_l) of the layer being computed (GCN)
+  DevBuf pre_norm;                   // [N, max width] s_l = res_l(h_l) + conv_l(h_l) before the norm
 };
 
 struct Workspace {
@@ -104,6 +109,8 @@ struct Workspace {
   DevBuf flags;  // 64 B of asynchronous error flags
   DevBuf out_flags, out_list, out_count;  // GraphSAGE KFAC: rows of the first backward plane set that can be non-zero
   DevBuf val_act2;  // P^T's values with the columns outside that row set zeroed (second backward level of deeper models)
+  DevBuf gram_scratch_res[kMaxLayers];  // res / norm models: per-call partial B of res.{l} (GCN; GraphSAGE shares the conv's)
+  DevBuf planes_c;  // GCN with res, >= 3 layers: u_l Wr_l of the level being computed
 };
 
 }  // namespace lgnn
@@ -128,6 +135,26 @@ struct lgnn_ctx {
   int act = 0, lik = 0;
   int64_t n_params = 0;
   lgnn::DevBuf Wt[lgnn::kMaxLayers];  // W_l^T [in_l, out_l] (forward GEMM operand)
+  // optional pieces of BaseGNN.forward (gnn/models/base_gnn.py:86-113, 141-149), bound by lgnn_bind_extras:
+  // x = res_l(x) + conv_l(adj, x); x = norms[l](x); x = act(x) for every hidden layer l < L-1
+  bool has_res = false;
+  int norm = 0;            // LGNN_NORM_*
+  float norm_eps = 1e-5f;
+  const float* Wr[lgnn::kMaxLayers] = {};  // res.{l}.weight [dims[l+1], dims[l]]
+  const float* br[lgnn::kMaxLayers] = {};
+  const float* norm_w[lgnn::kMaxLayers] = {};
+  const float* norm_b[lgnn::kMaxLayers] = {};
+  const float* norm_mean[lgnn::kMaxLayers] = {};  // BatchNorm1d running statistics (eval mode)
+  const float* norm_var[lgnn::kMaxLayers] = {};
+  lgnn::DevBuf Wrt[lgnn::kMaxLayers];    // GCN: Wr_l^T [dims[l], dims[l+1]] (forward GEMM operand)
+  // GraphSAGE with res: convs.{l}.lin and res.{l} read the same rows, so the forward and the backward use ONE combined
+  // weight  Wcomb_l = W_l + [Wr_l | 0]  [dims[l+1], 2 dims[l]] (row major; its transpose goes to Wt[l]) and bias b_l + br_l
+  lgnn::DevBuf Wcomb[lgnn::kMaxLayers], bcomb[lgnn::kMaxLayers];
+  bool extras() const { return has_res || norm != 0; }
+  int n_blocks() const { return has_res ? 2 * L - 1 : L; }  // KFAC blocks: convs.{0..L-1}.lin, then res.{0..L-2}
+  const float* Wback(int l) const {  // what the backward through layer l multiplies with
+    return (has_res && kind == LGNN_KIND_SAGE && l < L - 1) ? Wcomb[l].as<float>() : W[l];
+  }
   lgnn::ForwardCache fc;
   lgnn::Workspace ws;
   int64_t ws_limit = int64_t(32) << 30;  // backward planes (ping + pong) per class chunk: 288 GB of HBM, keep chunks large
@@ -258,7 +285,7 @@ int ll_bias_gemm(const float* Wq, const float* Phi, float* Sb, int64_t Q, int64_
 // lower triangle <- upper triangle
 int launch_symmetrize_upper(float* H, int64_t D, hipStream_t s);
 // out[i,j] += scale * scratch[min(i,j), max(i,j)]
-int launch_sym_accumulate(const float* scratch, int64_t D, float scale, float* out, hipStream_t s);
+int launch_sym_accumulate(const float* scratch, int64_t D, float scale, float* out, hipStream_t s, int64_t scratch_ld = 0);
 // fused: rows r=(plane, n): y = sum_j val*in_plane[col[j]]; scratch += y^T y; optional store of y
 int launch_spmm_ex(const SpmmArgs& a, int64_t nplanes, hipStream_t s);
 int launch_spmm_gram_ex(const FusedArgs& a, hipStream_t s);
@@ -275,6 +302,15 @@ int launch_fill_i32(int32_t* p, int64_t n, int32_t v, hipStream_t s);
 int launch_gather_rows(const float* in, int64_t ld, int64_t nrows_in, const int64_t* idx, int64_t M, int64_t width,
                        float* out, int* bad_flag, hipStream_t s);
 
+// ---- resnorm.hip: row-local pieces of models with res / norm (gnn/models/base_gnn.py:141-149) ------------------
+// h[n] = act(gamma * xhat[n] + beta), xhat = (s[n] - mean) * rstd; LayerNorm: per-row statistics (saved in rstd [N]);
+// eval-mode BatchNorm1d: running statistics (rstd [width], written here too)
+int launch_norm_forward(lgnn_ctx* h, int layer, const float* spre, int64_t s_ld, float* out, int64_t out_ld, hipStream_t s);
+// U [rows, width] (rows = planes * N, node = row % N), in place:
+//   t = U (+ add);  if mask: t *= act'(h_{layer+1}[node]);  U = norm_backward_layer(t)
+int launch_resnorm_backward(lgnn_ctx* h, int layer, float* U, int64_t ld, int64_t rows, const float* add, bool mask,
+                            hipStream_t s);
+int build_sage_res_weights(lgnn_ctx* h, int layer, hipStream_t s);  // Wcomb / bcomb of a GraphSAGE layer with res
 // ---- longrows.hip -----------------------------------------------------------------------
 constexpr int kLongRow = 64;
 constexpr int kTopSlice = 128;  // stored entries of a hub row per top-layer task  // rows of P^T with more stored entries leave the fused kernel's per-wave gather

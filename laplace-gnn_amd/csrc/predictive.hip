@@ -248,6 +248,7 @@ int glm_variance(lgnn_ctx* h, const int64_t* idx, int64_t M, const float* QA0, c
                  const float* QA1, const float* S1, const float* QB1sq, const float* kappa, float* f_mu, float* f_var,
                  hipStream_t s) {
   LGNN_REQUIRE(h->L == 2, "matrix-free GLM predictive: 2-layer models");
+  LGNN_REQUIRE(!h->extras(), "matrix-free GLM predictive: models without res / norm (use the Jacobian route)");
   LGNN_REQUIRE(M > 0 && idx && S0 && S1 && kappa && f_var, "empty batch or null pointers");
   const bool kron = QA0 != nullptr;
   const bool sage = h->kind == LGNN_KIND_SAGE;

@@ -15,6 +15,7 @@ from . import _lib
 KINDS = {"gcn": _lib.KIND_GCN, "sage": _lib.KIND_SAGE}
 ACTS = {"relu": _lib.ACT_RELU, "tanh": _lib.ACT_TANH}
 LIKS = {"classification": _lib.LIK_CLASSIFICATION, "regression": _lib.LIK_REGRESSION}
+NORMS = {None: _lib.NORM_NONE, "layer": _lib.NORM_LAYER, "batch": _lib.NORM_BATCH}
 
 
 def _stream(device) -> C.c_void_p:
@@ -125,7 +126,12 @@ class GraphEngine:
 
     # -- model ----------------------------------------------------------------------------------
     def bind(self, X: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
-             act: str = "relu", likelihood: str = "classification"):
+             act: str = "relu", likelihood: str = "classification", res_weights=None, res_biases=None, norm=None,
+             norm_weight=None, norm_bias=None, norm_mean=None, norm_var=None, norm_eps: float = 1e-5):
+        """``res_*`` / ``norm*``: the optional pieces of ``BaseGNN.forward`` (gnn/models/base_gnn.py:86-113, 141-149), one
+        entry per hidden layer: ``res.{l}`` Linear [dims[l+1], dims[l]] and ``norms.{l}`` ("layer": LayerNorm weight / bias,
+        "batch": eval-mode BatchNorm1d weight / bias + running mean / variance).  The ``res.{l}`` parameters follow all
+        ``convs.*`` in every per-parameter result."""
         L = len(weights)
         if L != len(biases) or L == 0:
             raise ValueError("need one bias per weight")
@@ -150,7 +156,45 @@ class GraphEngine:
         self._bind_opts = (act, likelihood)
         self.dims = dims
         self.in_dims = [mult * d for d in dims[:-1]]
+        if norm in ("none", ""):
+            norm = None
+        if norm not in NORMS:
+            raise ValueError(f"Unknown normalization type: {norm}")
+        self._extras = dict(res_weights=res_weights, res_biases=res_biases, norm=norm, norm_weight=norm_weight,
+                            norm_bias=norm_bias, norm_mean=norm_mean, norm_var=norm_var, norm_eps=norm_eps)
+        self.has_res = bool(res_weights) and L > 1
+        self.norm = norm if L > 1 else None
+        if self.has_res or self.norm is not None:
+            def ptrs(ts, what, shape_of):
+                if ts is None:
+                    return None
+                if len(ts) != L - 1:
+                    raise ValueError(f"need one {what} per hidden layer")
+                for l, t in enumerate(ts):
+                    if tuple(t.shape) != shape_of(l):
+                        raise ValueError(f"{what}[{l}] has shape {tuple(t.shape)}, expected {shape_of(l)}")
+                return _lib.ptr_array([_dev_ptr(t, torch.float32, what).value for t in ts])
+            hid = lambda l: (dims[l + 1],)  # noqa: E731
+            if self.has_res and (res_biases is None or len(res_biases) != L - 1):
+                raise ValueError("need one res bias per res weight")
+            if self.norm is not None and (norm_weight is None or norm_bias is None):
+                raise ValueError("norm weight / bias missing")
+            if self.norm == "batch" and (norm_mean is None or norm_var is None):
+                raise ValueError("BatchNorm needs its running statistics")
+            rc = self.lib.lgnn_bind_extras(
+                self._h, ptrs(res_weights if self.has_res else None, "res weight", lambda l: (dims[l + 1], dims[l])),
+                ptrs(res_biases if self.has_res else None, "res bias", hid), NORMS[self.norm],
+                ptrs(norm_weight if self.norm else None, "norm weight", hid), ptrs(norm_bias if self.norm else None, "norm bias", hid),
+                ptrs(norm_mean if self.norm == "batch" else None, "norm running mean", hid),
+                ptrs(norm_var if self.norm == "batch" else None, "norm running var", hid), float(norm_eps))
+            _lib.check(rc, "lgnn_bind_extras")
+        # KFAC blocks in parameter order: (in, out) of convs.{0..L-1}.lin, then of res.{0..L-2}
+        self.block_dims = list(zip(self.in_dims, dims[1:])) + ([(dims[l], dims[l + 1]) for l in range(L - 1)] if self.has_res else [])
         self._versions = self._param_versions()
+
+    @property
+    def has_extras(self) -> bool:
+        return self.has_res or self.norm is not None
 
     def set_likelihood(self, likelihood: str):
         """Switch the bound model between the classification and the regression likelihood (re-binds the same tensors)."""
@@ -158,7 +202,7 @@ class GraphEngine:
             raise _lib.HipLibraryError("no model bound")
         if self._bind_opts[1] != likelihood:
             X, ws, bs = self._bound
-            self.bind(X, ws, bs, self._bind_opts[0], likelihood)
+            self.bind(X, ws, bs, self._bind_opts[0], likelihood, **self._extras)
 
     @property
     def likelihood(self) -> str:
@@ -177,7 +221,9 @@ class GraphEngine:
 
     def _param_versions(self):
         _, ws, bs = self._bound
-        return [(t.data_ptr(), t._version) for t in (*ws, *bs)]
+        extra = [t for k in ("res_weights", "res_biases", "norm_weight", "norm_bias", "norm_mean", "norm_var")
+                 for t in (self._extras.get(k) or [])]
+        return [(t.data_ptr(), t._version) for t in (*ws, *bs, *extra)]
 
     def invalidate(self):
         _lib.check(self.lib.lgnn_invalidate(self._h), "lgnn_invalidate")
@@ -191,7 +237,7 @@ class GraphEngine:
             if [p for p, _ in v] != [p for p, _ in self._versions]:
                 # storage replaced (``param.data = ...``, e.g. torch.nn.utils.vector_to_parameters): bind the new pointers
                 X, ws, bs = self._bound
-                self.bind(X, ws, bs, *self._bind_opts)
+                self.bind(X, ws, bs, *self._bind_opts, **self._extras)
             self.invalidate()
             self._versions = v
 
@@ -201,7 +247,7 @@ class GraphEngine:
 
     @property
     def n_params(self):
-        return sum(i * o + o for i, o in zip(self.in_dims, self.dims[1:]))
+        return sum(i * o + o for i, o in self.block_dims)
 
     def device_bytes(self) -> int:
         return int(self.lib.lgnn_device_bytes(self._h))
@@ -235,11 +281,11 @@ class GraphEngine:
         """Zeroed caller-owned accumulators, as ONE flat fp32 buffer [A_0|B_0|...|A_{L-1}|B_{L-1}|loss]
         (one all-reduce suffices) plus per-factor views."""
         sizes = []
-        for i, o in zip(self.in_dims, self.dims[1:]):
+        for i, o in self.block_dims:
             sizes += [i * i, o * o]
         flat = torch.zeros(sum(sizes) + 1, dtype=torch.float32, device=self.device)
         views, off = [], 0
-        for l, (i, o) in enumerate(zip(self.in_dims, self.dims[1:])):
+        for l, (i, o) in enumerate(self.block_dims):
             A = flat[off:off + i * i].view(i, i); off += i * i
             B = flat[off:off + o * o].view(o, o); off += o * o
             views.append((A, B))

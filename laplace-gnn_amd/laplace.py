@@ -278,6 +278,7 @@ class ParametricLaplace(BaseLaplace):
         with a ReLU, hidden width <= 256, classification, Kronecker or diagonal posterior over all weights."""
         eng = getattr(self.backend, "engine", None)
         if (eng is None or not hasattr(eng, "glm_variance") or getattr(eng, "kind", None) not in ("gcn", "sage") or len(eng.dims) != 3
+                or getattr(eng, "has_extras", False)
                 or eng.dims[1] > 256 or getattr(eng, "_bind_opts", ("relu",))[0] != "relu" or self.likelihood != "classification"):
             return None
         ops = self._matrix_free_operands()

@@ -4,8 +4,9 @@ parameter names (``convs.{i}.lin.weight|bias``) and ``forward(x_indices) -> [M, 
 sparse adjacency held by the HIP engine instead of a dense N x N ``nn.Parameter``.
 
 Inference (eval mode) runs on the GPU through the C ABI; training the weights is outside the
-accelerated path.  Unsupported reference options raise immediately:
-``norm`` other than None, ``res=True``, neighbour sampling (``num_sampled_nodes_per_hop``).
+accelerated path.  ``res=True`` (``res.{i}`` Linears, base_gnn.py:97-113) and
+``norm="layer"|"batch"`` (``norms.{i}``, base_gnn.py:86-95) are part of the HIP forward / backward (csrc/resnorm.hip).
+Unsupported reference options raise immediately: neighbour sampling (``num_sampled_nodes_per_hop``).
 """
 from __future__ import annotations
 
@@ -50,10 +51,8 @@ class BaseGNN(nn.Module):
                  act_kwargs=None, update_adj: bool = False, norm: Optional[str] = None, res: bool = False,
                  symmetric: bool = False, **kwargs):
         super().__init__()
-        if norm not in (None, "none"):
-            raise NotImplementedError("norm layers are not supported on the HIP path")
-        if res:
-            raise NotImplementedError("residual connections are not supported on the HIP path")
+        if norm not in (None, "none", "layer", "batch"):
+            raise ValueError(f"Unknown normalization type: {norm}")  # base_gnn.py:94-95
         if update_adj:
             raise NotImplementedError("adjacency learning (STE variants) is out of scope")
         if act not in ("relu", "tanh"):
@@ -71,7 +70,19 @@ class BaseGNN(nn.Module):
         self.register_buffer("edge_index", _to_edge_index(init_adj).to(torch.int64), persistent=False)
         self.num_nodes = X.shape[0]
         dims = [in_channels] + [hidden_channels] * (num_layers - 1) + [out_channels]
+        # registration order as in the reference (base_gnn.py:94-98: norms, convs, res) -- it is the order of
+        # named_parameters(), hence of the Laplace parameter vector: convs.* first, then res.* (norms.* are filtered out)
+        self.norm_kind = None if norm in (None, "none") else norm
+        if self.norm_kind == "layer":
+            make_norm = lambda: nn.LayerNorm(hidden_channels)  # noqa: E731
+        elif self.norm_kind == "batch":
+            make_norm = lambda: nn.BatchNorm1d(hidden_channels)  # noqa: E731
+        else:
+            make_norm = nn.Identity
+        self.norms = nn.ModuleList(make_norm() for _ in range(num_layers - 1))
         self.convs = nn.ModuleList(_Conv(dims[i], dims[i + 1], self._mult) for i in range(num_layers))
+        # x = res[i](x) + convs[i](adj, x) for every hidden layer (base_gnn.py:100-113, 141-144)
+        self.res = nn.ModuleList(nn.Linear(dims[i], hidden_channels) for i in range(num_layers - 1)) if res else nn.ModuleList()
         self._engine: GraphEngine | None = None
 
     def reset_parameters(self):
@@ -94,9 +105,22 @@ class BaseGNN(nn.Module):
                                    "(there is no CPU fallback)")
             eng = GraphEngine(self.edge_index.to(dev), self.num_nodes, kind=self.kind, symmetric=self.symmetric)
             eng.bind(self.X.to(dev).contiguous(), [c.lin.weight for c in self.convs],
-                     [c.lin.bias for c in self.convs], act=self.act_name)
+                     [c.lin.bias for c in self.convs], act=self.act_name, **self._extras())
             self._engine = eng
         return self._engine
+
+    def _extras(self) -> dict:
+        """``res`` / ``norm`` state for ``GraphEngine.bind`` (borrowed tensors; BatchNorm runs on its running statistics:
+        Laplace.fit calls model.eval(), laplace/baselaplace.py:805)."""
+        kw = {}
+        if len(self.res):
+            kw["res_weights"], kw["res_biases"] = [m.weight for m in self.res], [m.bias for m in self.res]
+        if self.norm_kind is not None and len(self.norms):
+            kw.update(norm=self.norm_kind, norm_eps=float(self.norms[0].eps), norm_weight=[m.weight for m in self.norms],
+                      norm_bias=[m.bias for m in self.norms])
+            if self.norm_kind == "batch":
+                kw.update(norm_mean=[m.running_mean for m in self.norms], norm_var=[m.running_var for m in self.norms])
+        return kw
 
     def full_adj(self) -> torch.Tensor:
         """Dense 0/1 adjacency as the reference's ``model.adj`` holds it (small graphs only)."""
@@ -111,7 +135,7 @@ class BaseGNN(nn.Module):
         return torch.sparse_coo_tensor(torch.stack([r, c]), v, (self.num_nodes, self.num_nodes))
 
     def forward(self, x_indices: torch.Tensor) -> torch.Tensor:
-        if self.training and self.dropout.p > 0:
+        if self.training and (self.dropout.p > 0 or self.norm_kind == "batch"):
             raise NotImplementedError("only eval-mode forward runs on the HIP path (Laplace.fit calls model.eval())")
         return self.engine.forward(x_indices.to(self.convs[0].lin.weight.device))
 

@@ -9,6 +9,22 @@ import gnn_laplace_oracle as O
 from laplace_gnn_amd.matrix import Kron
 
 
+def oracle_model_of(m):
+    """The oracle's plain-array mirror of a laplace_gnn_amd model on the CPU, res / norm state included."""
+    rp, col = O.edge_index_to_adj_csr(m.edge_index.numpy(), m.num_nodes, m.kind, m.symmetric)
+    Ws = [c.lin.weight.detach().numpy() for c in m.convs]
+    bs = [c.lin.bias.detach().numpy() for c in m.convs]
+    kw = {}
+    if len(getattr(m, "res", [])):
+        kw.update(res_weights=[r.weight.detach().numpy() for r in m.res], res_biases=[r.bias.detach().numpy() for r in m.res])
+    if getattr(m, "norm_kind", None) is not None:
+        kw.update(norm=m.norm_kind, norm_eps=float(m.norms[0].eps), norm_weight=[n.weight.detach().numpy() for n in m.norms],
+                  norm_bias=[n.bias.detach().numpy() for n in m.norms])
+        if m.norm_kind == "batch":
+            kw.update(norm_mean=[n.running_mean.numpy() for n in m.norms], norm_var=[n.running_var.numpy() for n in m.norms])
+    return O.GnnModel(m.kind, rp, col, m.X.numpy(), Ws, bs, **kw)
+
+
 class CpuForwardGCN(torch.nn.Module):
     """Wraps a laplace_gnn_amd model so that forward() also runs through the oracle on the CPU."""
 
@@ -27,11 +43,7 @@ class CpuForwardGCN(torch.nn.Module):
         return self._oracle_engine
 
     def oracle_model(self):
-        m = self.inner
-        rp, col = O.edge_index_to_adj_csr(m.edge_index.numpy(), m.num_nodes, m.kind, m.symmetric)
-        Ws = [c.lin.weight.detach().numpy() for c in m.convs]
-        bs = [c.lin.bias.detach().numpy() for c in m.convs]
-        return O.GnnModel(m.kind, rp, col, m.X.numpy(), Ws, bs)
+        return oracle_model_of(self.inner)
 
     def forward(self, x_indices):
         out, _, _ = O.forward_all(self.oracle_model())
@@ -46,7 +58,7 @@ class OracleBackend:
         if likelihood == "regression":
             from torch.nn import MSELoss
             self.lossfunc, self.factor = MSELoss(reduction="sum"), 0.5
-        self.params = [p for k, p in model.named_parameters() if p.requires_grad and "adj" not in k]
+        self.params = [p for k, p in model.named_parameters() if p.requires_grad and "adj" not in k and "norms" not in k]
         self.params_dict = dict(model.named_parameters())
         self.buffers_dict = dict(model.named_buffers())
         self.calls = []
@@ -83,8 +95,8 @@ class OracleClassBackend(OracleBackend):
 
     def new_kfac_buffers(self):
         views = []
-        for conv in self.model.convs:
-            o, i = conv.lin.weight.shape
+        for lin in [c.lin for c in self.model.convs] + list(getattr(self.model.inner, "res", [])):
+            o, i = lin.weight.shape
             views.append((torch.zeros(i, i), torch.zeros(o, o)))
         return None, views, torch.zeros(1)
 

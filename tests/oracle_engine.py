@@ -21,12 +21,21 @@ class OracleEngine:
         mult = 2 if self.kind == "sage" else 1
         self.dims = [model.convs[0].lin.weight.shape[1] // mult] + [c.lin.weight.shape[0] for c in model.convs]
         self.in_dims = [mult * d for d in self.dims[:-1]]
+        L = len(self.dims) - 1
+        self.has_res = len(getattr(model, "res", [])) > 0
+        self.norm = getattr(model, "norm_kind", None)
+        self.block_dims = list(zip(self.in_dims, self.dims[1:])) + (
+            [(self.dims[l], self.dims[l + 1]) for l in range(L - 1)] if self.has_res else [])
         self.likelihood = "classification"
         self.calls = []
 
     @property
+    def has_extras(self):
+        return self.has_res or self.norm is not None
+
+    @property
     def n_params(self):
-        return sum(i * o + o for i, o in zip(self.in_dims, self.dims[1:]))
+        return sum(i * o + o for i, o in self.block_dims)
 
     @property
     def num_layers(self):
@@ -36,10 +45,8 @@ class OracleEngine:
         self.likelihood = likelihood
 
     def _om(self):
-        m = self.m
-        rp, col = O.edge_index_to_adj_csr(m.edge_index.numpy(), m.num_nodes, m.kind, m.symmetric)
-        return O.GnnModel(m.kind, rp, col, m.X.numpy(), [c.lin.weight.detach().numpy() for c in m.convs],
-                          [c.lin.bias.detach().numpy() for c in m.convs])
+        from oracle_backend import oracle_model_of
+        return oracle_model_of(self.m)
 
     def forward(self, idx):
         out, _, _ = O.forward_all(self._om())
@@ -47,11 +54,11 @@ class OracleEngine:
 
     def new_kfac_buffers(self):
         sizes = []
-        for i, o in zip(self.in_dims, self.dims[1:]):
+        for i, o in self.block_dims:
             sizes += [i * i, o * o]
         flat = torch.zeros(sum(sizes) + 1)
         views, off = [], 0
-        for i, o in zip(self.in_dims, self.dims[1:]):
+        for i, o in self.block_dims:
             A = flat[off:off + i * i].view(i, i); off += i * i
             B = flat[off:off + o * o].view(o, o); off += o * o
             views.append((A, B))

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN
+from golden_utils import constructor_extras
 from gpu_utils import rel
 
 pytestmark = pytest.mark.gpu
@@ -26,11 +27,21 @@ def model_from_golden(g, device="cuda"):
     F, C = X.shape[1], g[f"W{L - 1}"].shape[0]
     Hd = g["W0"].shape[0]
     cls = lg.GCN if kind == "gcn" else lg.GraphSAGE
-    model = cls(F, Hd, C, L, X, ei, symmetric=bool(g["symmetric"]))
+    model = cls(F, Hd, C, L, X, ei, symmetric=bool(g["symmetric"]), **constructor_extras(g))
     with torch.no_grad():
         for l, conv in enumerate(model.convs):
             conv.lin.weight.copy_(torch.from_numpy(g[f"W{l}"]))
             conv.lin.bias.copy_(torch.from_numpy(g[f"b{l}"]))
+        for l, lin in enumerate(model.res):  # res=True fixtures (gnn/models/base_gnn.py:100-113)
+            lin.weight.copy_(torch.from_numpy(g[f"Wr{l}"]))
+            lin.bias.copy_(torch.from_numpy(g[f"br{l}"]))
+        if model.norm_kind is not None:  # norm fixtures: LayerNorm / eval-mode BatchNorm1d state
+            for l, nm in enumerate(model.norms):
+                nm.weight.copy_(torch.from_numpy(g[f"norm_w{l}"]))
+                nm.bias.copy_(torch.from_numpy(g[f"norm_b{l}"]))
+                if model.norm_kind == "batch":
+                    nm.running_mean.copy_(torch.from_numpy(g[f"norm_rm{l}"]))
+                    nm.running_var.copy_(torch.from_numpy(g[f"norm_rv{l}"]))
     model.eval()
     return model.to(device) if device else model
 
@@ -41,8 +52,11 @@ def test_kron_laplace_fit(path):
 
     g = np.load(path)
     model = model_from_golden(g)
-    assert [k for k, _ in model.named_parameters()] == [
-        f"convs.{l}.lin.{w}" for l in range(int(g["num_layers"])) for w in ("weight", "bias")]
+    names = [k for k, _ in model.named_parameters() if "norms" not in k]  # the fork's filter, laplace/curvature/curvature.py:74-79
+    assert names == [f"convs.{l}.lin.{w}" for l in range(int(g["num_layers"])) for w in ("weight", "bias")] + [
+        f"res.{l}.{w}" for l in range(len(model.res)) for w in ("weight", "bias")]
+    if "param_names" in g.files:  # res / norm fixtures record the reference's own parameter order
+        assert names == [str(k) for k in g["param_names"]]
     loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(),
                                   batch_size=int(g["batch_size"]))
     la = lg.Laplace(model, "classification", subset_of_weights="all", hessian_structure="kron")

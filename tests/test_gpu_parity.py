@@ -11,6 +11,7 @@ import torch
 
 import gnn_laplace_oracle as O
 from conftest import GOLDEN
+from golden_utils import conv_offset
 from gpu_utils import engine_from_golden, kfac_fit_engine, oracle_from_arrays, rel
 
 pytestmark = pytest.mark.gpu
@@ -105,6 +106,7 @@ def test_lastlayer_full_matches_reference_block(path):
     loss = torch.zeros(1, device="cuda")
     eng.lastlayer_full_accumulate(idx, y, H, loss)
     torch.cuda.synchronize()
-    assert rel(H.cpu().numpy(), g["full_H"][-p_ll:, -p_ll:]) < RTOL
+    o = conv_offset(g, L - 1)  # the last conv's block (res.* parameters, where present, come after it)
+    assert rel(H.cpu().numpy(), g["full_H"][o:o + p_ll, o:o + p_ll]) < RTOL
     assert abs(float(loss.item()) - float(g["full_loss"])) <= RTOL * abs(float(g["full_loss"]))
     eng.close()

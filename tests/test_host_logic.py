@@ -242,15 +242,29 @@ def _cpu_model(g):
     kind, L = str(g["kind"]), int(g["num_layers"])
     X, ei = torch.from_numpy(g["X"]), torch.from_numpy(g["edge_index"])
     cls = lg.GCN if kind == "gcn" else lg.GraphSAGE
-    m = cls(X.shape[1], g["W0"].shape[0], g[f"W{L - 1}"].shape[0], L, X, ei, symmetric=bool(g["symmetric"]))
+    from golden_utils import constructor_extras
+    m = cls(X.shape[1], g["W0"].shape[0], g[f"W{L - 1}"].shape[0], L, X, ei, symmetric=bool(g["symmetric"]),
+            **constructor_extras(g))
     with torch.no_grad():
         for l, conv in enumerate(m.convs):
             conv.lin.weight.copy_(torch.from_numpy(g[f"W{l}"]))
             conv.lin.bias.copy_(torch.from_numpy(g[f"b{l}"]))
+        for l, lin in enumerate(m.res):
+            lin.weight.copy_(torch.from_numpy(g[f"Wr{l}"]))
+            lin.bias.copy_(torch.from_numpy(g[f"br{l}"]))
+        if m.norm_kind is not None:
+            for l, nm in enumerate(m.norms):
+                nm.weight.copy_(torch.from_numpy(g[f"norm_w{l}"]))
+                nm.bias.copy_(torch.from_numpy(g[f"norm_b{l}"]))
+                if m.norm_kind == "batch":
+                    nm.running_mean.copy_(torch.from_numpy(g[f"norm_rm{l}"]))
+                    nm.running_var.copy_(torch.from_numpy(g[f"norm_rv{l}"]))
     return CpuForwardGCN(m.eval())
 
 
-@pytest.mark.parametrize("name", ["gcn_small_3batch_s1", "sage_small_3batch_s1", "gcn_small_isolated_s0"])
+@pytest.mark.parametrize("name", ["gcn_small_3batch_s1", "sage_small_3batch_s1", "gcn_small_isolated_s0",
+                                  "gcn_resln_small_3batch_s1", "sage_resln_small_3batch_s1", "gcn_bn_small_3batch_s3",
+                                  "gcn3_resln_small_3batch_s5"])
 def test_fit_loop_with_oracle_backend_matches_reference(name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     model = _cpu_model(g)
@@ -527,8 +541,19 @@ def test_model_constructor_validation():
     assert [tuple(p.shape) for p in s.parameters()] == [(5, 8), (5,), (3, 10), (3,)]
     with pytest.raises(AssertionError):
         lg.GCN(4, 5, 3, 2, X, adj * 2)
-    for kw in (dict(norm="layer"), dict(res=True), dict(act="gelu"), dict(update_adj=True)):
+    for kw in (dict(act="gelu"), dict(update_adj=True)):
         with pytest.raises(NotImplementedError):
             lg.GCN(4, 5, 3, 2, X, adj, **kw)
+    with pytest.raises(ValueError):
+        lg.GCN(4, 5, 3, 2, X, adj, norm="group")  # gnn/models/base_gnn.py:94-95
+    # res / norm: the reference's module layout and parameter order (base_gnn.py:86-113; convs.* before res.*)
+    r = lg.GraphSAGE(4, 5, 3, 3, X, adj, None, norm="layer", res=True)
+    assert [k for k, _ in r.named_parameters()] == [
+        "norms.0.weight", "norms.0.bias", "norms.1.weight", "norms.1.bias",
+        "convs.0.lin.weight", "convs.0.lin.bias", "convs.1.lin.weight", "convs.1.lin.bias", "convs.2.lin.weight",
+        "convs.2.lin.bias", "res.0.weight", "res.0.bias", "res.1.weight", "res.1.bias"]
+    assert [tuple(p.shape) for p in r.res.parameters()] == [(5, 4), (5,), (5, 5), (5,)]
+    b = lg.GCN(4, 5, 3, 2, X, adj, norm="batch")
+    assert isinstance(b.norms[0], torch.nn.BatchNorm1d) and len(b.res) == 0
     with pytest.raises(NotImplementedError):
         lg.GraphSAGE(4, 5, 3, 2, X, adj, 5)

@@ -42,7 +42,8 @@ def _loader(g, y_key="train_y"):
 
 
 @pytest.mark.parametrize("name", ["gcn_small_3batch_s1", "sage_small_3batch_s1", "gcn_small_isolated_s0",
-                                  "gcn3_small_3batch_sym_s1", "sage3_small_3batch_s1"])
+                                  "gcn3_small_3batch_sym_s1", "sage3_small_3batch_s1",
+                                  "gcn_resln_small_3batch_s1", "sage_resln_small_3batch_s1", "sage_resbn_small_1batch_s4"])
 def test_reference_kron_and_diag_laplace_run_on_the_hip_backend_class(ref, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     model = _cpu_model(g)
