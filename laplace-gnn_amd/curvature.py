@@ -91,6 +91,10 @@ class HipCurvatureInterface:
                             "GraphSAGE); there is no generic autograd fallback")
         if likelihood == "regression" and last_layer:
             raise NotImplementedError("last-layer full GGN: classification likelihood only")
+        if stochastic and last_layer:
+            # the reference applies the MC functional Fisher to last_layer_jacobians here (laplace/curvature/curvature.py:
+            # 343-364, 374-432); the last-layer kernels build the exact GGN only -- refuse rather than ignore the flag
+            raise NotImplementedError("stochastic=True together with last_layer=True is not implemented")
 
     @property
     def _model(self) -> nn.Module:

@@ -48,6 +48,20 @@ def kfac_plan(kind: str, dims: Sequence[int], num_nodes: int, nnz: int, act: str
             "backgemm": [bool(out[4 + l] & 2) for l in range(L)]}
 
 
+class _IdentityKey:
+    """Hashable wrapper comparing by object identity (tensors define elementwise ``==``)."""
+    __slots__ = ("obj",)
+
+    def __init__(self, obj):
+        self.obj = obj
+
+    def __hash__(self):
+        return id(self.obj)
+
+    def __eq__(self, other):
+        return isinstance(other, _IdentityKey) and other.obj is self.obj
+
+
 class GraphEngine:
     """Graph ingest + model binding + per-batch curvature accumulation on one GPU."""
 
@@ -219,11 +233,18 @@ class GraphEngine:
         y = y.contiguous()
         return _dev_ptr(y, torch.int64, "y")
 
+    def feature_token(self):
+        """Exact identity of the bound feature tensor for callers that cache what depends on X only: the tensor object itself
+        (holding it keeps its storage from being recycled under the token) and its version counter."""
+        X = self._bound[0]
+        return (_IdentityKey(X), X._version, tuple(X.shape))
+
     def _param_versions(self):
         _, ws, bs = self._bound
         extra = [t for k in ("res_weights", "res_biases", "norm_weight", "norm_bias", "norm_mean", "norm_var")
                  for t in (self._extras.get(k) or [])]
-        return [(t.data_ptr(), t._version) for t in (*ws, *bs, *extra)]
+        X = self._bound[0]
+        return [(X.data_ptr(), X._version)] + [(t.data_ptr(), t._version) for t in (*ws, *bs, *extra)]
 
     def invalidate(self):
         _lib.check(self.lib.lgnn_invalidate(self._h), "lgnn_invalidate")
@@ -234,8 +255,10 @@ class GraphEngine:
             raise _lib.HipLibraryError("no model bound")
         v = self._param_versions()
         if v != self._versions:
-            if [p for p, _ in v] != [p for p, _ in self._versions]:
-                # storage replaced (``param.data = ...``, e.g. torch.nn.utils.vector_to_parameters): bind the new pointers
+            if [p for p, _ in v] != [p for p, _ in self._versions] or v[0] != self._versions[0]:
+                # storage replaced (``param.data = ...``, e.g. torch.nn.utils.vector_to_parameters): bind the new pointers.
+                # The feature tensor changed in place: lgnn_invalidate keeps what depends on X only (padded copy, P X,
+                # X^T X), a re-bind drops it
                 X, ws, bs = self._bound
                 self.bind(X, ws, bs, *self._bind_opts, **self._extras)
             self.invalidate()

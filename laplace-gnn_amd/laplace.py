@@ -178,7 +178,12 @@ class ParametricLaplace(BaseLaplace):
         if hasattr(self.backend, "check_async_errors"):
             self.backend.check_async_errors()
         if world > 1:
+            phase = getattr(self, "_on_phase", None)  # measurement hook (bench.py): brackets the factor all-reduce
+            if phase is not None:
+                phase("reduce_begin")
             all_reduce_flat_(self._reduce_tensors() + [loss], process_group)
+            if phase is not None:
+                phase("reduce_end")
             self._after_reduce()
         self._post_accumulate()  # e.g. the last-layer pair accumulators are placed into H here, once per fit
         if H_prev is not None:
@@ -456,9 +461,11 @@ class ParametricLaplace(BaseLaplace):
 class KronLaplace(ParametricLaplace):
     _key = ("all", "kron")
 
-    def __init__(self, model, likelihood, *args, damping: bool = False, **kwargs):
+    def __init__(self, model, likelihood, *args, damping: bool = False, cache_decompositions: bool = True, **kwargs):
         self.damping = damping
         self.H_facs = None
+        # reuse the eigendecomposition of a GCN's first input covariance across fits of the same model (``_decompose_cache``)
+        self.cache_decompositions = bool(cache_decompositions)
         super().__init__(model, likelihood, *args, **kwargs)
 
     def _init_H(self):
@@ -472,9 +479,9 @@ class KronLaplace(ParametricLaplace):
 
     def load_state_dict(self, state_dict: dict) -> None:
         super().load_state_dict(state_dict)
-        self._init_H()
-        self.H_facs = self.H
-        self.H_facs.kfacs = state_dict["H"]
+        # a fresh container WITHOUT the tied-factor hint: the loaded bias blocks need not repeat their weight block's B
+        # (regression: sqrt(.5) B vs .5 B), so decompose compares the tensors
+        self.H_facs = Kron(state_dict["H"])
         self.H = self.H_facs.decompose(damping=self.damping)
 
     def _inplace_backend(self) -> bool:
@@ -557,7 +564,24 @@ class KronLaplace(ParametricLaplace):
         else:
             self.H = self._rescale_factors(self.H, n_data_new / (n_data_new + n_data_old))
             self.H_facs += self.H
-        self.H = self.H_facs.decompose(damping=self.damping, process_group=process_group)
+        cache, keys = self._decompose_cache(train_loader, override)
+        self.H = self.H_facs.decompose(damping=self.damping, process_group=process_group, cache=cache, cache_keys=keys)
+
+    def _decompose_cache(self, train_loader, override: bool):
+        """A GCN's first input covariance is ``factor^(1/2) (T / N_train) X^T X``: a function of the feature tensor, the batch
+        count and N_train only -- not of the weights, not of the adjacency -- yet at the Cora shape (1 433 x 1 433) its
+        decomposition is 30 ms of a 2 ms fit, and the fork's structure-learning loop refits after every adjacency step
+        (gnn/marglik_training.py:197-216).  The eigenpairs are kept ON THE MODEL OBJECT under an exact key: the identity and
+        version counter of the feature tensor (a strong reference is held, so the storage cannot be recycled under the key),
+        T, N_train and the likelihood factor.  Nothing is compared numerically; ``cache_decompositions=False`` opts out."""
+        be = self._backend
+        eng = getattr(be, "engine", None) if be is not None else None
+        if (not self.cache_decompositions or not override or eng is None or getattr(eng, "kind", None) != "gcn"
+                or not hasattr(eng, "feature_token") or getattr(be, "_kron_fisher_type", "type2") != "type2"):
+            return None, None
+        store = self.model.__dict__.setdefault("_lgnn_eig_cache", {})
+        key = ("gcn_A0", eng.feature_token(), len(train_loader), len(train_loader.dataset), float(be.factor))
+        return store, {(0, 1): key}
 
     @property
     def posterior_precision(self) -> KronDecomposed:
@@ -615,7 +639,21 @@ class KronLaplace(ParametricLaplace):
         rank, world = _dist_info(process_group)
         cand, sym = None, bool(getattr(self.model, "symmetric", False))
         if candidates is not None:
-            ci, cj = candidates[0].to(eng.device), candidates[1].to(eng.device)
+            ci, cj = candidates[0].to(eng.device).to(torch.int64), candidates[1].to(eng.device).to(torch.int64)
+            # the device kernels index rows with these pairs: validate before the cast to int32 (one host round trip; this
+            # is not the per-batch path).  Stored pairs and the diagonal are not candidates: their gradient comes back with
+            # the stored entries (the diagonal's is 0 for a GCN, gnn/models/models.py:23).
+            Nn = eng.num_nodes
+            if ci.numel():
+                if bool(((ci < 0) | (ci >= Nn) | (cj < 0) | (cj >= Nn)).any()):
+                    raise ValueError(f"candidate pairs must index nodes in [0, {Nn})")
+                if bool((ci == cj).any()):
+                    raise ValueError("candidate pairs must not lie on the diagonal")
+                sr, sc = eng.export_adj()  # row-major sorted
+                skey, ckey = sr * Nn + sc, ci * Nn + cj
+                pos = torch.searchsorted(skey, ckey).clamp(max=max(skey.numel() - 1, 0))
+                if skey.numel() and bool((skey[pos] == ckey).any()):
+                    raise ValueError("candidate pairs must not be stored entries of the adjacency")
             if sym:  # (adj + adj^T) / 2 feeds the model: both orientations are needed
                 ci, cj = torch.cat([ci, cj]), torch.cat([cj, ci])
             # entry (i, j) of the adjacency is entry (a = j, b = i) of the GCN propagation matrix D A^T D and entry

@@ -18,21 +18,11 @@ from torch import nn
 # Cora-shaped GCN, 100 ms for GraphSAGE's 2 866 x 2 866 -- the whole fit otherwise costs 3 ms.  A GCN's first input covariance is
 # (batches / N_train) X^T X: it depends on neither the weights nor the adjacency, so in the fork's structure-learning loop
 # (gnn/marglik_training.py:197-216: fit, marglik, gradient step on the adjacency, repeat) every fit after the first asks for the
-# decomposition of the same matrix.  The last few large decompositions are kept and reused when the new factor equals the
-# cached one to fp32 rounding (max |dH| <= 1e-6 max |H|: the Gram kernel's atomics reorder sums between engines).
-_LARGE_EIG_CACHE: list = []  # [(H, lam, Q)], most recent last
+# decomposition of the same matrix.  A caller that KNOWS a factor's identity passes a cache (a dict it owns) and an exact key per
+# factor (``Kron.decompose(cache=..., cache_keys=...)``; KronLaplace keys a GCN's A_0 by the feature tensor's identity and
+# version, the batch count and N_train): no approximate matching, no comparison of matrix contents, no global state.
 _LARGE_EIG_KEEP = 4
 _SMALL_EIG = 256  # lgnn_symeig_batched's one-workgroup path
-
-
-def _cached_large_symeig(H: torch.Tensor):
-    for k, (Hc, lam, Q) in enumerate(_LARGE_EIG_CACHE):
-        if Hc.shape == H.shape and Hc.device == H.device:
-            scale = Hc.abs().max()
-            if bool((H - Hc).abs().max() <= 1e-6 * scale):
-                _LARGE_EIG_CACHE.append(_LARGE_EIG_CACHE.pop(k))
-                return lam.clone(), Q.clone()
-    return None
 
 
 def _symeig_group_hip(mats: list) -> list:
@@ -69,12 +59,14 @@ def _symeig_group_hip(mats: list) -> list:
     return out
 
 
-def symeig_batched_hip(mats: list) -> list:
+def symeig_batched_hip(mats: list, cache: dict | None = None, keys: list | None = None) -> list:
     """Eigendecompose several symmetric PSD factors on the GPU (``lgnn_symeig_batched``): per-factor ``torch.linalg.eigh`` is
     a serial chain of ~100 single-workgroup kernels (3.3 ms per 256 x 256 factor).  Factors of up to 256 rows go through ONE
     call (hand-written tridiagonalisation, all factors side by side: the four arxiv factors in 2 ms), larger ones one call
-    each (padding a 64 x 64 factor to 1 433 would cost a second large decomposition), reusing a cached result where the
-    same matrix was decomposed before.
+    each (padding a 64 x 64 factor to 1 433 would cost a second large decomposition).  ``cache`` / ``keys``: a dict owned by
+    the caller and one hashable key (or None) per factor -- a large factor whose key is in the cache is served from it, a
+    keyed one that is not gets stored (the ``_LARGE_EIG_KEEP`` most recent entries stay); factors without a key are always
+    decomposed.
 
     A factor H (n x n) smaller than the largest of its call (m x m) is embedded as blockdiag(H, -mean_eig(H) I): the blocks never couple (Householder reflectors and the divide and
     conquer splits keep exact zeros), D's eigenpairs sort first, H's are the last n rows restricted to the
@@ -88,12 +80,17 @@ def symeig_batched_hip(mats: list) -> list:
     for b, H in enumerate(mats):
         if out[b] is not None:
             continue
-        hit = _cached_large_symeig(H)
-        if hit is None:
-            hit = _symeig_group_hip([H])[0]
-            _LARGE_EIG_CACHE.append((H.detach().clone(), hit[0].clone(), hit[1].clone()))
-            del _LARGE_EIG_CACHE[:-_LARGE_EIG_KEEP]
-        out[b] = hit
+        key = keys[b] if (cache is not None and keys is not None) else None
+        if key is not None and key in cache:
+            lam, Q = cache.pop(key)
+            cache[key] = (lam, Q)  # most recently used last
+            out[b] = (lam.clone(), Q.clone())
+            continue
+        out[b] = _symeig_group_hip([H])[0]
+        if key is not None:
+            cache[key] = (out[b][0].clone(), out[b][1].clone())
+            while len(cache) > _LARGE_EIG_KEEP:
+                cache.pop(next(iter(cache)))
     return out
 
 
@@ -113,11 +110,21 @@ def symeig(M: torch.Tensor):
 
 class Kron:
     def __init__(self, kfacs: list, tied=None):
-        self.kfacs = kfacs
+        self._kfacs = kfacs
         # blocks i whose first factor is KNOWN to equal block i-1's (a bias block repeats the B factor of its weight block,
         # curvlinops.py:64-66): ``decompose`` then skips comparing the tensors, which would synchronise the stream while
-        # the accumulation is still queued.  A hint only: blocks not listed are compared.
+        # the accumulation is still queued.  A hint only: blocks not listed are compared.  The hint describes the factors it
+        # was given with: assigning ``kfacs`` (load_state_dict, callers that rebuild the list) drops it.
         self._tied = frozenset(tied or ())
+
+    @property
+    def kfacs(self) -> list:
+        return self._kfacs
+
+    @kfacs.setter
+    def kfacs(self, value: list):
+        self._kfacs = value
+        self._tied = frozenset()
 
     @classmethod
     def init_from_model(cls, model: nn.Module | Iterable[nn.Parameter], device) -> "Kron":
@@ -157,7 +164,8 @@ class Kron:
     def __len__(self):
         return len(self.kfacs)
 
-    def decompose(self, damping: bool = False, process_group=None) -> "KronDecomposed":
+    def decompose(self, damping: bool = False, process_group=None, cache: dict | None = None,
+                  cache_keys: dict | None = None) -> "KronDecomposed":
         """Eigendecompose every factor (laplace/utils/matrix.py:118-145).  Inside a ``torch.distributed``
         job the distinct factors are dealt to the ranks (largest first), each rank decomposes its share and
         ONE all-reduce of a zero-padded flat buffer hands every rank all eigenpairs: the replicated
@@ -173,7 +181,13 @@ class Kron:
         # distinct factors (a bias block repeats the B factor of its weight block, curvlinops.py:64-66: decompose once)
         distinct, where = self._distinct_factors()
         if distinct[0].is_cuda:
-            pairs = symeig_batched_hip(distinct)  # HIP path: one batched solver call, no CPU fallback
+            # cache_keys {(block, factor): key}: exact identities of factors the caller knows (see symeig_batched_hip)
+            keys = None
+            if cache is not None and cache_keys:
+                keys = [None] * len(distinct)
+                for (i, k), key in cache_keys.items():
+                    keys[where[i][k]] = key
+            pairs = symeig_batched_hip(distinct, cache, keys)  # HIP path: one batched solver call, no CPU fallback
         else:
             pairs = [symeig(Hi) for Hi in distinct]
         eigvecs = [[pairs[j][1] for j in idxs] for idxs in where]

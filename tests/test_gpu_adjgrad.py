@@ -101,3 +101,35 @@ def test_adjacency_gradient_is_refused_outside_the_first_slice():
     la.fit(loader)
     with pytest.raises(lg._lib.HipLibraryError, match="2-layer models"):
         la.neg_marglik_adj_grad(loader)
+
+
+def test_candidate_pairs_are_validated_before_they_reach_the_device():
+    """candidate pairs index rows in the device kernels; out-of-range ids, diagonal pairs and pairs that are
+    stored entries must be refused on the host."""
+    import laplace_gnn_amd as lg
+
+    g = torch.Generator().manual_seed(0)
+    N, F, H, C = 120, 10, 8, 3
+    X = torch.randn(N, F, generator=g)
+    ei = torch.randint(0, N, (2, 400), generator=g)
+    torch.manual_seed(0)
+    model = lg.GCN(F, H, C, 2, X, ei).cuda().eval()
+    idx = torch.randperm(N, generator=g)[:40].cuda()
+    y = torch.randint(0, C, (40,), generator=g).cuda()
+    loader = lg.TensorBatchLoader(idx, y, batch_size=40)
+    la = lg.KronLaplace(model, "classification")
+    la.fit(loader)
+    rows, cols = model.engine.export_adj()
+    stored = torch.stack([rows[rows != cols][:1], cols[rows != cols][:1]])
+    for bad in (torch.tensor([[0], [N]]), torch.tensor([[-1], [3]]), torch.tensor([[5], [5]]), stored.cpu(),
+                torch.tensor([[2 ** 33], [1]])):
+        with pytest.raises(ValueError, match="candidate"):
+            la.neg_marglik_adj_grad(loader, candidates=bad)
+    dense = torch.zeros(N, N, dtype=torch.bool)
+    dense[rows.cpu(), cols.cpu()] = True
+    ne = (~dense).nonzero()[:50].t().contiguous()
+    ne = ne[:, ne[0] != ne[1]]
+    out = la.neg_marglik_adj_grad(loader, candidates=ne)
+    assert len(out) == 4 and out[3].shape[0] == ne.shape[1] and torch.isfinite(out[3]).all()
+    model.engine.check_async_errors()
+

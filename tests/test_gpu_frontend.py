@@ -303,6 +303,30 @@ def test_two_ranks_share_one_gpu():
     assert out.returncode == 0 and "DIST_GPU_OK world=2" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
+@pytest.mark.parametrize("structure", ["kron", "diag"])
+def test_bench_two_rank_line_is_self_evidencing(structure):
+    """``bench.py --gpus 2`` rehearsed on this one GPU (gloo; RCCL refuses two ranks per device): the line must carry the
+    evidence a SCALE record needs -- backend name, the rank count an all-reduce of ones returns, the all-reduce's own device
+    time and the spread of the per-rank accumulate times."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LGNN_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "cora", "--structure", structure,
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    d = line["dist"]
+    assert d["dist_backend"] == "gloo" and d["ranks_seen"] == 2
+    assert d["allreduce_ms"] > 0 and 0 < d["accumulate_ms_min"] <= d["accumulate_ms_max"]
+    if structure == "kron":  # [A_0|B_0|A_1|B_1|loss] + the fit's loss scalar
+        assert d["allreduce_floats"] == 1433 ** 2 + 64 ** 2 + 64 ** 2 + 7 ** 2 + 2
+
+
 def test_batched_symeig_matches_float64_eigh():
     """lgnn_symeig_batched behind Kron.decompose: factors of different sizes go through one padded batched solver
     call; eigenvalues against float64 LAPACK, eigenvectors through gauge-free properties (orthonormal,
@@ -461,8 +485,8 @@ def test_matrix_free_glm_variance_matches_the_jacobian_route_and_the_reference(n
 
 def test_decomposition_groups_small_factors_and_caches_large_ones():
     """Kron.decompose on the GPU: factors of up to 256 rows share one call of the hand-written path, larger ones (a
-    Cora-shaped model's 1 433 x 1 433 input covariance) get a call of their own and are served from the cache the second
-    time; every eigenpair against fp64."""
+    Cora-shaped model's 1 433 x 1 433 input covariance) get a call of their own and are served from the CALLER's cache under
+    the caller's exact key the second time; every eigenpair against fp64."""
     from laplace_gnn_amd import matrix as mx
 
     g = torch.Generator().manual_seed(1)
@@ -472,10 +496,10 @@ def test_decomposition_groups_small_factors_and_caches_large_ones():
         if rank < n:
             G[:, rank:] = G[:, : n - rank] + G[:, 1: n - rank + 1]
         mats.append((G.T @ G / 700).float().cuda())
-    mx._LARGE_EIG_CACHE.clear()
-    first = mx.symeig_batched_hip(mats)
-    assert len(mx._LARGE_EIG_CACHE) == 2  # the 300 and the 257
-    second = mx.symeig_batched_hip(mats)
+    cache, keys = {}, [("k", b) if H.shape[0] > 256 else None for b, H in enumerate(mats)]
+    first = mx.symeig_batched_hip(mats, cache, keys)
+    assert len(cache) == 2  # the 300 and the 257, under the caller's exact keys
+    second = mx.symeig_batched_hip(mats, cache, keys)
     for H, (lam, Q), (lam2, Q2) in zip(mats, first, second):
         ref = torch.linalg.eigvalsh(H.double()).clamp(min=0)
         assert float((lam.double() - ref).abs().max()) <= 2e-6 * float(ref.max())
@@ -483,7 +507,9 @@ def test_decomposition_groups_small_factors_and_caches_large_ones():
         assert float((Q.T @ Q - torch.eye(H.shape[0], device="cuda")).abs().max()) < 1e-4
         if H.shape[0] > 256:
             assert torch.equal(lam, lam2) and torch.equal(Q, Q2)  # served from the cache
-    mx._LARGE_EIG_CACHE.clear()
+    # no key, no cache: an unkeyed call neither reads nor writes it
+    third = mx.symeig_batched_hip(mats, cache, [None] * len(mats))
+    assert len(cache) == 2 and float((third[0][0] - first[0][0]).abs().max()) <= 1e-5 * float(first[0][0].max())
     # more factors than side streams (8), sizes 1 and 2 included
     many = []
     for i, n in enumerate((1, 2, 3, 5, 17, 40, 64, 100, 128, 200, 255, 256)):
@@ -493,6 +519,51 @@ def test_decomposition_groups_small_factors_and_caches_large_ones():
         ref = torch.linalg.eigvalsh(H.double()).clamp(min=0)
         assert float((lam.double() - ref).abs().max()) <= 2e-6 * float(ref.max()), H.shape
         assert float(((Q * lam) @ Q.T - H).norm() / H.norm()) < 1e-5, H.shape
+
+
+def test_kron_laplace_reuses_a_gcn_first_input_covariance_decomposition_under_an_exact_key():
+    """F = 300 > 256: A_0 = (T / N) X^T X takes the library solver; a second fit of the same model (weights changed, same X)
+    is served from the cache kept on the model object; an in-place change of X, another batch count or
+    ``cache_decompositions=False`` are not."""
+    import laplace_gnn_amd as lg
+
+    g = torch.Generator().manual_seed(3)
+    N, F, H, C = 400, 300, 16, 4
+    X = torch.randn(N, F, generator=g)
+    ei = torch.randint(0, N, (2, 1500), generator=g)
+    torch.manual_seed(0)
+    model = lg.GCN(F, H, C, 2, X, ei, symmetric=True).cuda().eval()
+    idx = torch.randperm(N, generator=g)[:120].cuda()
+    y = torch.randint(0, C, (120,), generator=g).cuda()
+    loader = lg.TensorBatchLoader(idx, y, batch_size=50)
+    la = lg.KronLaplace(model, "classification")
+    la.fit(loader)
+    cache = model.__dict__["_lgnn_eig_cache"]
+    assert len(cache) == 1
+    lamA = la.H.eigenvalues[0][1].clone()
+    ref = torch.linalg.eigvalsh(la.H_facs.kfacs[0][1].double()).clamp(min=0)
+    assert float((lamA.double() - ref).abs().max()) <= 2e-6 * float(ref.max())
+    with torch.no_grad():
+        model.convs[0].lin.weight.mul_(1.1)  # the weights do not enter A_0
+    la2 = lg.KronLaplace(model, "classification")
+    la2.fit(loader)
+    assert len(cache) == 1 and torch.equal(la2.H.eigenvalues[0][1], lamA)  # the cached eigenpairs, bit for bit
+    assert not torch.equal(la2.H.eigenvalues[0][0], la.H.eigenvalues[0][0])  # B_0 did change
+    lg.KronLaplace(model, "classification").fit(lg.TensorBatchLoader(idx, y, batch_size=40))
+    assert len(cache) == 2  # another batch count: another matrix, another key
+    lg.KronLaplace(model, "classification", cache_decompositions=False).fit(loader)
+    assert len(cache) == 2
+    # an in-place change of the bound feature tensor is seen by the engine (ADVICE r2: the X-only caches used to survive)
+    before = model(idx).clone()
+    model.X.mul_(2.0)
+    after = model(idx)
+    assert float((after - before).abs().max()) > 1e-3
+    la3 = lg.KronLaplace(model, "classification")
+    la3.fit(loader)
+    assert len(cache) == 3
+    ref3 = torch.linalg.eigvalsh(la3.H_facs.kfacs[0][1].double()).clamp(min=0)
+    assert float((la3.H.eigenvalues[0][1].double() - ref3).abs().max()) <= 2e-6 * float(ref3.max())
+    assert float(ref3.max()) > 3.9 * float(ref.max())
 
 
 def test_rccl_backend_initialises_and_reduces_on_this_box():

@@ -530,3 +530,85 @@ def test_glm_predictive_on_every_node_of_the_arxiv_shape(arxiv):
     assert rel(f_vd.cpu().numpy(), ref.cpu().numpy()) < 1e-4 and rel(f_mu.cpu().numpy(), f.cpu().numpy()) < 1e-6
     print(f"GLM predictive of {w['N']} nodes: {dt * 1e3:.1f} ms")
     assert dt < 30.0
+
+
+# ---- independent reference of the dominant kernel's output at the headline shape -------------------
+def _fp64_kfac_classes(kind, eng, idx, y, classes, X, Ws, bs):
+    """fp64 torch restatement, on the GPU, of one batch's KFAC backward passes for the class columns ``classes`` at FULL size,
+    built from the engine's exported propagation matrix and the oracle's fork-exact seeds (curvlinops/kfac.py:637-661,
+    777-817; gnn/models/layers.py:26-29, 45-46): B_0, B_1 and the loss.  Nothing of the HIP curvature path is involved --
+    only ``export_propagation`` (bit exact vs the reference, tests/test_gpu_parity.py) and ``forward_all`` for the logits,
+    which is itself checked against this restatement's own fp64 forward."""
+    from test_gpu_baseline_shapes import _prop_csr, _torch_forward
+
+    N = X.shape[0]
+    P = _prop_csr(eng, N)
+    PT = P.t().to_sparse_csr()
+    Xd = X.cuda().double()
+    W0, W1 = Ws[0].double(), Ws[1].double()
+    logits64, _ = _torch_forward(kind, P, Xd, Ws, bs)
+    logits = eng.forward_all()
+    assert rel(logits.cpu().numpy(), logits64.cpu().numpy()) < 1e-5
+    # pre-activation sign of the hidden layer from the fp64 forward
+    if kind == "gcn":
+        pre = torch.sparse.mm(P, Xd @ W0.T + bs[0].double())
+    else:
+        pre = torch.cat([Xd, torch.sparse.mm(P, Xd)], dim=1) @ W0.T + bs[0].double()
+    mask = (pre > 0).double()
+    f = logits64[idx]
+    V = torch.from_numpy(O.kfac_seeds(f.float().cpu().numpy())).cuda().double()  # [M, k, c] from the oracle's closed form
+    C, H = W1.shape[0], W0.shape[0]
+    B0 = torch.zeros(H, H, dtype=torch.float64, device="cuda")
+    B1 = torch.zeros(C, C, dtype=torch.float64, device="cuda")
+    for c in classes:
+        G = torch.zeros(N, C, dtype=torch.float64, device="cuda")
+        G.index_add_(0, idx, V[:, :, c])
+        if kind == "gcn":
+            g1 = torch.sparse.mm(PT, G)
+            g0 = torch.sparse.mm(PT, (g1 @ W1) * mask)
+        else:
+            g1 = G
+            dcat = g1 @ W1
+            g0 = mask * (dcat[:, :H] + torch.sparse.mm(PT, dcat[:, H:]))
+        B1 += g1.T @ g1
+        B0 += g0.T @ g0
+    ce = torch.nn.functional.cross_entropy(f, y, reduction="sum")
+    return B0, B1, float(ce)
+
+
+@pytest.mark.parametrize("workload", ["arxiv", "arxiv_powerlaw", "arxiv_sage"])
+def test_headline_shape_B0_against_an_independent_fp64_restatement(workload):
+    """The 256-wide fused SpMM^T -> Gram kernel at N = 169 343 with one full batch of 10 000: ``lgnn_kfac_accumulate_classes``
+    for three class columns against fp64 torch sparse algebra (B_0 256 x 256, B_1 40 x 40, loss), uniform and power-law
+    graph, GCN and GraphSAGE.  fp32 <= 1e-4 relative Frobenius error (BASELINE.json north_star)."""
+    import bench
+    import laplace_gnn_amd as lg
+
+    w, ei, X, train_idx, train_y = bench.make_workload(workload, "cuda")
+    kind = w.get("kind", "gcn")
+    torch.manual_seed(0)
+    cls = lg.GraphSAGE if kind == "sage" else lg.GCN
+    model = cls(w["F"], w["H"], w["C"], 2, X, ei, symmetric=True).to("cuda").eval()
+    eng = model.engine
+    M = w["batch"]
+    idx, y = train_idx.cuda()[:M].clone(), train_y.cuda()[:M]
+    idx[-20:] = idx[:20]  # repeated node ids accumulate like x[x_indices]'s backward
+    Ws = [c.lin.weight.detach() for c in model.convs]
+    bs = [c.lin.bias.detach() for c in model.convs]
+    classes = (0, 17, 39)
+    B0, B1, ce = _fp64_kfac_classes(kind, eng, idx, y, classes, X, Ws, bs)
+    _, views, loss = eng.new_kfac_buffers()
+    for c in classes:
+        eng.kfac_accumulate(idx, y, w["n_train"], views, loss, classes=(c, c + 1))
+    torch.cuda.synchronize()
+    if kind == "sage":
+        # GraphSAGE: the whole top-layer Gram (M * C rows of the seeds) travels with the share that holds class 0
+        Vall = torch.from_numpy(O.kfac_seeds(eng.forward(idx).cpu().numpy())).cuda().double()
+        G = torch.zeros(w["N"], w["C"], w["C"], dtype=torch.float64, device="cuda")
+        G.index_add_(0, idx, Vall)  # [node, k, c]: duplicated ids accumulate
+        B1 = torch.einsum("nkc,nlc->kl", G, G)
+    assert rel(views[0][1].cpu().numpy(), B0.cpu().numpy()) < RTOL, "B_0"
+    assert rel(views[1][1].cpu().numpy(), B1.cpu().numpy()) < RTOL, "B_1"
+    assert abs(float(loss) - ce) < RTOL * ce
+    eng.check_async_errors()
+    eng.close()

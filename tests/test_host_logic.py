@@ -167,24 +167,54 @@ def test_kron_tied_hint_follows_the_arithmetic(monkeypatch):
     assert torch.allclose(kd.to_matrix(), plain.to_matrix(), atol=1e-5)
 
 
-def test_large_factor_decomposition_cache_hits_only_within_rounding():
-    """matrix._cached_large_symeig: the decomposition of a large factor (a GCN's X^T X: independent of weights and adjacency)
-    is reused when the new factor equals a cached one to fp32 rounding, never for a genuinely different matrix."""
+def test_decomposition_cache_is_keyed_exactly_and_owned_by_the_caller():
+    """The decomposition of a large factor is reused only under an EXACT key the caller supplies (KronLaplace: identity and
+    version of the feature tensor, batch count, N_train, likelihood factor) -- never by comparing matrix contents, never
+    from module-global state."""
+    from laplace_gnn_amd import engine as en
     from laplace_gnn_amd import matrix as mx
 
-    g = torch.Generator().manual_seed(0)
-    G = torch.randn(500, 300, generator=g)
-    H = G.T @ G / 500
-    lam, Q = mx.symeig(H)
-    saved = list(mx._LARGE_EIG_CACHE)
-    try:
-        mx._LARGE_EIG_CACHE[:] = [(H.clone(), lam, Q)]
-        hit = mx._cached_large_symeig(H + 1e-8 * torch.randn(300, 300, generator=g))
-        assert hit is not None and torch.equal(hit[0], lam) and hit[0] is not lam
-        assert mx._cached_large_symeig(H * 1.001) is None
-        assert mx._cached_large_symeig(H[:200, :200]) is None
-    finally:
-        mx._LARGE_EIG_CACHE[:] = saved
+    assert not hasattr(mx, "_LARGE_EIG_CACHE") and not hasattr(mx, "_cached_large_symeig")
+    X, Y = torch.zeros(3, 2), torch.zeros(3, 2)
+    k1, k2 = en._IdentityKey(X), en._IdentityKey(X)
+    assert k1 == k2 and hash(k1) == hash(k2) and k1 != en._IdentityKey(Y)  # identity, not (elementwise) equality
+    store = {("gcn_A0", (k1, X._version, (3, 2)), 3, 33, 1.0): "pair"}
+    assert ("gcn_A0", (k2, X._version, (3, 2)), 3, 33, 1.0) in store
+    X.add_(1.0)  # an in-place change bumps the version: the old key no longer matches
+    assert ("gcn_A0", (k2, X._version, (3, 2)), 3, 33, 1.0) not in store
+    # without an engine that can name its feature tensor (here: the CPU stand-in) nothing is cached
+    g = np.load(os.path.join(GOLDEN, "gcn_small_3batch_s1.npz"))
+    model = _cpu_model(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"]), int(g["batch_size"]))
+    la = lg.KronLaplace(model, "classification", backend=lg.HipGGN)
+    la.fit(loader)
+    assert la._decompose_cache(loader, True) == (None, None) and "_lgnn_eig_cache" not in model.__dict__
+    assert lg.KronLaplace(model, "classification", cache_decompositions=False).cache_decompositions is False
+
+
+def test_assigning_kfacs_drops_the_tied_hint_and_regression_state_round_trips(tmp_path):
+    """``load_state_dict`` used to keep init_from_model's 'zeros equal zeros' hint and reuse the weight
+    block's eigenpairs of B for the bias block; for a regression fit the two differ (sqrt(.5) B vs .5 B)."""
+    k = lg.Kron.init_from_model([torch.zeros(3, 2), torch.zeros(3)], "cpu")
+    assert k._tied == frozenset({1})
+    k.kfacs = [[torch.eye(3), torch.eye(2)], [2 * torch.eye(3)]]
+    assert k._tied == frozenset()
+    kd = k.decompose()
+    assert torch.allclose(kd.eigenvalues[1][0], torch.full((3,), 2.0))
+    g = np.load(os.path.join(GOLDEN, "gcn_small_1batch_s0.npz"))
+    model = _cpu_model(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["reg_y"]), int(g["batch_size"]))
+    la = lg.Laplace(model, "regression", "all", "kron", backend=OracleBackend, sigma_noise=0.7)
+    la.fit(loader)
+    path = tmp_path / "reg_kron.pt"
+    torch.save(la.state_dict(), path)
+    lb = lg.Laplace(model, "regression", "all", "kron", backend=OracleBackend, sigma_noise=0.7)
+    lb.load_state_dict(torch.load(path, weights_only=True))
+    assert abs(float(lb.log_marginal_likelihood()) - float(la.log_marginal_likelihood())) < 1e-5 * abs(float(la.log_marginal_likelihood()))
+    for la_l, lb_l in zip(la.H.eigenvalues, lb.H.eigenvalues):
+        for a, b in zip(la_l, lb_l):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    assert abs(float(la.log_marginal_likelihood()) - float(g["reg_kron_marglik"])) < 2e-4 * abs(float(g["reg_kron_marglik"]))
 
 
 # ---- loaders ------------------------------------------------------------------------------------------
@@ -517,6 +547,16 @@ def test_factory_keys_and_errors():
         lg.KronLaplace(model, "classification", sigma_noise=2.0)
     with pytest.raises(TypeError, match="engine"):
         lg.HipGGN(torch.nn.Linear(2, 2), "classification")
+
+
+def test_stochastic_last_layer_backend_is_refused_not_ignored():
+    """HipGGN(stochastic=True, last_layer=True) used to fall through to the deterministic last-layer GGN."""
+    g = np.load(os.path.join(GOLDEN, "sage_small_1batch_s0.npz"))
+    model = _cpu_model(g)
+    with pytest.raises(NotImplementedError, match="stochastic"):
+        lg.HipGGN(model, "classification", last_layer=True, stochastic=True)
+    lg.HipGGN(model, "classification", last_layer=True)
+    lg.HipGGN(model, "classification", stochastic=True)
 
 
 def test_lastlayer_full_front_with_oracle_backend():
