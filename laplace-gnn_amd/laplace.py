@@ -641,14 +641,13 @@ class KronLaplace(ParametricLaplace):
         if candidates is not None:
             ci, cj = candidates[0].to(eng.device).to(torch.int64), candidates[1].to(eng.device).to(torch.int64)
             # the device kernels index rows with these pairs: validate before the cast to int32 (one host round trip; this
-            # is not the per-batch path).  Stored pairs and the diagonal are not candidates: their gradient comes back with
-            # the stored entries (the diagonal's is 0 for a GCN, gnn/models/models.py:23).
+            # is not the per-batch path).  Stored pairs are not candidates: their gradient comes back with the stored
+            # entries (a GCN stores its diagonal, gnn/models/models.py:23; GraphSAGE's diagonal entries are genuine
+            # non-edges of the reference's dense adj.grad, gnn/models/models.py:47).
             Nn = eng.num_nodes
             if ci.numel():
                 if bool(((ci < 0) | (ci >= Nn) | (cj < 0) | (cj >= Nn)).any()):
                     raise ValueError(f"candidate pairs must index nodes in [0, {Nn})")
-                if bool((ci == cj).any()):
-                    raise ValueError("candidate pairs must not lie on the diagonal")
                 sr, sc = eng.export_adj()  # row-major sorted
                 skey, ckey = sr * Nn + sc, ci * Nn + cj
                 pos = torch.searchsorted(skey, ckey).clamp(max=max(skey.numel() - 1, 0))

@@ -549,7 +549,7 @@ def test_kron_laplace_reuses_a_gcn_first_input_covariance_decomposition_under_an
     la2.fit(loader)
     assert len(cache) == 1 and torch.equal(la2.H.eigenvalues[0][1], lamA)  # the cached eigenpairs, bit for bit
     assert not torch.equal(la2.H.eigenvalues[0][0], la.H.eigenvalues[0][0])  # B_0 did change
-    lg.KronLaplace(model, "classification").fit(lg.TensorBatchLoader(idx, y, batch_size=40))
+    lg.KronLaplace(model, "classification").fit(lg.TensorBatchLoader(idx, y, batch_size=30))
     assert len(cache) == 2  # another batch count: another matrix, another key
     lg.KronLaplace(model, "classification", cache_decompositions=False).fit(loader)
     assert len(cache) == 2
