@@ -60,6 +60,8 @@ extern "C" {
 #define LGNN_FLAG_FORK_EXACT_SEED 1u /* back-propagate d/df sum_i f_i S_ic(f) (curvlinops/kfac.py:637-661 as
                                         modified by the fork) instead of upstream's detached S[:,c]          */
 #define LGNN_FLAG_NO_FUSE 2u         /* debugging: run SpMM^T and the Gram contraction as separate kernels    */
+#define LGNN_FLAG_NO_PATHS 4u        /* 2-layer GCN: keep the class-plane route (backward GEMM + fused SpMM^T -> Gram) instead
+                                        of the two-hop path route (csrc/paths.hip); same results up to fp32 reassociation */
 
 typedef struct lgnn_ctx lgnn_ctx; /* opaque: graph + bound model + forward cache + workspace */
 
@@ -180,7 +182,8 @@ LGNN_API int lgnn_ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_s
  * shape -- the per-layer choice between the fused SpMM^T -> Gram kernel and the SpMM + Gram pair through HBM, the
  * compacted backward GEMM, and the workspace layout (curvlinops/kfac.py:653-661 has one autograd backward per class
  * instead; nothing to choose there).  out: int64 [4 + num_layers] = {seeds_on_the_fly, sage_compact, need_pong,
- * classes_per_chunk, step_0 .. step_{L-1}} with step_l = 1 (fused) | 2 (compacted backward GEMM); step_0 is unused. */
+ * classes_per_chunk, step_0 .. step_{L-1}} with step_l = 1 (fused) | 2 (compacted backward GEMM) | 4 (step L-1 only: the
+ * first layer's B comes from the batch's two-hop paths, no class planes); step_0 is unused. */
 LGNN_API int lgnn_kfac_plan(int kind, int num_layers, const int64_t* dims /* host [L+1] */, int64_t num_nodes, int64_t nnz,
                    int activation, uint32_t flags, int64_t workspace_limit, int64_t* out /* host */);
 

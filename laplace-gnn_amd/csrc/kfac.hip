@@ -661,7 +661,7 @@ static int attach_long_rows(lgnn_ctx* h, FusedArgs& a, hipStream_t s) {
 // are 256-byte aligned, so alignment follows from the widths).  One helper serves the launch loop, the workspace
 // sizing (need_pong, cc_max) and lgnn_kfac_plan, so that the prediction cannot drift from what the loop does.
 KfacPlan plan_kfac(int kind, int L, int64_t N, int64_t nnz, const int64_t* dims, int act, bool no_fuse,
-                   int64_t ws_limit) {
+                   int64_t ws_limit, bool no_paths) {
   KfacPlan p{};
   const int64_t C = dims[L];
   const bool gcn = kind == LGNN_KIND_GCN;
@@ -673,6 +673,7 @@ KfacPlan plan_kfac(int kind, int L, int64_t N, int64_t nnz, const int64_t* dims,
                    fused_supported(d_top, 2 * d_top, (N + 1) * 2 * d_top, nullptr, N + 1) && hact_ld(L - 2) % 4 == 0;
   const bool row_active = gcn && !no_fuse && nnz > 0;  // flags of the non-zero top-layer gradient rows exist
   p.need_pong = L > 2 || no_fuse;
+  p.paths = !no_fuse && !no_paths && p.seeds_on_the_fly && paths_supported(kind, L, dims, act, nnz);
   for (int l = L - 1; l >= 1; --l) {
     const int64_t d = dims[l], dout = dims[l + 1];
     const bool top = l == L - 1;
@@ -689,7 +690,11 @@ KfacPlan plan_kfac(int kind, int L, int64_t N, int64_t nnz, const int64_t* dims,
     if (!p.fuse[l]) p.need_pong = true;  // the unfused path writes its SpMM output there
     p.maxw = std::max(p.maxw, gcn ? d : 2 * d);  // GEMM output width of layer l
   }
-  const int64_t per_class = (N + 1) * p.maxw * 4 * (p.need_pong ? 2 : 1);
+  if (p.paths) {  // Y [N][classes][H] is the only plane-sized buffer; no fused kernel, no backward GEMM, no second buffer
+    p.need_pong = false;
+    for (int l = 0; l < L; ++l) p.fuse[l] = p.backgemm[l] = false;
+  }
+  const int64_t per_class = p.paths ? N * p.maxw * 4 : (N + 1) * p.maxw * 4 * (p.need_pong ? 2 : 1);
   p.cc_max = std::max<int64_t>(1, std::min<int64_t>(C, ws_limit / std::max<int64_t>(per_class, 1)));
   return p;
 }
@@ -788,7 +793,8 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   LGNN_REQUIRE(M < INT32_MAX, "batch too large");
 
   const bool fork_exact = (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0;
-  const KfacPlan plan = plan_kfac(h->kind, L, N, h->nnz, h->dims, h->act, no_fuse, h->ws_limit);
+  const KfacPlan plan = plan_kfac(h->kind, L, N, h->nnz, h->dims, h->act, no_fuse, h->ws_limit,
+                                  (flags & LGNN_FLAG_NO_PATHS) != 0 || fisher != nullptr);
   // GCN, fused path: the top-layer kernel rebuilds each sample's C x C seed block from its probabilities and logits,
   // so the blocks are never written (64 MB per arxiv-shaped batch); every other path reads them from ws.seeds
   const bool seeds_on_the_fly = plan.seeds_on_the_fly && !fisher;  // the on-the-fly rebuild knows the GGN blocks only
@@ -837,8 +843,10 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
       LGNN_CALL(compact_flags(h->ws.active.as<uint8_t>(), N, h->ws.act_list.as<int32_t>(),
                               h->ws.act_count.as<int32_t>(), h->ws.select_tmp, s));
       have_act_list = true;
-      float* gplanes = L > 1 ? gtop : nullptr;  // a single-layer model needs the Gram only
-      if (L > 1 && !plan.fuse[L - 1])
+      // a single-layer model needs the Gram only -- and so does the two-hop path route (paths.hip), which never reads planes
+      const bool paths_route = plan.paths && !fisher;
+      float* gplanes = (L > 1 && !paths_route) ? gtop : nullptr;
+      if (L > 1 && !plan.fuse[L - 1] && !paths_route)
         // the unfused lower path reads every row of the planes: the rows this kernel skips must be zero
         LGNN_HIP_CHECK(hipMemsetAsync(gtop + cb * N * C, 0, size_t(N) * nq * 4, s));
       float* sc = h->ws.gram_scratch[L - 1].as<float>();
@@ -869,8 +877,14 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
     }
   }
 
+  // ---- 2-layer GCN: B_0 from the batch's 2-hop paths -- no class planes (paths.hip) -------------------------
+  const bool paths_route = plan.paths && !fisher && seeds_on_the_fly;
+  if (paths_route)
+    LGNN_CALL(kfac_paths_first_layer(h, idx, M, h->lik == LGNN_LIK_REGRESSION ? 2 : (fork_exact ? 1 : 0), cb, ce,
+                                     h->ws.gram_scratch[0].as<float>(), s));
+
   // ---- lower layers, chunked over classes ----------------------------------------------------------
-  if (L > 1) {
+  if (L > 1 && !paths_route) {
     // Source rows of the first backward plane set are non-zero only where the top-layer gradient is:
     // GCN: nodes with a batch node among their P^T neighbours (flags from the seed SpMM);
     // GraphSAGE: the batch nodes themselves.  Zeroed values make the fused SpMM skip those gathers.
@@ -1143,9 +1157,10 @@ extern "C" int lgnn_kfac_plan(int kind, int num_layers, const int64_t* dims, int
   LGNN_REQUIRE(kind == LGNN_KIND_GCN || kind == LGNN_KIND_SAGE, "unknown graph kind");
   LGNN_REQUIRE(workspace_limit > 0 && num_nodes > 0, "workspace limit and node count must be positive");
   const KfacPlan p = plan_kfac(kind, num_layers, num_nodes, nnz, dims, activation, (flags & LGNN_FLAG_NO_FUSE) != 0,
-                               workspace_limit);
+                               workspace_limit, (flags & LGNN_FLAG_NO_PATHS) != 0);
   out[0] = p.seeds_on_the_fly; out[1] = p.sage_compact; out[2] = p.need_pong; out[3] = p.cc_max;
-  for (int l = 0; l < num_layers; ++l) out[4 + l] = (p.fuse[l] ? 1 : 0) | (p.backgemm[l] ? 2 : 0);
+  for (int l = 0; l < num_layers; ++l)
+    out[4 + l] = (p.fuse[l] ? 1 : 0) | (p.backgemm[l] ? 2 : 0) | ((p.paths && l == num_layers - 1) ? 4 : 0);
   return 0;
 }
 

@@ -109,6 +109,10 @@ struct Workspace {
   DevBuf flags;  // 64 B of asynchronous error flags
   DevBuf out_flags, out_list, out_count;  // GraphSAGE KFAC: rows of the first backward plane set that can be non-zero
   DevBuf val_act2;  // P^T's values with the columns outside that row set zeroed (second backward level of deeper models)
+  // two-hop path route of the first layer's B (paths.hip): per-sample coefficient rows [M][3][64], the rows (u | p) [2 M][C]
+  // and their products with W_1 [2 M][H]; R = P^T[:, batch] as CSR over v (counts / cursors, row pointers, sample, weight)
+  DevBuf path_coef, path_up, path_bg, path_cnt, path_rptr, path_rm, path_rw, path_zeros;
+  bool path_zeros_set = false;
   DevBuf gram_scratch_res[kMaxLayers];  // res / norm models: per-call partial B of res.{l} (GCN; GraphSAGE shares the conv's)
   DevBuf planes_c;  // GCN with res, >= 3 layers: u_l Wr_l of the level being computed
 };
@@ -324,11 +328,14 @@ struct KfacPlan {
   bool seeds_on_the_fly;       // GCN top layer rebuilds the seed blocks from probabilities + logits
   bool sage_compact;           // GraphSAGE top level over the batch nodes only (compacted backward GEMM + fused MODE 1)
   bool need_pong;              // the second plane buffer is written by some step
+  bool paths;                  // 2-layer GCN, ReLU, 128 < H <= 256, C <= 64: B_0 from the batch's 2-hop paths (paths.hip),
+                               // no class planes, no backward GEMM, no gather of planes
   bool fuse[kMaxLayers];       // step l (l = L-1 .. 1): fused SpMM^T -> Gram kernel (else SpMM + Gram through HBM)
   bool backgemm[kMaxLayers];   // step l: compacted producer / consumer backward GEMM (else the generic GEMM)
   int64_t maxw, cc_max;        // widest GEMM output of the lower layers; class planes per chunk under the workspace cap
 };
-KfacPlan plan_kfac(int kind, int L, int64_t N, int64_t nnz, const int64_t* dims, int act, bool no_fuse, int64_t ws_limit);
+KfacPlan plan_kfac(int kind, int L, int64_t N, int64_t nnz, const int64_t* dims, int act, bool no_fuse, int64_t ws_limit,
+                   bool no_paths = false);
 // empirical / Monte-Carlo Fisher variant of the KFAC accumulate (curvlinops/kfac.py:663-674)
 struct KfacFisherOpts {
   const void* y_seed;   // labels int64 [M] (classification) / fp32 targets [M, C] (regression) the gradient seed uses
@@ -344,6 +351,13 @@ int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bo
 int batch_epilogue(lgnn_ctx* h, const int64_t* idx, int64_t M, hipStream_t s);
 // timing hook (lgnn_enable_kernel_timing): one HIP event on the launch stream; callers bracket the dominant kernel
 int record_event(lgnn_ctx* h, hipStream_t s);
+// ---- paths.hip ----------------------------------------------------------------------------
+bool paths_supported(int kind, int L, const int64_t* dims, int act, int64_t nnz);
+// scratch [H, H] += B_0 of this batch's class columns [cb, ce) (seed_mode: 0 upstream, 1 fork exact, 2 regression)
+int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce, float* scratch,
+                           hipStream_t s);
+// scratch [width, width] (upper 32 x 32 sub-tiles) += Y^T Y for contiguous rows of `width` floats, 128 < width <= 256
+int launch_gram256_stream(const float* Y, int64_t rows, int64_t width, float* scratch, const float* zeros, hipStream_t s);
 // ---- forward.hip ------------------------------------------------------------------------
 int forward_ensure(lgnn_ctx* h, hipStream_t s);
 int forward_ensure_grams(lgnn_ctx* h, hipStream_t s);

@@ -1,0 +1,442 @@
+// First-layer gradient covariance B_0 of a 2-layer GCN WITHOUT class planes: the headline KFAC path.
+//
+// Reference: KFACLinearOperator._compute_loss_and_backward / _accumulate_gradient_covariance (curvlinops/kfac.py:607-661,
+// 777-817) run one dense backward pass per class column c of the loss-Hessian square root through the model
+// (gnn/models/base_gnn.py:141-156, gnn/models/layers.py:45-46) and add g^T g at the first Linear's output.
+//
+// The route this file replaces materialised the C right-hand sides as class-major planes
+//     U[c][v][:] = [h_1[v] > 0] * (g1_c[v] W_1)          (40 planes x 173 MB at the arxiv shape, written by backgemm.hip)
+// and gathered them back through P^T inside the fused SpMM^T -> Gram kernel (fused256.hip): 55 GB per batch through the
+// Infinity Cache, 7.1x the algorithmic bytes, the gather and not the matrix pipes setting the time.
+//
+// The seed block is diagonal + rank 2 (kfac.hip, seed_spmm_gram_kernel):  V_m[k, c] = alpha_c d_kc - beta_c u_k - gamma_c p_k,
+// hence  V_m[:, c]^T W_1 = alpha_c^m W_1[c, :] - beta_c^m b_m - gamma_c^m g_m  with the per-sample H-vectors b_m = u_m^T W_1,
+// g_m = p_m^T W_1, and for a destination node n the C x H block of all its class rows is a sum over the batch's 2-hop paths
+// j = (n <- v_j <- m_j), weight w_j = P^T[n, v_j] P^T[v_j, m_j]:
+//     Y[n] = W_1 (.) (A_alpha Mk) + A_beta (B_k (.) Mk) + A_gamma (G_k (.) Mk)
+//       A_*[c, j] = w_j * (alpha, -beta, -gamma)_c^{m_j}   (C x K),   Mk[j, :] = ReLU mask bits of v_j  (K x H, 0 / 1),
+//       B_k[j, :] = b_{m_j},  G_k[j, :] = g_{m_j}                    (K x H, rows of a 20 MB per-batch table: L2 / MALL resident)
+//     B_0 += Y[n]^T Y[n]
+// (oracle: kfac_first_layer_B_by_paths, pinned to the reference's goldens).  ~13 paths per node at the arxiv shape, ~2.8 KB
+// gathered per path instead of 40 KB per edge; three C x K x H products on the matrix pipes (+ ~1/3 of the Gram's MFMA work)
+// buy the removal of the planes' gather.
+//
+// Kernels (per mini-batch):
+//   path_tables_kernel   per-sample coefficient rows (alpha, -beta, -gamma) and the rows (u, p) whose product with W_1 (one
+//                        small GEMM, kernels.hip) gives b_m, g_m
+//   path_count / fill    R = P^T[:, batch] as CSR over v (counting sort: count, rocPRIM scan, fill): the batch neighbours of v
+//   ybuild_kernel        one workgroup per node, one wave per (32 classes x 64 columns): enumerate the node's paths into LDS (block scan over
+//                        its neighbours' R lists, windows of 128 paths), accumulate the three products with
+//                        v_mfma_f32_32x32x2_f32 (A = coefficient rows, B = mask / masked table rows, 128-byte operand rows
+//                        straight from L2), fold W_1 in, stream Y[n] (R x H floats, contiguous) to HBM     -- HBM write bound
+//   gram256_stream_kernel  S += Y^T Y over N*R rows of 1 KiB: one persistent 512-thread workgroup per CU, ALL EIGHT waves on
+//                        the matrix pipes (36 upper 32 x 32 sub-tiles dealt 5 + 4 to the two waves of a SIMD), row blocks of
+//                        32 rows arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, issued by the MFMA
+//                        waves themselves) into a 3-slot ring: one raw s_barrier and one counted vmcnt wait per block
+//                                                                                                           -- fp32 MFMA bound
+#include "device_utils.h"
+#include "gram256.h"
+#include "lgnn_internal.h"
+
+namespace lgnn {
+
+namespace {
+
+constexpr int kCoefStride = 64;  // classes per coefficient row (zero padded): two 32-row MFMA tiles
+constexpr int kPathWindow = 128; // paths staged in LDS per accumulation window
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// One wave per batch sample (first occurrences only; a node listed t times carries t in its R weights).
+// mode: 0 upstream seeds, 1 fork exact, 2 regression (V = sqrt(2) I).
+__global__ __launch_bounds__(256) void path_tables_kernel(const float* __restrict__ probs, const float* __restrict__ logits,
+                                                          const int64_t* __restrict__ idx, const int32_t* __restrict__ pos,
+                                                          int64_t M, int64_t N, int C, int mode, float* __restrict__ coef,
+                                                          float* __restrict__ up) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int64_t n = idx[m];
+  float* __restrict__ cm = coef + m * 3 * kCoefStride;
+  float* __restrict__ um = up + m * C;
+  float* __restrict__ pm = up + (M + m) * C;
+  const bool own = n >= 0 && n < N && pos[n] == int32_t(m);
+  float pk = 0.f, fk = 0.f;
+  if (own && lane < C && mode != 2) { pk = probs[m * C + lane]; fk = logits[n * C + lane]; }
+  const float mb = wsum(pk * fk);  // same summation order as seed_kernel / seed_spmm_gram_kernel
+  const float sp = sqrtf(pk), t = fk - mb;
+  float al = 0.f, be = 0.f, ga = 0.f, u = 0.f;
+  if (own && lane < C) {
+    if (mode == 2) al = 1.41421356237309515f;
+    else if (mode == 1) { al = sp * (1.f + 0.5f * t); be = sp; ga = 0.5f * sp * t; u = pk * (1.f + t); }
+    else { al = sp; be = sp; u = pk; }
+  }
+  cm[lane] = al;                       // lanes >= C write the zero padding
+  cm[kCoefStride + lane] = -be;
+  cm[2 * kCoefStride + lane] = -ga;
+  if (lane < C) { um[lane] = u; pm[lane] = own ? pk : 0.f; }
+}
+
+// R = P^T[:, batch]: for every distinct batch node u (its first position m) and every entry (v, val) of row u of P.
+template <bool FILL>
+__global__ __launch_bounds__(256) void path_r_kernel(const int64_t* __restrict__ idx, int64_t M, int64_t N,
+                                                     const int32_t* __restrict__ pos, const int32_t* __restrict__ mult,
+                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                     const float* __restrict__ val, int32_t* __restrict__ cnt,
+                                                     const int32_t* __restrict__ rptr, int32_t* __restrict__ r_m,
+                                                     float* __restrict__ r_w) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int64_t u = idx[m];
+  if (u < 0 || u >= N || pos[u] != int32_t(m)) return;  // invalid ids are flagged by mark_batch_kernel
+  const float tm = FILL ? float(mult[m]) : 0.f;
+  const int32_t e = rowptr[u + 1];
+  for (int32_t p = rowptr[u] + lane; p < e; p += 64) {
+    const int32_t v = col[p];
+    const int32_t k = atomicAdd(&cnt[v], 1);
+    if constexpr (FILL) {
+      const int32_t slot = rptr[v] + k;
+      r_m[slot] = int32_t(m);
+      r_w[slot] = val[p] * tm;
+    }
+  }
+}
+
+struct YArgs {
+  const int32_t* rowptr; const int32_t* col; const float* val;  // P^T
+  const int32_t* rptr; const int32_t* r_m; const float* r_w;    // R = P^T[:, batch]
+  const float* coef;        // [M][3][64]
+  const float* bg;          // [2 M][H]: rows b_m, then rows g_m
+  const uint32_t* mask;     // [N][mask_words] ReLU bits of h_1
+  int mask_words;
+  const float* W1;          // [C][H]
+  float* Y;                 // [N][R][H]
+  int64_t N, M;
+  int H, c0, R;
+  int no_bg;                // regression / nothing but the diagonal term: the beta / gamma products vanish
+};
+
+// One workgroup per node, blockDim = 64 * colgroups * rowtiles: wave (rt, cg) owns the 32-class row tile rt (classes
+// c0 + 32 rt ...) and the columns [64 cg, 64 cg + 64) of Y[n]: two 32 x 32 accumulator tiles for the alpha product and two
+// for the beta / gamma products (64 accumulator registers), so that several workgroups fit a CU and hide the dependent
+// loads of the path enumeration (row of P^T -> R pointers -> R entries -> table rows).  Waves w and w + 4 (the two row
+// tiles of one column group) share a SIMD.
+__global__ __launch_bounds__(512, 4) void ybuild_kernel(YArgs a) {
+  __shared__ int32_t s_m[kPathWindow];
+  __shared__ int32_t s_v[kPathWindow];
+  __shared__ float s_w[kPathWindow];
+  __shared__ int32_t s_scan[8];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+  const int ncg = (a.H + 63) >> 6;          // column groups
+  const int cg = wave % ncg, rt = wave / ncg;
+  const int64_t n = blockIdx.x;
+  const int H = a.H;
+
+  f32x16 t1[2], y2[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
+
+  // class of this lane's A-operand row (i = lane & 31), clamped into the zero-padded coefficient row
+  const bool cls_ok = 32 * rt + li < a.R;
+  const int cls = min(a.c0 + 32 * rt + li, kCoefStride - 1);
+  int colv[2];
+  bool col_ok[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    colv[ct] = 64 * cg + 32 * ct + li;
+    col_ok[ct] = colv[ct] < H;
+    if (!col_ok[ct]) colv[ct] = 0;
+  }
+
+  const int32_t rs = a.rowptr[n], re = a.rowptr[n + 1];
+  for (int32_t base = rs; base < re; base += nthreads) {
+    // ---- this thread's neighbour v and the extent of its batch list R[v]
+    int32_t v = 0, r0 = 0, cnt = 0;
+    float pv = 0.f;
+    if (base + tid < re) {
+      v = a.col[base + tid];
+      pv = a.val[base + tid];
+      r0 = a.rptr[v];
+      cnt = a.rptr[v + 1] - r0;
+    }
+    // ---- block-wide exclusive scan of cnt
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < nwaves; ++w) {
+      const int sw = s_scan[w];
+      if (w < wave) woff += sw;
+      total += sw;
+    }
+    const int off = woff + incl - cnt;
+    __syncthreads();  // s_scan is rewritten by the next row chunk
+    // ---- windows of kPathWindow paths
+    for (int wb = 0; wb < total; wb += kPathWindow) {
+      const int lo = max(off, wb), hi = min(off + cnt, wb + kPathWindow);
+      for (int j = lo; j < hi; ++j) {
+        const int k = j - off;
+        s_m[j - wb] = a.r_m[r0 + k];
+        s_w[j - wb] = pv * a.r_w[r0 + k];
+        s_v[j - wb] = v;
+      }
+      __syncthreads();
+      const int kw = min(kPathWindow, total - wb);
+      for (int ks = 0; 2 * ks < kw; ++ks) {
+        const int j = 2 * ks + half;  // MFMA k index = lane >> 5: the two paths of this step
+        const bool valid = j < kw;
+        const int32_t mj = valid ? s_m[j] : 0;
+        const int32_t vj = valid ? s_v[j] : 0;
+        const float wk = (valid && cls_ok) ? s_w[j] : 0.f;
+        const float* __restrict__ cm = a.coef + int64_t(mj) * 3 * kCoefStride + cls;
+        const float aa = wk * cm[0];
+        const float ab = wk * cm[kCoefStride];
+        const float ag = wk * cm[2 * kCoefStride];
+        float mf[2], bb[2], gg[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const uint32_t word = a.mask[int64_t(vj) * a.mask_words + (colv[ct] >> 5)];
+          mf[ct] = (col_ok[ct] && ((word >> (colv[ct] & 31)) & 1u)) ? 1.f : 0.f;
+          bb[ct] = a.no_bg ? 0.f : mf[ct] * a.bg[int64_t(mj) * H + colv[ct]];
+          gg[ct] = a.no_bg ? 0.f : mf[ct] * a.bg[(a.M + int64_t(mj)) * H + colv[ct]];
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          t1[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, mf[ct], t1[ct], 0, 0, 0);
+          if (!a.no_bg) {
+            y2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab, bb[ct], y2[ct], 0, 0, 0);
+            y2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag, gg[ct], y2[ct], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();  // the next window overwrites the path arrays
+    }
+  }
+
+  // ---- Y[n][c - c0][col] = W_1[c][col] * T1 + Y2   (C / D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+  float* __restrict__ yn = a.Y + n * int64_t(a.R) * H;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int colc = 64 * cg + 32 * ct + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (row < a.R && colc < H) {
+        const float w1 = a.W1[int64_t(a.c0 + row) * H + colc];
+        yn[int64_t(row) * H + colc] = w1 * t1[ct][r] + y2[ct][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Streaming Gram: S += Y^T Y for rows of `width` floats (129 .. 256), all eight waves on the matrix pipes.
+// Tile split: the 4 groups of gram256.h (9 sub-tiles each, <= 6 of the 8 column blocks) go to the two waves that share a SIMD
+// (hardware waves g and g + 4): 5 + 4 sub-tiles.
+template <int W, int LO, int HI> __device__ __forceinline__ constexpr bool part_uses(int b) {
+  for (int s = LO; s < HI; ++s)
+    if (Tiles256<W>::si[s] == b || Tiles256<W>::sj[s] == b) return true;
+  return false;
+}
+template <int W, int LO, int HI>
+__device__ __forceinline__ void part_load(const float* __restrict__ p, float (&x)[8]) {
+#pragma unroll
+  for (int b = 0; b < 8; ++b) x[b] = part_uses<W, LO, HI>(b) ? p[b * 32] : 0.f;
+}
+template <int W, int LO, int HI>
+__device__ __forceinline__ void part_mfma(const float (&x)[8], f32x16 (&acc)[HI - LO]) {
+#pragma unroll
+  for (int s = LO; s < HI; ++s)
+    acc[s - LO] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[Tiles256<W>::si[s]], x[Tiles256<W>::sj[s]], acc[s - LO], 0, 0, 0);
+}
+
+constexpr int kSlots = 3;
+constexpr int kBlockRows = 32;
+
+struct GramStreamArgs {
+  const float* Y;       // [rows][width]
+  int64_t rows;
+  int width;
+  const float* zeros;   // >= 16 bytes of zeros: the source of lanes past the row's end and of rows past the last
+  float* scratch;       // [width][width], upper sub-tiles, float atomics
+};
+
+// the 4 LDS-DMA row copies of block `blk` that this wave issues (rows 4 hw .. 4 hw + 3 of the block) into slot `slot`
+__device__ __forceinline__ void issue_block(const GramStreamArgs& a, float* tiles, int64_t blk, int slot, int hw, int lane,
+                                            bool lane_ok) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 4 * hw + q;
+    const int64_t row = blk * kBlockRows + r;
+    const float* src = (lane_ok && row < a.rows) ? a.Y + row * a.width + 4 * lane : a.zeros;
+    float* dst = tiles + (slot * kBlockRows + r) * 256;  // wave-uniform LDS base; lane l lands at + 4 l floats
+    __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                              reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
+  }
+}
+
+template <int W, int LO, int HI>
+__device__ __forceinline__ void stream_wave(const GramStreamArgs& a, float* tiles, int64_t nb, int hw, int lane) {
+  constexpr int NT = HI - LO;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int s = 0; s < NT; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  const bool lane_ok = 4 * lane < a.width;  // width % 4 == 0 (launcher)
+  const int64_t stride = gridDim.x;
+  // prologue: blocks 0 and 1 of this workgroup are in flight before the loop
+  issue_block(a, tiles, blockIdx.x, 0, hw, lane, lane_ok);
+  issue_block(a, tiles, blockIdx.x + stride, 1, hw, lane, lane_ok);
+  for (int64_t i = 0; i < nb; ++i) {
+    // all but this wave's 4 youngest copies (block i + 1) have landed => its rows of block i are in LDS; the barrier then
+    // says so for every wave's rows, and that everybody is done reading block i - 1, whose slot block i + 2 reuses
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_block(a, tiles, blockIdx.x + (i + 2) * stride, int((i + 2) % kSlots), hw, lane, lane_ok);
+    const float* __restrict__ base = tiles + int(i % kSlots) * kBlockRows * 256 + (lane >> 5) * 256 + (lane & 31);
+    float xa[8], xb[8];
+    part_load<W, LO, HI>(base, xa);
+#pragma unroll 2
+    for (int kk = 0; kk < kBlockRows / 2; kk += 2) {
+      part_load<W, LO, HI>(base + (kk + 1) * 512, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      part_mfma<W, LO, HI>(xa, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk + 2 < kBlockRows / 2) part_load<W, LO, HI>(base + (kk + 2) * 512, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      part_mfma<W, LO, HI>(xb, acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two look-ahead blocks past the end (zeros) before the LDS dies
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int64_t D = a.width;
+#pragma unroll
+  for (int s = LO; s < HI; ++s) {
+    const int64_t j = Tiles256<W>::sj[s] * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t i = Tiles256<W>::si[s] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (i < D && j < D) atomicAdd(&a.scratch[i * D + j], acc[s - LO][r]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void gram256_stream_kernel(GramStreamArgs a) {
+  __shared__ float tiles[kSlots * kBlockRows * 256];  // 96 KiB: ONE LDS object (a second one makes hipcc drain vmcnt)
+  const int lane = threadIdx.x & 63;
+  const int hw = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int64_t nblocks = (a.rows + kBlockRows - 1) / kBlockRows;
+  const int64_t nb = nblocks > int64_t(blockIdx.x) ? (nblocks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  // hardware waves g and g + 4 share a SIMD (waves are dealt round-robin to the CU's four SIMDs)
+  switch (hw) {
+    case 0: stream_wave<0, 0, 5>(a, tiles, nb, hw, lane); break;
+    case 4: stream_wave<0, 5, 9>(a, tiles, nb, hw, lane); break;
+    case 1: stream_wave<1, 0, 5>(a, tiles, nb, hw, lane); break;
+    case 5: stream_wave<1, 5, 9>(a, tiles, nb, hw, lane); break;
+    case 2: stream_wave<2, 0, 5>(a, tiles, nb, hw, lane); break;
+    case 6: stream_wave<2, 5, 9>(a, tiles, nb, hw, lane); break;
+    case 3: stream_wave<3, 0, 5>(a, tiles, nb, hw, lane); break;
+    default: stream_wave<3, 5, 9>(a, tiles, nb, hw, lane); break;
+  }
+}
+
+}  // namespace
+
+bool paths_supported(int kind, int L, const int64_t* dims, int act, int64_t nnz) {
+  const int64_t C = dims[L], H = L >= 2 ? dims[L - 1] : 0;
+  return kind == LGNN_KIND_GCN && L == 2 && act == LGNN_ACT_RELU && nnz > 0 && C <= kCoefStride && H > 128 && H <= 256 &&
+         H % 4 == 0;
+}
+
+int launch_gram256_stream(const float* Y, int64_t rows, int64_t width, float* scratch, const float* zeros, hipStream_t s) {
+  LGNN_REQUIRE(width > 128 && width <= 256 && width % 4 == 0, "internal: streaming Gram width");
+  if (rows <= 0) return 0;
+  GramStreamArgs g{Y, rows, int(width), zeros, scratch};
+  const int64_t nblocks = cdiv(rows, kBlockRows);
+  hipLaunchKernelGGL(gram256_stream_kernel, dim3(unsigned(std::min<int64_t>(nblocks, 256))), dim3(512), 0, s, g);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// B_0 scratch += sum over the class columns [cb, ce) of this batch (see the file header).  Needs batch_prologue's
+// probabilities / multiplicities / positions and the cached forward (logits, mask bits).
+int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce, float* scratch,
+                           hipStream_t s) {
+  const int64_t N = h->N, C = h->dims[2], H = h->dims[1];
+  Workspace& ws = h->ws;
+  LGNN_REQUIRE(paths_supported(h->kind, h->L, h->dims, h->act, h->nnz), "internal: path route on an unsupported model");
+  // ---- per-sample tables and b_m / g_m
+  LGNN_CALL(ws.path_coef.reserve(size_t(M) * 3 * kCoefStride * 4));
+  LGNN_CALL(ws.path_up.reserve(size_t(2 * M) * C * 4));
+  LGNN_CALL(ws.path_bg.reserve(size_t(2 * M) * H * 4));
+  hipLaunchKernelGGL(path_tables_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, ws.probs.as<float>(),
+                     h->fc.out.as<float>(), idx, ws.pos.as<int32_t>(), M, N, int(C), seed_mode, ws.path_coef.as<float>(),
+                     ws.path_up.as<float>());
+  LGNN_HIP_CHECK(hipGetLastError());
+  const bool no_bg = seed_mode == 2;
+  if (!no_bg) {
+    GemmEpilogue none;
+    LGNN_CALL(launch_gemm(ws.path_up.as<float>(), C, h->W[1], H, ws.path_bg.as<float>(), H, 2 * M, C, H, none, s));
+  }
+  // ---- R = P^T[:, batch]
+  LGNN_CALL(ws.path_cnt.reserve(size_t(N + 1) * 4));
+  LGNN_CALL(ws.path_rptr.reserve(size_t(N + 1) * 4));
+  LGNN_CALL(ws.path_rm.reserve(size_t(std::max<int64_t>(h->nnz, 1)) * 4));
+  LGNN_CALL(ws.path_rw.reserve(size_t(std::max<int64_t>(h->nnz, 1)) * 4));
+  LGNN_CALL(ws.path_zeros.reserve(256));
+  if (!ws.path_zeros_set) {
+    LGNN_HIP_CHECK(hipMemsetAsync(ws.path_zeros.p, 0, 256, s));
+    ws.path_zeros_set = true;
+  }
+  LGNN_HIP_CHECK(hipMemsetAsync(ws.path_cnt.p, 0, size_t(N + 1) * 4, s));
+  hipLaunchKernelGGL(path_r_kernel<false>, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, idx, M, N, ws.pos.as<int32_t>(),
+                     ws.mult.as<int32_t>(), h->P.rowptr, h->P.col, h->P.val, ws.path_cnt.as<int32_t>(),
+                     static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr), static_cast<float*>(nullptr));
+  LGNN_CALL(exclusive_scan_i32(ws.path_cnt.as<int32_t>(), ws.path_rptr.as<int32_t>(), N + 1, ws.select_tmp, s));
+  LGNN_HIP_CHECK(hipMemsetAsync(ws.path_cnt.p, 0, size_t(N + 1) * 4, s));
+  hipLaunchKernelGGL(path_r_kernel<true>, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, idx, M, N, ws.pos.as<int32_t>(),
+                     ws.mult.as<int32_t>(), h->P.rowptr, h->P.col, h->P.val, ws.path_cnt.as<int32_t>(),
+                     ws.path_rptr.as<int32_t>(), ws.path_rm.as<int32_t>(), ws.path_rw.as<float>());
+  LGNN_HIP_CHECK(hipGetLastError());
+  // ---- class chunks under the workspace cap: Y [N][R][H], then the streaming Gram
+  const int64_t per_class = N * H * 4;
+  const int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(ce - cb, h->ws_limit / std::max<int64_t>(per_class, 1)));
+  LGNN_CALL(ws.planes_a.reserve(size_t(cc_max) * N * H * 4));
+  ws.planes_a_zero_ptr = nullptr;
+  LGNN_REQUIRE(N < (int64_t(1) << 31), "too many nodes for one launch");
+  for (int64_t c0 = cb; c0 < ce; c0 += cc_max) {
+    const int64_t R = std::min(cc_max, ce - c0);
+    YArgs y{};
+    y.rowptr = h->PT.rowptr; y.col = h->PT.col; y.val = h->PT.val;
+    y.rptr = ws.path_rptr.as<int32_t>(); y.r_m = ws.path_rm.as<int32_t>(); y.r_w = ws.path_rw.as<float>();
+    y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>();
+    y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
+    y.W1 = h->W[1]; y.Y = ws.planes_a.as<float>(); y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
+    y.no_bg = no_bg ? 1 : 0;
+    const unsigned threads = unsigned(64 * cdiv(H, 64) * cdiv(R, 32));  // (column groups) x (32-class row tiles) waves
+    hipLaunchKernelGGL(ybuild_kernel, dim3(unsigned(N)), dim3(threads), 0, s, y);
+    LGNN_HIP_CHECK(hipGetLastError());
+    if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the KFAC path (bench.py roofline)
+    LGNN_CALL(launch_gram256_stream(y.Y, N * R, H, scratch, ws.path_zeros.as<float>(), s));
+    if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
+  }
+  return 0;
+}
+
+}  // namespace lgnn

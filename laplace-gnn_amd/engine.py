@@ -32,20 +32,28 @@ def _dev_ptr(t: torch.Tensor, dtype, what: str) -> C.c_void_p:
     return C.c_void_p(t.data_ptr())
 
 
+def _no_paths_default() -> bool:
+    """LGNN_NO_PATHS=1 (read per call): keep the class-plane route of the 2-layer GCN KFAC for A/B timing."""
+    import os
+    return os.environ.get("LGNN_NO_PATHS", "") not in ("", "0")
+
+
 def kfac_plan(kind: str, dims: Sequence[int], num_nodes: int, nnz: int, act: str = "relu", fuse: bool = True,
-              workspace_limit: int = 32 << 30) -> dict:
+              workspace_limit: int = 32 << 30, paths: bool | None = None) -> dict:
     """Which kernels ``lgnn_kfac_accumulate`` would run for a model of this shape (host-only query, no GPU work):
     per backward step l = L-1 .. 1 whether the fused SpMM^T -> Gram kernel and the compacted backward GEMM are used,
     whether the second plane buffer is needed and how many class planes fit one chunk of the workspace."""
     lib = _lib.load()
     L = len(dims) - 1
     out = (C.c_int64 * (4 + L))()
+    no_paths = _no_paths_default() if paths is None else not paths
     rc = lib.lgnn_kfac_plan(KINDS[kind], L, (C.c_int64 * (L + 1))(*dims), int(num_nodes), int(nnz), ACTS[act],
-                            0 if fuse else _lib.FLAG_NO_FUSE, int(workspace_limit), out)
+                            (0 if fuse else _lib.FLAG_NO_FUSE) | (_lib.FLAG_NO_PATHS if no_paths else 0),
+                            int(workspace_limit), out)
     _lib.check(rc, "lgnn_kfac_plan")
     return {"seeds_on_the_fly": bool(out[0]), "sage_compact": bool(out[1]), "need_pong": bool(out[2]),
             "classes_per_chunk": int(out[3]), "fused": [bool(out[4 + l] & 1) for l in range(L)],
-            "backgemm": [bool(out[4 + l] & 2) for l in range(L)]}
+            "backgemm": [bool(out[4 + l] & 2) for l in range(L)], "paths": bool(out[4 + L - 1] & 4)}
 
 
 class _IdentityKey:
@@ -279,10 +287,12 @@ class GraphEngine:
         _lib.check(self.lib.lgnn_set_workspace_limit(self._h, int(nbytes)), "lgnn_set_workspace_limit")
         self._ws_limit = int(nbytes)
 
-    def kfac_plan(self, fuse: bool = True) -> dict:
+    def kfac_plan(self, fuse: bool = True, paths: bool | None = None) -> dict:
         """The kernel choices a KFAC accumulate on the bound model makes (see ``kfac_plan``)."""
+        if self.has_extras:
+            fuse = False  # res / norm models take the unfused route (csrc/resnorm.hip)
         return kfac_plan(self.kind, self.dims, self.num_nodes, self.nnz, self._bind_opts[0], fuse,
-                         getattr(self, "_ws_limit", 32 << 30))
+                         getattr(self, "_ws_limit", 32 << 30), paths)
 
     # -- forward --------------------------------------------------------------------------------
     def forward(self, idx: torch.Tensor) -> torch.Tensor:
@@ -316,14 +326,16 @@ class GraphEngine:
         return flat, views, loss
 
     def kfac_accumulate(self, idx, y, n_train: int, views, loss, fork_exact: bool = True, fuse: bool = True,
-                        classes: tuple[int, int] | None = None):
+                        classes: tuple[int, int] | None = None, paths: bool | None = None):
         """Add one batch's factors into the caller-owned buffers.  ``classes=(begin, end)`` restricts the call to
         that range of class columns (an exact additive share of the batch; the share with class 0 also adds
         the loss and the A increment)."""
         self._sync_versions()
         idx = idx.contiguous()
         yp = self._labels(y, idx.shape[0])
-        flags = (_lib.FLAG_FORK_EXACT_SEED if fork_exact else 0) | (0 if fuse else _lib.FLAG_NO_FUSE)
+        no_paths = _no_paths_default() if paths is None else not paths  # (2-layer GCN: two-hop path route, csrc/paths.hip)
+        flags = (_lib.FLAG_FORK_EXACT_SEED if fork_exact else 0) | (0 if fuse else _lib.FLAG_NO_FUSE) | \
+            (_lib.FLAG_NO_PATHS if no_paths else 0)
         A = _lib.ptr_array([a.data_ptr() for a, _ in views])
         B = _lib.ptr_array([b.data_ptr() for _, b in views])
         cb, ce = (0, self.dims[-1]) if classes is None else (int(classes[0]), int(classes[1]))

@@ -355,13 +355,13 @@ def test_every_need_pong_outcome_under_the_smallest_workspace(kind, H, C, L, fus
     eng = lg.GraphEngine(ei.cuda(), N, kind=kind, symmetric=True)
     eng.bind(X.cuda(), [w.cuda() for w in Ws], [b.cuda() for b in bs])
     eng.set_workspace_limit(1 << 20)  # the minimum: one or two class planes per chunk
-    plan = eng.kfac_plan(fuse=fuse)
+    plan = eng.kfac_plan(fuse=fuse, paths=False)  # the class-plane routes (the path route has its own tests)
     assert plan["need_pong"] == expect[0], plan
     assert plan["fused"][1:][::-1] == expect[1], plan
     assert plan["classes_per_chunk"] < C, plan
     _, views, loss = eng.new_kfac_buffers()
     for s in (0, 80):
-        eng.kfac_accumulate(idx[s:s + 80].cuda(), y[s:s + 80].cuda(), 150, views, loss, fuse=fuse)
+        eng.kfac_accumulate(idx[s:s + 80].cuda(), y[s:s + 80].cuda(), 150, views, loss, fuse=fuse, paths=False)
     torch.cuda.synchronize()
     om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], True)
     oloss, oH = O.fit_kron(om, idx.numpy(), y.numpy(), 80)

@@ -1,0 +1,128 @@
+"""The two-hop path route of the 2-layer GCN KFAC (csrc/paths.hip): B_0 without class planes, from the
+diagonal + rank-2 structure of the seed blocks, against the CPU oracle (pinned to the reference, incl. the identity itself:
+tests/test_oracle_golden.py::test_first_layer_B_from_two_hop_paths_...) and against the class-plane route of the same
+library.  fp32 <= 1e-4 relative Frobenius error per block (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import gnn_laplace_oracle as O
+from gpu_utils import kfac_fit_engine, oracle_from_arrays, rel
+from test_gpu_scale import _engine, _make
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.mark.parametrize("H,C,skew,fork_exact", [
+    (256, 40, False, True), (256, 40, True, True), (192, 7, False, True), (132, 33, True, True), (256, 64, False, True),
+    (256, 1, False, True), (160, 10, True, False), (256, 32, False, False)])
+def test_path_route_vs_oracle_and_plane_route(H, C, skew, fork_exact):
+    N, F, E = 3000, 48, 12000
+    ei, X, Ws, bs = _make("gcn", N, F, H, C, E, L=2, seed=H + C, skew=skew)
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randperm(N, generator=g)[:700]
+    idx[7] = idx[11]
+    idx[650:] = idx[100:150]  # node ids listed twice accumulate (x[x_indices] backward)
+    y = torch.randint(0, C, (700,), generator=g)
+    eng = _engine("gcn", N, ei, X, Ws, bs)
+    assert eng.kfac_plan(paths=True)["paths"] and not eng.kfac_plan(paths=False)["paths"]
+    flat, views, loss = eng.new_kfac_buffers()
+    flat2, views2, loss2 = eng.new_kfac_buffers()
+    for s in range(0, 700, 300):  # 300 / 300 / 100
+        eng.kfac_accumulate(idx[s:s + 300].cuda(), y[s:s + 300].cuda(), 700, views, loss, fork_exact=fork_exact, paths=True)
+        eng.kfac_accumulate(idx[s:s + 300].cuda(), y[s:s + 300].cuda(), 700, views2, loss2, fork_exact=fork_exact, paths=False)
+    torch.cuda.synchronize()
+    om = oracle_from_arrays("gcn", N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], True)
+    oloss, oH = O.fit_kron(om, idx.numpy(), y.numpy(), 300, fork_exact)
+    for l, (A, B) in enumerate(views):
+        assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL, f"B_{l} vs oracle"
+        assert rel(A.cpu().numpy(), oH[2 * l][1]) < RTOL, f"A_{l} vs oracle"
+        assert rel(B.cpu().numpy(), views2[l][1].cpu().numpy()) < 2e-5, f"B_{l} vs the plane route"
+        assert torch.equal(B, B.T)
+    assert abs(float(loss) - float(oloss)) < RTOL * abs(float(oloss))
+    eng.check_async_errors()
+    eng.close()
+
+
+@pytest.mark.parametrize("H,C", [(256, 40), (192, 64)])
+def test_path_route_class_ranges_and_small_workspace(H, C):
+    """Class ranges (the multi-GPU units) are exact shares on the path route too -- ranges of one class, of less and of more
+    than one 32-class MFMA tile, ranges that start in the second tile -- and a workspace cap below one batch's Y cuts the
+    classes into chunks."""
+    N, F, E = 2000, 32, 8000
+    ei, X, Ws, bs = _make("gcn", N, F, H, C, E, L=2, seed=3)
+    g = torch.Generator().manual_seed(6)
+    idx = torch.randperm(N, generator=g)[:400].cuda()
+    y = torch.randint(0, C, (400,), generator=g).cuda()
+    eng = _engine("gcn", N, ei, X, Ws, bs)
+    flat, views, loss = eng.new_kfac_buffers()
+    eng.kfac_accumulate(idx, y, 400, views, loss, paths=True)
+    flat2, v2, l2 = eng.new_kfac_buffers()
+    cuts = [0, 1, 20, 33, 36, C]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        eng.kfac_accumulate(idx, y, 400, v2, l2, classes=(a, b), paths=True)
+    torch.cuda.synchronize()
+    assert rel(flat2.cpu().numpy(), flat.cpu().numpy()) < 1e-5
+    eng.set_workspace_limit(N * H * 4 * 3 + 1024)  # three classes of Y per chunk
+    assert eng.kfac_plan(paths=True)["classes_per_chunk"] == 3
+    flat3, v3, l3 = eng.new_kfac_buffers()
+    eng.kfac_accumulate(idx, y, 400, v3, l3, paths=True)
+    torch.cuda.synchronize()
+    assert rel(flat3.cpu().numpy(), flat.cpu().numpy()) < 1e-5
+    eng.check_async_errors()
+    eng.close()
+
+
+def test_path_route_regression_and_empty_neighbourhoods():
+    """Regression likelihood (V = sqrt(2) I: only the diagonal term survives) and a graph whose nodes are mostly far from the
+    batch (their Y rows are zero but still written: the streaming Gram reads every row)."""
+    import laplace_gnn_amd as lg
+
+    N, F, H, C, E = 2500, 16, 256, 3, 1500  # sparse: most nodes have no 2-hop path to the 40 batch nodes
+    ei, X, Ws, bs = _make("gcn", N, F, H, C, E, L=2, seed=9)
+    g = torch.Generator().manual_seed(2)
+    idx = torch.randperm(N, generator=g)[:40]
+    yr = torch.randn(40, C, generator=g)
+    eng = lg.GraphEngine(ei.cuda(), N, kind="gcn", symmetric=True)
+    eng.bind(X.cuda(), [w.cuda() for w in Ws], [b.cuda() for b in bs], likelihood="regression")
+    om = oracle_from_arrays("gcn", N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], True)
+    for paths in (True, False):
+        _, views, loss = eng.new_kfac_buffers()
+        eng.kfac_accumulate(idx.cuda(), yr.cuda(), 40, views, loss, paths=paths)
+        torch.cuda.synchronize()
+        ol, okf = O.kfac_batch(om, idx.numpy(), yr.numpy(), 40, likelihood="regression")
+        # the oracle applied the interface's factor 0.5 (sqrt(.5) per factor of a weight block); the engine returns raw factors
+        for l, (A, B) in enumerate(views):
+            assert rel(B.cpu().numpy() * np.sqrt(0.5), okf[2 * l][0]) < RTOL, (paths, l)
+    yc = torch.randint(0, C, (40,), generator=g)
+    eng.bind(X.cuda(), [w.cuda() for w in Ws], [b.cuda() for b in bs])
+    _, views, loss = eng.new_kfac_buffers()
+    eng.kfac_accumulate(idx.cuda(), yc.cuda(), 40, views, loss, paths=True)
+    torch.cuda.synchronize()
+    ol, okf = O.kfac_batch(om, idx.numpy(), yc.numpy(), 40)
+    for l, (A, B) in enumerate(views):
+        assert rel(B.cpu().numpy(), okf[2 * l][0]) < RTOL, l
+    eng.check_async_errors()
+    eng.close()
+
+
+def test_streaming_gram_kernel_through_the_path_route_on_a_hub_graph():
+    """A star-like graph: one node adjacent to a third of all nodes (thousands of paths: several 128-path windows and more
+    than one 512-entry row chunk in ybuild_kernel), batch = everything."""
+    N, F, H, C = 1800, 12, 256, 5
+    g = torch.Generator().manual_seed(4)
+    hub = torch.stack([torch.zeros(600, dtype=torch.int64), torch.randperm(N, generator=g)[:600]])
+    ei = torch.cat([hub, torch.randint(0, N, (2, 2500), generator=g)], 1)
+    _, X, Ws, bs = _make("gcn", N, F, H, C, 10, L=2, seed=8)
+    idx = torch.arange(N)
+    y = torch.randint(0, C, (N,), generator=g)
+    eng = _engine("gcn", N, ei, X, Ws, bs)
+    views, loss = kfac_fit_engine(eng, idx.cuda(), y.cuda(), 1000)
+    om = oracle_from_arrays("gcn", N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], True)
+    oloss, oH = O.fit_kron(om, idx.numpy(), y.numpy(), 1000)
+    assert eng.kfac_plan()["paths"]
+    for l, (A, B) in enumerate(views):
+        assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL, f"B_{l}"
+    eng.check_async_errors()
+    eng.close()

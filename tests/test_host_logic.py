@@ -59,9 +59,17 @@ def test_kfac_plan_decisions_without_a_gpu():
     -- decided without allocating anything."""
     from laplace_gnn_amd.engine import kfac_plan
 
-    arxiv = kfac_plan("gcn", [128, 256, 40], 169_343, 2_500_000)
+    arxiv = kfac_plan("gcn", [128, 256, 40], 169_343, 2_500_000, paths=False)
     assert arxiv == {"seeds_on_the_fly": True, "sage_compact": False, "need_pong": False, "classes_per_chunk": 40,
-                     "fused": [False, True], "backgemm": [False, True]}
+                     "fused": [False, True], "backgemm": [False, True], "paths": False}
+    # the headline shape's default: B_0 from the batch's two-hop paths (csrc/paths.hip) -- no planes, no fused kernel
+    assert kfac_plan("gcn", [128, 256, 40], 169_343, 2_500_000, paths=True) == {
+        "seeds_on_the_fly": True, "sage_compact": False, "need_pong": False, "classes_per_chunk": 40,
+        "fused": [False, False], "backgemm": [False, False], "paths": True}
+    for dims in ([128, 128, 40], [128, 256, 70], [128, 256, 256, 40], [128, 254, 40]):  # width, classes, depth, alignment
+        assert not kfac_plan("gcn", dims, 169_343, 2_500_000, paths=True)["paths"], dims
+    assert not kfac_plan("sage", [128, 256, 40], 169_343, 2_500_000, paths=True)["paths"]
+    assert not kfac_plan("gcn", [128, 256, 40], 169_343, 2_500_000, act="tanh", paths=True)["paths"]
     assert kfac_plan("gcn", [128, 256, 40], 169_343, 2_500_000, fuse=False)["need_pong"]
     sage = kfac_plan("sage", [128, 256, 40], 169_343, 2_500_000)
     assert sage["sage_compact"] and sage["fused"] == [False, True] and not sage["need_pong"]
