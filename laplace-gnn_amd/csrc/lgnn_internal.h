@@ -112,6 +112,7 @@ struct Workspace {
   // two-hop path route of the first layer's B (paths.hip): per-sample coefficient rows [M][3][64], the rows (u | p) [2 M][C]
   // and their products with W_1 [2 M][H]; R = P^T[:, batch] as CSR over v (counts / cursors, row pointers, sample, weight)
   DevBuf path_coef, path_up, path_bg, path_cnt, path_rptr, path_rm, path_rw, path_zeros;
+  DevBuf path_pcnt, path_pptr, path_pm, path_pv, path_pw;  // the batch's paths per destination node (CSR over n)
   bool path_zeros_set = false;
   DevBuf gram_scratch_res[kMaxLayers];  // res / norm models: per-call partial B of res.{l} (GCN; GraphSAGE shares the conv's)
   DevBuf planes_c;  // GCN with res, >= 3 layers: u_l Wr_l of the level being computed

@@ -107,9 +107,59 @@ __global__ __launch_bounds__(256) void path_r_kernel(const int64_t* __restrict__
   }
 }
 
+// The batch's 2-hop paths per destination node, materialised once per batch (count, rocPRIM scan, fill): the irregular
+// three-level walk (row of P^T -> R pointers -> R entries) runs here with one wave per node and tens of thousands of waves
+// in flight, so that ybuild_kernel's own chain is just  pointer -> entries -> table rows.
+// One wave per node n:  cnt[n] = sum over the entries (v, pv) of row n of P^T of |R[v]|.
+template <bool FILL>
+__global__ __launch_bounds__(256) void path_list_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                        const float* __restrict__ val, int64_t N,
+                                                        const int32_t* __restrict__ rptr, const int32_t* __restrict__ r_m,
+                                                        const float* __restrict__ r_w, int32_t* __restrict__ pcnt,
+                                                        const int32_t* __restrict__ pptr, int64_t cap,
+                                                        int32_t* __restrict__ pm, int32_t* __restrict__ pv,
+                                                        float* __restrict__ pw) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  if constexpr (FILL) {
+    if (int64_t(pptr[N]) > cap) return;  // the list does not fit its buffer: ybuild enumerates on the fly (same results)
+  }
+  const int32_t s = rowptr[n], e = rowptr[n + 1];
+  int32_t run = FILL ? pptr[n] : 0;
+  for (int32_t base = s; base < e; base += 64) {
+    int32_t v = 0, r0 = 0, cnt = 0;
+    float pval = 0.f;
+    if (base + lane < e) {
+      v = col[base + lane];
+      pval = val[base + lane];
+      r0 = rptr[v];
+      cnt = rptr[v + 1] - r0;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if constexpr (FILL) {
+      const int32_t off = run + incl - cnt;
+      for (int k = 0; k < cnt; ++k) {
+        pm[off + k] = r_m[r0 + k];
+        pv[off + k] = v;
+        pw[off + k] = pval * r_w[r0 + k];
+      }
+    }
+    run += __shfl(incl, 63);
+  }
+  if (!FILL && lane == 0) pcnt[n] = run;
+}
+
 struct YArgs {
   const int32_t* rowptr; const int32_t* col; const float* val;  // P^T
   const int32_t* rptr; const int32_t* r_m; const float* r_w;    // R = P^T[:, batch]
+  const int32_t* pptr; const int32_t* pm; const int32_t* pv; const float* pw;  // the paths per node (when they fit `cap`)
+  int64_t cap;
   const float* coef;        // [M][3][64]
   const float* bg;          // [2 M][H]: rows b_m, then rows g_m
   const uint32_t* mask;     // [N][mask_words] ReLU bits of h_1
@@ -121,32 +171,103 @@ struct YArgs {
   int no_bg;                // regression / nothing but the diagonal term: the beta / gamma products vanish
 };
 
-// One workgroup per node, blockDim = 64 * colgroups * rowtiles: wave (rt, cg) owns the 32-class row tile rt (classes
-// c0 + 32 rt ...) and the columns [64 cg, 64 cg + 64) of Y[n]: two 32 x 32 accumulator tiles for the alpha product and two
-// for the beta / gamma products (64 accumulator registers), so that several workgroups fit a CU and hide the dependent
-// loads of the path enumeration (row of P^T -> R pointers -> R entries -> table rows).  Waves w and w + 4 (the two row
-// tiles of one column group) share a SIMD.
+constexpr int kWin = 16;  // paths staged per window: 16 x (2 x 1 KiB table rows + 768 B coefficients + 32 B mask) = 45 KiB
+
+struct YShared {
+  float bg[kWin][2][256];     // b_m * mask_v, g_m * mask_v
+  float coef[kWin][3][kCoefStride];  // w_j * (alpha, -beta, -gamma)
+  uint32_t mask[kWin][8];
+  int32_t m[kPathWindow], v[kPathWindow];  // on-the-fly enumeration only: the window's triples
+  float w[kPathWindow];
+  int32_t scan[8];
+};
+
+// Stage paths [j0, j0 + kw) (kw <= kWin) given by get(j) -> (m, v, w) into LDS: every thread issues all its loads at once
+// (full 16-byte pieces of the 1 KiB table rows), the mask and the weight are applied on the way in.
+template <class Get>
+__device__ __forceinline__ void stage_window(const YArgs& a, YShared& sh, int kw, int tid, int nthreads, Get get) {
+  const int H = a.H;
+  const int kw2 = (kw + 1) & ~1;  // the last MFMA step reads an even number of paths: zero the odd one out
+  for (int q = tid; q < kw2 * 128; q += nthreads) {       // b / g rows: 64 float4 each
+    const int j = q >> 7, part = (q >> 6) & 1, c4 = q & 63;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < kw && 4 * c4 < H && !a.no_bg) {
+      int32_t mj, vj; float wj;
+      get(j, mj, vj, wj);
+      const float4 t = *reinterpret_cast<const float4*>(a.bg + ((part ? a.M : 0) + int64_t(mj)) * H + 4 * c4);
+      const uint32_t bits = a.mask[int64_t(vj) * a.mask_words + (c4 >> 3)] >> ((4 * c4) & 31);
+      x.x = (bits & 1u) ? t.x : 0.f; x.y = (bits & 2u) ? t.y : 0.f;
+      x.z = (bits & 4u) ? t.z : 0.f; x.w = (bits & 8u) ? t.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(&sh.bg[j][part][4 * c4]) = x;
+  }
+  for (int q = tid; q < kw2 * 48; q += nthreads) {        // coefficient rows: 3 x 16 float4
+    const int j = q / 48, r = q - j * 48;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < kw) {
+      int32_t mj, vj; float wj;
+      get(j, mj, vj, wj);
+      const float4 t = *reinterpret_cast<const float4*>(a.coef + int64_t(mj) * 3 * kCoefStride + 4 * r);
+      x = make_float4(wj * t.x, wj * t.y, wj * t.z, wj * t.w);
+    }
+    *reinterpret_cast<float4*>(&sh.coef[j][0][0] + 4 * r) = x;
+  }
+  for (int q = tid; q < kw2 * 8; q += nthreads) {         // mask words (the alpha product's B operand)
+    const int j = q >> 3, wd = q & 7;
+    uint32_t word = 0;
+    if (j < kw && wd < a.mask_words) {
+      int32_t mj, vj; float wj;
+      get(j, mj, vj, wj);
+      word = a.mask[int64_t(vj) * a.mask_words + wd];
+    }
+    sh.mask[j][wd] = word;
+  }
+}
+
+// The three products of one staged window: wave (rt, cg), lane l: A row i = l & 31 (class), B column = l & 31, k = l >> 5.
+__device__ __forceinline__ void mfma_window(const YShared& sh, int kw, int cls, const int (&colv)[2], const bool (&col_ok)[2],
+                                            int half, bool no_bg, f32x16 (&t1)[2], f32x16 (&y2)[2]) {
+  for (int ks = 0; 2 * ks < kw; ++ks) {
+    const int j = 2 * ks + half;
+    const float aa = sh.coef[j][0][cls], ab = sh.coef[j][1][cls], ag = sh.coef[j][2][cls];
+    float mf[2], bb[2], gg[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const uint32_t word = sh.mask[j][colv[ct] >> 5];
+      mf[ct] = (col_ok[ct] && ((word >> (colv[ct] & 31)) & 1u)) ? 1.f : 0.f;
+      bb[ct] = sh.bg[j][0][colv[ct]];
+      gg[ct] = sh.bg[j][1][colv[ct]];
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      t1[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, mf[ct], t1[ct], 0, 0, 0);
+      if (!no_bg) {
+        y2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab, bb[ct], y2[ct], 0, 0, 0);
+        y2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag, gg[ct], y2[ct], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// One workgroup per node (LIST) or a grid-stride loop over nodes (!LIST), blockDim = 64 * colgroups * rowtiles: wave (rt, cg)
+// owns the 32-class row tile rt (classes c0 + 32 rt ...) and the columns [64 cg, 64 cg + 64) of Y[n]: two 32 x 32
+// accumulator tiles for the alpha product and two for the beta / gamma products (64 accumulator registers); waves w and
+// w + 4 (the two row tiles of one column group) share a SIMD.  Two workgroups per CU: one stages while the other multiplies.
+// LIST: the node's paths come from the per-batch list.  !LIST (the list did not fit its buffer: very large batches on
+// hub-heavy graphs): the paths are enumerated here -- block scan over the neighbours' R lists, windows of 128 triples in LDS.
+template <bool LIST>
 __global__ __launch_bounds__(512, 4) void ybuild_kernel(YArgs a) {
-  __shared__ int32_t s_m[kPathWindow];
-  __shared__ int32_t s_v[kPathWindow];
-  __shared__ float s_w[kPathWindow];
-  __shared__ int32_t s_scan[8];
+  __shared__ YShared sh;
+  const bool overflow = int64_t(a.pptr[a.N]) > a.cap;
+  if (overflow == LIST) return;  // exactly one of the two launches does the work
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nthreads = blockDim.x, nwaves = nthreads >> 6;
   const int ncg = (a.H + 63) >> 6;          // column groups
   const int cg = wave % ncg, rt = wave / ncg;
-  const int64_t n = blockIdx.x;
   const int H = a.H;
-
-  f32x16 t1[2], y2[2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
-
-  // class of this lane's A-operand row (i = lane & 31), clamped into the zero-padded coefficient row
-  const bool cls_ok = 32 * rt + li < a.R;
+  // class of this lane's A-operand row (i = lane & 31), clamped into the zero-padded coefficient row; rows past the class
+  // range are computed on whatever sits there and never stored
   const int cls = min(a.c0 + 32 * rt + li, kCoefStride - 1);
   int colv[2];
   bool col_ok[2];
@@ -157,89 +278,94 @@ __global__ __launch_bounds__(512, 4) void ybuild_kernel(YArgs a) {
     if (!col_ok[ct]) colv[ct] = 0;
   }
 
-  const int32_t rs = a.rowptr[n], re = a.rowptr[n + 1];
-  for (int32_t base = rs; base < re; base += nthreads) {
-    // ---- this thread's neighbour v and the extent of its batch list R[v]
-    int32_t v = 0, r0 = 0, cnt = 0;
-    float pv = 0.f;
-    if (base + tid < re) {
-      v = a.col[base + tid];
-      pv = a.val[base + tid];
-      r0 = a.rptr[v];
-      cnt = a.rptr[v + 1] - r0;
-    }
-    // ---- block-wide exclusive scan of cnt
-    int incl = cnt;
+  // LIST: one node per workgroup (grid = N); !LIST: a grid-stride loop (its launch must cost nothing when it has nothing to do)
+  for (int64_t n = blockIdx.x; n < (LIST ? int64_t(blockIdx.x) + 1 : a.N); n += gridDim.x) {
+    f32x16 t1[2], y2[2];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) s_scan[wave] = incl;
-    __syncthreads();
-    int woff = 0, total = 0;
-    for (int w = 0; w < nwaves; ++w) {
-      const int sw = s_scan[w];
-      if (w < wave) woff += sw;
-      total += sw;
-    }
-    const int off = woff + incl - cnt;
-    __syncthreads();  // s_scan is rewritten by the next row chunk
-    // ---- windows of kPathWindow paths
-    for (int wb = 0; wb < total; wb += kPathWindow) {
-      const int lo = max(off, wb), hi = min(off + cnt, wb + kPathWindow);
-      for (int j = lo; j < hi; ++j) {
-        const int k = j - off;
-        s_m[j - wb] = a.r_m[r0 + k];
-        s_w[j - wb] = pv * a.r_w[r0 + k];
-        s_v[j - wb] = v;
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
+
+    if constexpr (LIST) {
+      const int32_t p0 = a.pptr[n], p1 = a.pptr[n + 1];
+      for (int32_t wb = p0; wb < p1; wb += kWin) {
+        const int kw = min(kWin, p1 - wb);
+        if (wb > p0) __syncthreads();  // the previous window's operands are still being read
+        stage_window(a, sh, kw, tid, nthreads, [&](int j, int32_t& mj, int32_t& vj, float& wj) {
+          mj = a.pm[wb + j]; vj = a.pv[wb + j]; wj = a.pw[wb + j];
+        });
+        __syncthreads();
+        mfma_window(sh, kw, cls, colv, col_ok, half, a.no_bg != 0, t1, y2);
       }
-      __syncthreads();
-      const int kw = min(kPathWindow, total - wb);
-      for (int ks = 0; 2 * ks < kw; ++ks) {
-        const int j = 2 * ks + half;  // MFMA k index = lane >> 5: the two paths of this step
-        const bool valid = j < kw;
-        const int32_t mj = valid ? s_m[j] : 0;
-        const int32_t vj = valid ? s_v[j] : 0;
-        const float wk = (valid && cls_ok) ? s_w[j] : 0.f;
-        const float* __restrict__ cm = a.coef + int64_t(mj) * 3 * kCoefStride + cls;
-        const float aa = wk * cm[0];
-        const float ab = wk * cm[kCoefStride];
-        const float ag = wk * cm[2 * kCoefStride];
-        float mf[2], bb[2], gg[2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          const uint32_t word = a.mask[int64_t(vj) * a.mask_words + (colv[ct] >> 5)];
-          mf[ct] = (col_ok[ct] && ((word >> (colv[ct] & 31)) & 1u)) ? 1.f : 0.f;
-          bb[ct] = a.no_bg ? 0.f : mf[ct] * a.bg[int64_t(mj) * H + colv[ct]];
-          gg[ct] = a.no_bg ? 0.f : mf[ct] * a.bg[(a.M + int64_t(mj)) * H + colv[ct]];
+    } else {
+      const int32_t rs = a.rowptr[n], re = a.rowptr[n + 1];
+      for (int32_t base = rs; base < re; base += nthreads) {
+        // ---- this thread's neighbour v and the extent of its batch list R[v]
+        int32_t v = 0, r0 = 0, cnt = 0;
+        float pv = 0.f;
+        if (base + tid < re) {
+          v = a.col[base + tid];
+          pv = a.val[base + tid];
+          r0 = a.rptr[v];
+          cnt = a.rptr[v + 1] - r0;
         }
+        // ---- block-wide exclusive scan of cnt
+        int incl = cnt;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          t1[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, mf[ct], t1[ct], 0, 0, 0);
-          if (!a.no_bg) {
-            y2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab, bb[ct], y2[ct], 0, 0, 0);
-            y2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag, gg[ct], y2[ct], 0, 0, 0);
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(incl, o);
+          if (lane >= o) incl += t;
+        }
+        __syncthreads();  // sh.scan / the triples of the previous chunk are still being read
+        if (lane == 63) sh.scan[wave] = incl;
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < nwaves; ++w) {
+          const int sw = sh.scan[w];
+          if (w < wave) woff += sw;
+          total += sw;
+        }
+        const int off = woff + incl - cnt;
+        // ---- windows of kPathWindow triples, each consumed kWin paths at a time
+        for (int wb = 0; wb < total; wb += kPathWindow) {
+          __syncthreads();
+          const int lo = max(off, wb), hi = min(off + cnt, wb + kPathWindow);
+          for (int j = lo; j < hi; ++j) {
+            const int k = j - off;
+            sh.m[j - wb] = a.r_m[r0 + k];
+            sh.w[j - wb] = pv * a.r_w[r0 + k];
+            sh.v[j - wb] = v;
+          }
+          __syncthreads();
+          const int kall = min(kPathWindow, total - wb);
+          for (int sb = 0; sb < kall; sb += kWin) {
+            const int kw = min(kWin, kall - sb);
+            if (sb > 0) __syncthreads();
+            stage_window(a, sh, kw, tid, nthreads, [&](int j, int32_t& mj, int32_t& vj, float& wj) {
+              mj = sh.m[sb + j]; vj = sh.v[sb + j]; wj = sh.w[sb + j];
+            });
+            __syncthreads();
+            mfma_window(sh, kw, cls, colv, col_ok, half, a.no_bg != 0, t1, y2);
           }
         }
       }
-      __syncthreads();  // the next window overwrites the path arrays
     }
-  }
 
-  // ---- Y[n][c - c0][col] = W_1[c][col] * T1 + Y2   (C / D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-  float* __restrict__ yn = a.Y + n * int64_t(a.R) * H;
+    // ---- Y[n][c - c0][col] = W_1[c][col] * T1 + Y2   (C / D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+    float* __restrict__ yn = a.Y + n * int64_t(a.R) * H;
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int colc = 64 * cg + 32 * ct + li;
+    for (int ct = 0; ct < 2; ++ct) {
+      const int colc = 64 * cg + 32 * ct + li;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (row < a.R && colc < H) {
-        const float w1 = a.W1[int64_t(a.c0 + row) * H + colc];
-        yn[int64_t(row) * H + colc] = w1 * t1[ct][r] + y2[ct][r];
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < a.R && colc < H) {
+          const float w1 = a.W1[int64_t(a.c0 + row) * H + colc];
+          yn[int64_t(row) * H + colc] = w1 * t1[ct][r] + y2[ct][r];
+        }
       }
     }
+    if (!LIST) __syncthreads();  // the next node restages the shared buffers
   }
 }
 
@@ -414,6 +540,24 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
                      ws.mult.as<int32_t>(), h->P.rowptr, h->P.col, h->P.val, ws.path_cnt.as<int32_t>(),
                      ws.path_rptr.as<int32_t>(), ws.path_rm.as<int32_t>(), ws.path_rw.as<float>());
   LGNN_HIP_CHECK(hipGetLastError());
+  // ---- the paths of every destination node: count (one wave per node), scan, fill -- when they fit the buffer
+  const int64_t cap = std::max<int64_t>(4 * h->nnz, int64_t(1) << 22);  // (arxiv shape: 2.2 M paths per batch of 10 000)
+  LGNN_CALL(ws.path_pcnt.reserve(size_t(N + 1) * 4));
+  LGNN_CALL(ws.path_pptr.reserve(size_t(N + 1) * 4));
+  LGNN_CALL(ws.path_pm.reserve(size_t(cap) * 4));
+  LGNN_CALL(ws.path_pv.reserve(size_t(cap) * 4));
+  LGNN_CALL(ws.path_pw.reserve(size_t(cap) * 4));
+  LGNN_HIP_CHECK(hipMemsetAsync(ws.path_pcnt.as<int32_t>() + N, 0, 4, s));
+  const dim3 pgrid{unsigned(cdiv(N, 4))};
+  hipLaunchKernelGGL(path_list_kernel<false>, pgrid, dim3(256), 0, s, h->PT.rowptr, h->PT.col, h->PT.val, N,
+                     ws.path_rptr.as<int32_t>(), ws.path_rm.as<int32_t>(), ws.path_rw.as<float>(), ws.path_pcnt.as<int32_t>(),
+                     static_cast<const int32_t*>(nullptr), cap, static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
+                     static_cast<float*>(nullptr));
+  LGNN_CALL(exclusive_scan_i32(ws.path_pcnt.as<int32_t>(), ws.path_pptr.as<int32_t>(), N + 1, ws.select_tmp, s));
+  hipLaunchKernelGGL(path_list_kernel<true>, pgrid, dim3(256), 0, s, h->PT.rowptr, h->PT.col, h->PT.val, N,
+                     ws.path_rptr.as<int32_t>(), ws.path_rm.as<int32_t>(), ws.path_rw.as<float>(), ws.path_pcnt.as<int32_t>(),
+                     ws.path_pptr.as<int32_t>(), cap, ws.path_pm.as<int32_t>(), ws.path_pv.as<int32_t>(), ws.path_pw.as<float>());
+  LGNN_HIP_CHECK(hipGetLastError());
   // ---- class chunks under the workspace cap: Y [N][R][H], then the streaming Gram
   const int64_t per_class = N * H * 4;
   const int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(ce - cb, h->ws_limit / std::max<int64_t>(per_class, 1)));
@@ -425,12 +569,16 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     YArgs y{};
     y.rowptr = h->PT.rowptr; y.col = h->PT.col; y.val = h->PT.val;
     y.rptr = ws.path_rptr.as<int32_t>(); y.r_m = ws.path_rm.as<int32_t>(); y.r_w = ws.path_rw.as<float>();
+    y.pptr = ws.path_pptr.as<int32_t>(); y.pm = ws.path_pm.as<int32_t>(); y.pv = ws.path_pv.as<int32_t>();
+    y.pw = ws.path_pw.as<float>(); y.cap = cap;
     y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>();
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
     y.W1 = h->W[1]; y.Y = ws.planes_a.as<float>(); y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
     const unsigned threads = unsigned(64 * cdiv(H, 64) * cdiv(R, 32));  // (column groups) x (32-class row tiles) waves
-    hipLaunchKernelGGL(ybuild_kernel, dim3(unsigned(N)), dim3(threads), 0, s, y);
+    hipLaunchKernelGGL(ybuild_kernel<true>, dim3(unsigned(N)), dim3(threads), 0, s, y);
+    // (returns at once unless the path list overflowed its buffer: then this launch does the work, enumerating on the fly)
+    hipLaunchKernelGGL(ybuild_kernel<false>, dim3(unsigned(std::min<int64_t>(N, 1024))), dim3(threads), 0, s, y);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the KFAC path (bench.py roofline)
     LGNN_CALL(launch_gram256_stream(y.Y, N * R, H, scratch, ws.path_zeros.as<float>(), s));

@@ -36,9 +36,12 @@ def test_path_route_vs_oracle_and_plane_route(H, C, skew, fork_exact):
     om = oracle_from_arrays("gcn", N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], True)
     oloss, oH = O.fit_kron(om, idx.numpy(), y.numpy(), 300, fork_exact)
     for l, (A, B) in enumerate(views):
-        assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL, f"B_{l} vs oracle"
+        if C == 1:  # one class: the seed is exactly zero (p = 1); the path route leaves fp32 cancellation residue, not zeros
+            assert float(B.abs().max()) < 1e-10 and float(np.abs(oH[2 * l][0]).max()) == 0.0
+        else:
+            assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL, f"B_{l} vs oracle"
+            assert rel(B.cpu().numpy(), views2[l][1].cpu().numpy()) < 2e-5, f"B_{l} vs the plane route"
         assert rel(A.cpu().numpy(), oH[2 * l][1]) < RTOL, f"A_{l} vs oracle"
-        assert rel(B.cpu().numpy(), views2[l][1].cpu().numpy()) < 2e-5, f"B_{l} vs the plane route"
         assert torch.equal(B, B.T)
     assert abs(float(loss) - float(oloss)) < RTOL * abs(float(oloss))
     eng.check_async_errors()
