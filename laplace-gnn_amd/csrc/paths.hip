@@ -43,6 +43,7 @@ namespace lgnn {
 namespace {
 
 constexpr int kCoefStride = 64;  // classes per coefficient row (zero padded): two 32-row MFMA tiles
+constexpr int kCoefRow = 256;    // floats per sample in the coefficient table: (alpha | -beta | -gamma | pad) = 1 KiB, one LDS-DMA piece
 constexpr int kPathWindow = 128; // paths staged in LDS per accumulation window
 
 __device__ __forceinline__ float wsum(float v) {
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void path_tables_kernel(const float* __restric
   const int64_t m = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
   const int64_t n = idx[m];
-  float* __restrict__ cm = coef + m * 3 * kCoefStride;
+  float* __restrict__ cm = coef + m * kCoefRow;
   float* __restrict__ um = up + m * C;
   float* __restrict__ pm = up + (M + m) * C;
   const bool own = n >= 0 && n < N && pos[n] == int32_t(m);
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256) void path_tables_kernel(const float* __restric
   cm[lane] = al;                       // lanes >= C write the zero padding
   cm[kCoefStride + lane] = -be;
   cm[2 * kCoefStride + lane] = -ga;
+  cm[3 * kCoefStride + lane] = 0.f;
   if (lane < C) { um[lane] = u; pm[lane] = own ? pk : 0.f; }
 }
 
@@ -160,7 +162,8 @@ struct YArgs {
   const int32_t* rptr; const int32_t* r_m; const float* r_w;    // R = P^T[:, batch]
   const int32_t* pptr; const int32_t* pm; const int32_t* pv; const float* pw;  // the paths per node (when they fit `cap`)
   int64_t cap;
-  const float* coef;        // [M][3][64]
+  const float* coef;        // [M][256]: (alpha | -beta | -gamma | 0) x 64 classes
+  const float* zeros;       // >= 1 KiB of zeros
   const float* bg;          // [2 M][H]: rows b_m, then rows g_m
   const uint32_t* mask;     // [N][mask_words] ReLU bits of h_1
   int mask_words;
@@ -171,57 +174,49 @@ struct YArgs {
   int no_bg;                // regression / nothing but the diagonal term: the beta / gamma products vanish
 };
 
-constexpr int kWin = 16;  // paths staged per window: 16 x (2 x 1 KiB table rows + 768 B coefficients + 32 B mask) = 45 KiB
+constexpr int kWin = 16;  // paths staged per window: 16 x (2 x 1 KiB table rows + 1 KiB coefficients + 32 B mask) = 48.5 KiB
 
 struct YShared {
-  float bg[kWin][2][256];     // b_m * mask_v, g_m * mask_v
-  float coef[kWin][3][kCoefStride];  // w_j * (alpha, -beta, -gamma)
+  float bg[kWin][2][256];       // rows b_m, g_m as they sit in the table (the mask is applied when they are read)
+  float coef[kWin][kCoefRow];   // (alpha | -beta | -gamma | 0) of the path's sample (the path weight is applied when read)
   uint32_t mask[kWin][8];
-  int32_t m[kPathWindow], v[kPathWindow];  // on-the-fly enumeration only: the window's triples
-  float w[kPathWindow];
+  int32_t m[kWin], v[kWin];     // the staged window's triples
+  float w[kWin];
+  int32_t fm[kPathWindow], fv[kPathWindow];  // on-the-fly enumeration only: up to kPathWindow triples of the row chunk
+  float fw[kPathWindow];
   int32_t scan[8];
 };
 
-// Stage paths [j0, j0 + kw) (kw <= kWin) given by get(j) -> (m, v, w) into LDS: every thread issues all its loads at once
-// (full 16-byte pieces of the 1 KiB table rows), the mask and the weight are applied on the way in.
-template <class Get>
-__device__ __forceinline__ void stage_window(const YArgs& a, YShared& sh, int kw, int tid, int nthreads, Get get) {
-  const int H = a.H;
-  const int kw2 = (kw + 1) & ~1;  // the last MFMA step reads an even number of paths: zero the odd one out
-  for (int q = tid; q < kw2 * 128; q += nthreads) {       // b / g rows: 64 float4 each
-    const int j = q >> 7, part = (q >> 6) & 1, c4 = q & 63;
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < kw && 4 * c4 < H && !a.no_bg) {
-      int32_t mj, vj; float wj;
-      get(j, mj, vj, wj);
-      const float4 t = *reinterpret_cast<const float4*>(a.bg + ((part ? a.M : 0) + int64_t(mj)) * H + 4 * c4);
-      const uint32_t bits = a.mask[int64_t(vj) * a.mask_words + (c4 >> 3)] >> ((4 * c4) & 31);
-      x.x = (bits & 1u) ? t.x : 0.f; x.y = (bits & 2u) ? t.y : 0.f;
-      x.z = (bits & 4u) ? t.z : 0.f; x.w = (bits & 8u) ? t.w : 0.f;
-    }
-    *reinterpret_cast<float4*>(&sh.bg[j][part][4 * c4]) = x;
-  }
-  for (int q = tid; q < kw2 * 48; q += nthreads) {        // coefficient rows: 3 x 16 float4
-    const int j = q / 48, r = q - j * 48;
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+__device__ __forceinline__ void lds_dma16(const float* src, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                            reinterpret_cast<uintptr_t>(lds_dst)), 16, 0, 0);
+}
+
+// Stage the window's kw <= kWin paths, whose triples (m, v, w) sit in sh.m / sh.v / sh.w, into LDS by LDS-DMA: three 1 KiB
+// pieces per path (row b_m, row g_m, the coefficient row), one wave instruction each, no data registers -- the accumulators
+// of a node with several windows stay where they are.  The caller waits (vmcnt(0) + barrier) before the products read.
+__device__ __forceinline__ void stage_window(const YArgs& a, YShared& sh, int kw, int tid, int wave, int nwaves, int lane) {
+  const int kw2 = (kw + 1) & ~1;  // the last MFMA step reads an even number of paths: the odd one out is staged as zeros
+  const bool lane_ok = 4 * lane < a.H;
+  const int npieces = kw2 * 3;
+  for (int q = wave; q < npieces; q += nwaves) {   // q, j, kind are wave uniform
+    const int j = q / 3, kind = q - 3 * j;
+    const float* src = a.zeros;
+    float* dst = kind < 2 ? &sh.bg[j][kind][0] : &sh.coef[j][0];
     if (j < kw) {
-      int32_t mj, vj; float wj;
-      get(j, mj, vj, wj);
-      const float4 t = *reinterpret_cast<const float4*>(a.coef + int64_t(mj) * 3 * kCoefStride + 4 * r);
-      x = make_float4(wj * t.x, wj * t.y, wj * t.z, wj * t.w);
+      const int64_t mj = __builtin_amdgcn_readfirstlane(sh.m[j]);
+      if (kind == 2) src = a.coef + mj * kCoefRow + 4 * lane;
+      else if (lane_ok && !a.no_bg) src = a.bg + ((kind ? a.M : 0) + mj) * a.H + 4 * lane;
     }
-    *reinterpret_cast<float4*>(&sh.coef[j][0][0] + 4 * r) = x;
+    lds_dma16(src, dst);
   }
-  for (int q = tid; q < kw2 * 8; q += nthreads) {         // mask words (the alpha product's B operand)
-    const int j = q >> 3, wd = q & 7;
-    uint32_t word = 0;
-    if (j < kw && wd < a.mask_words) {
-      int32_t mj, vj; float wj;
-      get(j, mj, vj, wj);
-      word = a.mask[int64_t(vj) * a.mask_words + wd];
-    }
-    sh.mask[j][wd] = word;
+  if (tid < kw2 * 8) {
+    const int j = tid >> 3, wd = tid & 7;
+    uint32_t wm = 0;
+    if (j < kw && wd < a.mask_words) wm = a.mask[int64_t(sh.v[j]) * a.mask_words + wd];
+    sh.mask[j][wd] = wm;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // The three products of one staged window: wave (rt, cg), lane l: A row i = l & 31 (class), B column = l & 31, k = l >> 5.
@@ -229,14 +224,15 @@ __device__ __forceinline__ void mfma_window(const YShared& sh, int kw, int cls, 
                                             int half, bool no_bg, f32x16 (&t1)[2], f32x16 (&y2)[2]) {
   for (int ks = 0; 2 * ks < kw; ++ks) {
     const int j = 2 * ks + half;
-    const float aa = sh.coef[j][0][cls], ab = sh.coef[j][1][cls], ag = sh.coef[j][2][cls];
+    const float wj = j < kw ? sh.w[j] : 0.f;
+    const float aa = wj * sh.coef[j][cls], ab = wj * sh.coef[j][kCoefStride + cls], ag = wj * sh.coef[j][2 * kCoefStride + cls];
     float mf[2], bb[2], gg[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const uint32_t word = sh.mask[j][colv[ct] >> 5];
       mf[ct] = (col_ok[ct] && ((word >> (colv[ct] & 31)) & 1u)) ? 1.f : 0.f;
-      bb[ct] = sh.bg[j][0][colv[ct]];
-      gg[ct] = sh.bg[j][1][colv[ct]];
+      bb[ct] = mf[ct] * sh.bg[j][0][colv[ct]];
+      gg[ct] = mf[ct] * sh.bg[j][1][colv[ct]];
     }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -291,9 +287,9 @@ __global__ __launch_bounds__(512, 4) void ybuild_kernel(YArgs a) {
       for (int32_t wb = p0; wb < p1; wb += kWin) {
         const int kw = min(kWin, p1 - wb);
         if (wb > p0) __syncthreads();  // the previous window's operands are still being read
-        stage_window(a, sh, kw, tid, nthreads, [&](int j, int32_t& mj, int32_t& vj, float& wj) {
-          mj = a.pm[wb + j]; vj = a.pv[wb + j]; wj = a.pw[wb + j];
-        });
+        if (tid < kw) { sh.m[tid] = a.pm[wb + tid]; sh.v[tid] = a.pv[wb + tid]; sh.w[tid] = a.pw[wb + tid]; }
+        __syncthreads();
+        stage_window(a, sh, kw, tid, wave, nwaves, lane);
         __syncthreads();
         mfma_window(sh, kw, cls, colv, col_ok, half, a.no_bg != 0, t1, y2);
       }
@@ -332,18 +328,18 @@ __global__ __launch_bounds__(512, 4) void ybuild_kernel(YArgs a) {
           const int lo = max(off, wb), hi = min(off + cnt, wb + kPathWindow);
           for (int j = lo; j < hi; ++j) {
             const int k = j - off;
-            sh.m[j - wb] = a.r_m[r0 + k];
-            sh.w[j - wb] = pv * a.r_w[r0 + k];
-            sh.v[j - wb] = v;
+            sh.fm[j - wb] = a.r_m[r0 + k];
+            sh.fw[j - wb] = pv * a.r_w[r0 + k];
+            sh.fv[j - wb] = v;
           }
           __syncthreads();
           const int kall = min(kPathWindow, total - wb);
           for (int sb = 0; sb < kall; sb += kWin) {
             const int kw = min(kWin, kall - sb);
             if (sb > 0) __syncthreads();
-            stage_window(a, sh, kw, tid, nthreads, [&](int j, int32_t& mj, int32_t& vj, float& wj) {
-              mj = sh.m[sb + j]; vj = sh.v[sb + j]; wj = sh.w[sb + j];
-            });
+            if (tid < kw) { sh.m[tid] = sh.fm[sb + tid]; sh.v[tid] = sh.fv[sb + tid]; sh.w[tid] = sh.fw[sb + tid]; }
+            __syncthreads();
+            stage_window(a, sh, kw, tid, wave, nwaves, lane);
             __syncthreads();
             mfma_window(sh, kw, cls, colv, col_ok, half, a.no_bg != 0, t1, y2);
           }
@@ -352,17 +348,22 @@ __global__ __launch_bounds__(512, 4) void ybuild_kernel(YArgs a) {
     }
 
     // ---- Y[n][c - c0][col] = W_1[c][col] * T1 + Y2   (C / D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+    // (32-bit offsets from two uniform bases; `late` ties the address arithmetic to this point of the program -- hipcc
+    //  otherwise computes all 64 addresses at the top of the kernel and spills them around the products)
+    int late = 0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(late));  // a value that exists only from here on
     float* __restrict__ yn = a.Y + n * int64_t(a.R) * H;
+    const float* __restrict__ w1p = a.W1 + int64_t(a.c0) * H;
+    const int row0 = 32 * rt + 4 * half + late;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const int colc = 64 * cg + 32 * ct + li;
+      const bool cok = colc < H;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < a.R && colc < H) {
-          const float w1 = a.W1[int64_t(a.c0 + row) * H + colc];
-          yn[int64_t(row) * H + colc] = w1 * t1[ct][r] + y2[ct][r];
-        }
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        const int o = row * H + colc;
+        if (cok && row < a.R) yn[o] = w1p[o] * t1[ct][r] + y2[ct][r];
       }
     }
     if (!LIST) __syncthreads();  // the next node restages the shared buffers
@@ -508,7 +509,7 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
   Workspace& ws = h->ws;
   LGNN_REQUIRE(paths_supported(h->kind, h->L, h->dims, h->act, h->nnz), "internal: path route on an unsupported model");
   // ---- per-sample tables and b_m / g_m
-  LGNN_CALL(ws.path_coef.reserve(size_t(M) * 3 * kCoefStride * 4));
+  LGNN_CALL(ws.path_coef.reserve(size_t(M) * kCoefRow * 4));
   LGNN_CALL(ws.path_up.reserve(size_t(2 * M) * C * 4));
   LGNN_CALL(ws.path_bg.reserve(size_t(2 * M) * H * 4));
   hipLaunchKernelGGL(path_tables_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, ws.probs.as<float>(),
@@ -525,9 +526,9 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
   LGNN_CALL(ws.path_rptr.reserve(size_t(N + 1) * 4));
   LGNN_CALL(ws.path_rm.reserve(size_t(std::max<int64_t>(h->nnz, 1)) * 4));
   LGNN_CALL(ws.path_rw.reserve(size_t(std::max<int64_t>(h->nnz, 1)) * 4));
-  LGNN_CALL(ws.path_zeros.reserve(256));
+  LGNN_CALL(ws.path_zeros.reserve(1024));
   if (!ws.path_zeros_set) {
-    LGNN_HIP_CHECK(hipMemsetAsync(ws.path_zeros.p, 0, 256, s));
+    LGNN_HIP_CHECK(hipMemsetAsync(ws.path_zeros.p, 0, 1024, s));
     ws.path_zeros_set = true;
   }
   LGNN_HIP_CHECK(hipMemsetAsync(ws.path_cnt.p, 0, size_t(N + 1) * 4, s));
@@ -571,7 +572,7 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.rptr = ws.path_rptr.as<int32_t>(); y.r_m = ws.path_rm.as<int32_t>(); y.r_w = ws.path_rw.as<float>();
     y.pptr = ws.path_pptr.as<int32_t>(); y.pm = ws.path_pm.as<int32_t>(); y.pv = ws.path_pv.as<int32_t>();
     y.pw = ws.path_pw.as<float>(); y.cap = cap;
-    y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>();
+    y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>(); y.zeros = ws.path_zeros.as<float>();
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
     y.W1 = h->W[1]; y.Y = ws.planes_a.as<float>(); y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
