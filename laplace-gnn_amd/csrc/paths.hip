@@ -25,10 +25,13 @@
 //   path_tables_kernel   per-sample coefficient rows (alpha, -beta, -gamma) and the rows (u, p) whose product with W_1 (one
 //                        small GEMM, kernels.hip) gives b_m, g_m
 //   path_count / fill    R = P^T[:, batch] as CSR over v (counting sort: count, rocPRIM scan, fill): the batch neighbours of v
-//   ybuild_kernel        one workgroup per node, one wave per (32 classes x 64 columns): enumerate the node's paths into LDS (block scan over
-//                        its neighbours' R lists, windows of 128 paths), accumulate the three products with
-//                        v_mfma_f32_32x32x2_f32 (A = coefficient rows, B = mask / masked table rows, 128-byte operand rows
-//                        straight from L2), fold W_1 in, stream Y[n] (R x H floats, contiguous) to HBM     -- HBM write bound
+//   path_list_kernel     the batch's 2-hop paths per destination node as CSR over n (count, rocPRIM scan, fill; one wave per node)
+//   ybuild_pipe_kernel   one persistent workgroup per CU, one wave per (32 classes x 64 columns): per node, windows of 16 paths
+//                        whose operands (rows b_m, g_m, coefficient rows: 1 KiB each) arrive by LDS-DMA into a double buffer
+//                        one node ahead of the products; three products per window on v_mfma_f32_32x32x2_f32 (A = weighted
+//                        coefficient rows, B = mask bits / masked table rows, all from LDS), W_1 folded in from registers,
+//                        Y[n] (R x H floats, contiguous) streamed to HBM                      -- fp32 MFMA / HBM write bound
+//   ybuild_kernel        the same products with the paths enumerated on the fly (taken only when the path list does not fit)
 //   gram256_stream_kernel  S += Y^T Y over N*R rows of 1 KiB: one persistent 512-thread workgroup per CU, ALL EIGHT waves on
 //                        the matrix pipes (36 upper 32 x 32 sub-tiles dealt 5 + 4 to the two waves of a SIMD), row blocks of
 //                        32 rows arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, issued by the MFMA
@@ -176,15 +179,14 @@ struct YArgs {
 
 constexpr int kWin = 16;  // paths staged per window: 16 x (2 x 1 KiB table rows + 1 KiB coefficients + 32 B mask) = 48.5 KiB
 
-struct YShared {
+struct YWin {
   float bg[kWin][2][256];       // rows b_m, g_m as they sit in the table (the mask is applied when they are read)
   float coef[kWin][kCoefRow];   // (alpha | -beta | -gamma | 0) of the path's sample (the path weight is applied when read)
-  uint32_t mask[kWin][8];
-  int32_t m[kWin], v[kWin];     // the staged window's triples
+  uint32_t mask[kWin][8];       // ReLU bits of the path's middle node v
+};
+struct YMeta {                  // the window's triples
+  int32_t m[kWin], v[kWin];
   float w[kWin];
-  int32_t fm[kPathWindow], fv[kPathWindow];  // on-the-fly enumeration only: up to kPathWindow triples of the row chunk
-  float fw[kPathWindow];
-  int32_t scan[8];
 };
 
 __device__ __forceinline__ void lds_dma16(const float* src, float* lds_dst) {
@@ -192,47 +194,44 @@ __device__ __forceinline__ void lds_dma16(const float* src, float* lds_dst) {
                                             reinterpret_cast<uintptr_t>(lds_dst)), 16, 0, 0);
 }
 
-// Stage the window's kw <= kWin paths, whose triples (m, v, w) sit in sh.m / sh.v / sh.w, into LDS by LDS-DMA: three 1 KiB
-// pieces per path (row b_m, row g_m, the coefficient row), one wave instruction each, no data registers -- the accumulators
-// of a node with several windows stay where they are.  The caller waits (vmcnt(0) + barrier) before the products read.
-__device__ __forceinline__ void stage_window(const YArgs& a, YShared& sh, int kw, int tid, int wave, int nwaves, int lane) {
+// Start the LDS-DMA copies of a window of kw <= kWin paths (triples in `mt`): three 1 KiB pieces per path (row b_m, row g_m,
+// the coefficient row), one wave instruction each, no data registers.  Asynchronous: the consumer waits on vmcnt + a barrier.
+__device__ __forceinline__ void stage_dma(const YArgs& a, YWin& win, const YMeta& mt, int kw, int wave, int nwaves, int lane) {
   const int kw2 = (kw + 1) & ~1;  // the last MFMA step reads an even number of paths: the odd one out is staged as zeros
   const bool lane_ok = 4 * lane < a.H;
   const int npieces = kw2 * 3;
   for (int q = wave; q < npieces; q += nwaves) {   // q, j, kind are wave uniform
     const int j = q / 3, kind = q - 3 * j;
     const float* src = a.zeros;
-    float* dst = kind < 2 ? &sh.bg[j][kind][0] : &sh.coef[j][0];
+    float* dst = kind < 2 ? &win.bg[j][kind][0] : &win.coef[j][0];
     if (j < kw) {
-      const int64_t mj = __builtin_amdgcn_readfirstlane(sh.m[j]);
+      const int64_t mj = __builtin_amdgcn_readfirstlane(mt.m[j]);
       if (kind == 2) src = a.coef + mj * kCoefRow + 4 * lane;
       else if (lane_ok && !a.no_bg) src = a.bg + ((kind ? a.M : 0) + mj) * a.H + 4 * lane;
     }
     lds_dma16(src, dst);
   }
-  if (tid < kw2 * 8) {
-    const int j = tid >> 3, wd = tid & 7;
-    uint32_t wm = 0;
-    if (j < kw && wd < a.mask_words) wm = a.mask[int64_t(sh.v[j]) * a.mask_words + wd];
-    sh.mask[j][wd] = wm;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// the mask word (j = tid >> 3, word = tid & 7) of the window's paths, for threads tid < 8 * kw2
+__device__ __forceinline__ uint32_t load_mask_word(const YArgs& a, const YMeta& mt, int kw, int tid) {
+  const int j = tid >> 3, wd = tid & 7;
+  return (j < kw && wd < a.mask_words) ? a.mask[int64_t(mt.v[j]) * a.mask_words + wd] : 0u;
 }
 
 // The three products of one staged window: wave (rt, cg), lane l: A row i = l & 31 (class), B column = l & 31, k = l >> 5.
-__device__ __forceinline__ void mfma_window(const YShared& sh, int kw, int cls, const int (&colv)[2], const bool (&col_ok)[2],
-                                            int half, bool no_bg, f32x16 (&t1)[2], f32x16 (&y2)[2]) {
+__device__ __forceinline__ void mfma_window(const YWin& win, const YMeta& mt, int kw, int cls, const int (&colv)[2],
+                                            const bool (&col_ok)[2], int half, bool no_bg, f32x16 (&t1)[2], f32x16 (&y2)[2]) {
   for (int ks = 0; 2 * ks < kw; ++ks) {
     const int j = 2 * ks + half;
-    const float wj = j < kw ? sh.w[j] : 0.f;
-    const float aa = wj * sh.coef[j][cls], ab = wj * sh.coef[j][kCoefStride + cls], ag = wj * sh.coef[j][2 * kCoefStride + cls];
+    const float wj = j < kw ? mt.w[j] : 0.f;
+    const float aa = wj * win.coef[j][cls], ab = wj * win.coef[j][kCoefStride + cls], ag = wj * win.coef[j][2 * kCoefStride + cls];
     float mf[2], bb[2], gg[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      const uint32_t word = sh.mask[j][colv[ct] >> 5];
+      const uint32_t word = win.mask[j][colv[ct] >> 5];
       mf[ct] = (col_ok[ct] && ((word >> (colv[ct] & 31)) & 1u)) ? 1.f : 0.f;
-      bb[ct] = mf[ct] * sh.bg[j][0][colv[ct]];
-      gg[ct] = mf[ct] * sh.bg[j][1][colv[ct]];
+      bb[ct] = mf[ct] * win.bg[j][0][colv[ct]];
+      gg[ct] = mf[ct] * win.bg[j][1][colv[ct]];
     }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -245,119 +244,213 @@ __device__ __forceinline__ void mfma_window(const YShared& sh, int kw, int cls, 
   }
 }
 
-// One workgroup per node (LIST) or a grid-stride loop over nodes (!LIST), blockDim = 64 * colgroups * rowtiles: wave (rt, cg)
-// owns the 32-class row tile rt (classes c0 + 32 rt ...) and the columns [64 cg, 64 cg + 64) of Y[n]: two 32 x 32
-// accumulator tiles for the alpha product and two for the beta / gamma products (64 accumulator registers); waves w and
-// w + 4 (the two row tiles of one column group) share a SIMD.  Two workgroups per CU: one stages while the other multiplies.
-// LIST: the node's paths come from the per-batch list.  !LIST (the list did not fit its buffer: very large batches on
-// hub-heavy graphs): the paths are enumerated here -- block scan over the neighbours' R lists, windows of 128 triples in LDS.
-template <bool LIST>
-__global__ __launch_bounds__(512, 4) void ybuild_kernel(YArgs a) {
-  __shared__ YShared sh;
-  const bool overflow = int64_t(a.pptr[a.N]) > a.cap;
-  if (overflow == LIST) return;  // exactly one of the two launches does the work
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, half = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nthreads = blockDim.x, nwaves = nthreads >> 6;
-  const int ncg = (a.H + 63) >> 6;          // column groups
-  const int cg = wave % ncg, rt = wave / ncg;
-  const int H = a.H;
-  // class of this lane's A-operand row (i = lane & 31), clamped into the zero-padded coefficient row; rows past the class
-  // range are computed on whatever sits there and never stored
-  const int cls = min(a.c0 + 32 * rt + li, kCoefStride - 1);
+// Role of a wave: (rt, cg) owns the 32-class row tile rt (classes c0 + 32 rt ...) and the columns [64 cg, 64 cg + 64) of
+// Y[n]: two 32 x 32 accumulator tiles for the alpha product and two for the beta / gamma products; waves w and w + 4 (the
+// two row tiles of one column group) share a SIMD.
+struct YRole {
+  int lane, li, half, wave, nwaves, cg, rt, cls;
   int colv[2];
   bool col_ok[2];
+};
+__device__ __forceinline__ YRole y_role(const YArgs& a) {
+  YRole r;
+  const int tid = threadIdx.x;
+  r.lane = tid & 63; r.li = r.lane & 31; r.half = r.lane >> 5;
+  r.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  r.nwaves = blockDim.x >> 6;
+  const int ncg = (a.H + 63) >> 6;
+  r.cg = r.wave % ncg; r.rt = r.wave / ncg;
+  // class of this lane's A-operand row (i = lane & 31), clamped into the zero-padded coefficient row; rows past the class
+  // range are computed on whatever sits there and never stored
+  r.cls = min(a.c0 + 32 * r.rt + r.li, kCoefStride - 1);
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
-    colv[ct] = 64 * cg + 32 * ct + li;
-    col_ok[ct] = colv[ct] < H;
-    if (!col_ok[ct]) colv[ct] = 0;
+    r.colv[ct] = 64 * r.cg + 32 * ct + r.li;
+    r.col_ok[ct] = r.colv[ct] < a.H;
+    if (!r.col_ok[ct]) r.colv[ct] = 0;
   }
+  return r;
+}
 
-  // LIST: one node per workgroup (grid = N); !LIST: a grid-stride loop (its launch must cost nothing when it has nothing to do)
-  for (int64_t n = blockIdx.x; n < (LIST ? int64_t(blockIdx.x) + 1 : a.N); n += gridDim.x) {
+// The headline route: ONE persistent workgroup per CU walks its nodes with the window of node i + 1 in flight (LDS-DMA into
+// the other half of a double buffer, its triples loaded one node earlier still) while the eight waves multiply node i: per
+// node one barrier, no exposed memory latency, W_1's slice of the wave in registers for the whole launch.
+// Nodes with more than kWin paths (hubs) restage further windows in place.
+__global__ __launch_bounds__(512, 2) void ybuild_pipe_kernel(YArgs a) {
+  __shared__ struct { YWin win[2]; YMeta meta[4]; } sh;   // ~100 KiB: one workgroup per CU
+  if (int64_t(a.pptr[a.N]) > a.cap) return;               // the list overflowed: ybuild_kernel enumerates on the fly
+  const YRole ro = y_role(a);
+  const int tid = threadIdx.x, H = a.H;
+  const bool no_bg = a.no_bg != 0;
+  // ---- this wave's slice of W_1 (C / D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+  float w1r[2][16];
+  int yoff[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int colc = 64 * ro.cg + 32 * ct + ro.li;
+    yoff[ct] = (32 * ro.rt + 4 * ro.half) * H + colc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * ro.rt + 4 * ro.half + (r & 3) + 8 * (r >> 2);
+      w1r[ct][r] = (row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * H + colc] : 0.f;
+    }
+  }
+  const int64_t stride = gridDim.x;
+  const int64_t cnt = a.N > int64_t(blockIdx.x) ? (a.N - blockIdx.x + stride - 1) / stride : 0;
+  if (cnt == 0) return;
+  auto range = [&](int64_t i, int32_t& p0, int32_t& p1) {
+    p0 = p1 = 0;
+    if (i < cnt) { const int64_t n = blockIdx.x + i * stride; p0 = a.pptr[n]; p1 = a.pptr[n + 1]; }
+  };
+  // ---- prologue: node 0's first window in flight, node 1's triples in registers
+  int32_t p0c, p1c, p0n, p1n;
+  range(0, p0c, p1c);
+  int kwc = min(kWin, p1c - p0c);
+  if (tid < kwc) { sh.meta[0].m[tid] = a.pm[p0c + tid]; sh.meta[0].v[tid] = a.pv[p0c + tid]; sh.meta[0].w[tid] = a.pw[p0c + tid]; }
+  __syncthreads();
+  stage_dma(a, sh.win[0], sh.meta[0], kwc, ro.wave, ro.nwaves, ro.lane);
+  if (tid < 8 * kWin) sh.win[0].mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta[0], kwc, tid);
+  range(1, p0n, p1n);
+  int kwn = min(kWin, p1n - p0n);
+  int32_t trm = 0, trv = 0;
+  float trw = 0.f;
+  if (tid < kwn) { trm = a.pm[p0n + tid]; trv = a.pv[p0n + tid]; trw = a.pw[p0n + tid]; }
+
+  for (int64_t i = 0; i < cnt; ++i) {
+    const int b = int(i & 1), ms = int(i % 3), msn = int((i + 1) % 3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // node i's window has landed; node i + 1's triples are in registers
+    if (tid < kwn) { sh.meta[msn].m[tid] = trm; sh.meta[msn].v[tid] = trv; sh.meta[msn].w[tid] = trw; }
+    __syncthreads();  // window i visible to all waves; everybody is done with node i - 1 (the other buffer, meta slot msn's
+                      // previous tenant is three nodes back)
+    // ---- asynchronous, behind this node's products: node i + 1's window, its mask words, node i + 2's triples
+    stage_dma(a, sh.win[b ^ 1], sh.meta[msn], kwn, ro.wave, ro.nwaves, ro.lane);
+    uint32_t mwn = 0;
+    if (tid < 8 * kWin) mwn = load_mask_word(a, sh.meta[msn], kwn, tid);
+    int32_t p0nn, p1nn;
+    range(i + 2, p0nn, p1nn);
+    const int kwnn = min(kWin, p1nn - p0nn);
+    trm = 0; trv = 0; trw = 0.f;
+    if (tid < kwnn) { trm = a.pm[p0nn + tid]; trv = a.pv[p0nn + tid]; trw = a.pw[p0nn + tid]; }
+    // ---- node i
     f32x16 t1[2], y2[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
-
-    if constexpr (LIST) {
-      const int32_t p0 = a.pptr[n], p1 = a.pptr[n + 1];
-      for (int32_t wb = p0; wb < p1; wb += kWin) {
-        const int kw = min(kWin, p1 - wb);
-        if (wb > p0) __syncthreads();  // the previous window's operands are still being read
-        if (tid < kw) { sh.m[tid] = a.pm[wb + tid]; sh.v[tid] = a.pv[wb + tid]; sh.w[tid] = a.pw[wb + tid]; }
-        __syncthreads();
-        stage_window(a, sh, kw, tid, wave, nwaves, lane);
-        __syncthreads();
-        mfma_window(sh, kw, cls, colv, col_ok, half, a.no_bg != 0, t1, y2);
-      }
-    } else {
-      const int32_t rs = a.rowptr[n], re = a.rowptr[n + 1];
-      for (int32_t base = rs; base < re; base += nthreads) {
-        // ---- this thread's neighbour v and the extent of its batch list R[v]
-        int32_t v = 0, r0 = 0, cnt = 0;
-        float pv = 0.f;
-        if (base + tid < re) {
-          v = a.col[base + tid];
-          pv = a.val[base + tid];
-          r0 = a.rptr[v];
-          cnt = a.rptr[v + 1] - r0;
-        }
-        // ---- block-wide exclusive scan of cnt
-        int incl = cnt;
+    mfma_window(sh.win[b], sh.meta[ms], kwc, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
+    for (int32_t wb = p0c + kWin; wb < p1c; wb += kWin) {  // hubs: further windows, restaged in place (not overlapped)
+      const int kw = min(kWin, p1c - wb);
+      __syncthreads();
+      if (tid < kw) { sh.meta[3].m[tid] = a.pm[wb + tid]; sh.meta[3].v[tid] = a.pv[wb + tid]; sh.meta[3].w[tid] = a.pw[wb + tid]; }
+      __syncthreads();
+      stage_dma(a, sh.win[b], sh.meta[3], kw, ro.wave, ro.nwaves, ro.lane);
+      if (tid < 8 * kWin) sh.win[b].mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta[3], kw, tid);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      mfma_window(sh.win[b], sh.meta[3], kw, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
+    }
+    // ---- Y[n][c - c0][col] = W_1[c][col] * T1 + Y2, streamed out (128-byte row segments)
+    float* __restrict__ yn = a.Y + (blockIdx.x + i * stride) * int64_t(a.R) * H;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int t = __shfl_up(incl, o);
-          if (lane >= o) incl += t;
-        }
-        __syncthreads();  // sh.scan / the triples of the previous chunk are still being read
-        if (lane == 63) sh.scan[wave] = incl;
+    for (int ct = 0; ct < 2; ++ct) {
+      const bool cok = 64 * ro.cg + 32 * ct + ro.li < H;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int drow = (r & 3) + 8 * (r >> 2);
+        if (cok && 32 * ro.rt + 4 * ro.half + drow < a.R) yn[yoff[ct] + drow * H] = w1r[ct][r] * t1[ct][r] + y2[ct][r];
+      }
+    }
+    if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = mwn;  // (readers of that buffer passed this node's barrier)
+    p0c = p0n; p1c = p1n; kwc = kwn;
+    p0n = p0nn; p1n = p1nn; kwn = kwnn;
+  }
+}
+
+// The fallback when the batch's path list does not fit its buffer (very large batches on hub-heavy graphs): a grid-stride loop
+// over nodes, the paths enumerated here -- block scan over the neighbours' R lists, up to kPathWindow triples at a time in
+// LDS, staged kWin at a time.  Same arithmetic, no overlap; its launch returns at once when the list did fit.
+__global__ __launch_bounds__(512, 4) void ybuild_kernel(YArgs a) {
+  __shared__ struct {
+    YWin win;
+    YMeta meta;
+    int32_t fm[kPathWindow], fv[kPathWindow];
+    float fw[kPathWindow];
+    int32_t scan[8];
+  } sh;
+  if (int64_t(a.pptr[a.N]) <= a.cap) return;
+  const YRole ro = y_role(a);
+  const int tid = threadIdx.x, lane = ro.lane, wave = ro.wave, H = a.H;
+  const int nthreads = blockDim.x, nwaves = ro.nwaves;
+  const bool no_bg = a.no_bg != 0;
+  for (int64_t n = blockIdx.x; n < a.N; n += gridDim.x) {
+    f32x16 t1[2], y2[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
+    const int32_t rs = a.rowptr[n], re = a.rowptr[n + 1];
+    for (int32_t base = rs; base < re; base += nthreads) {
+      // ---- this thread's neighbour v and the extent of its batch list R[v]
+      int32_t v = 0, r0 = 0, cnt = 0;
+      float pv = 0.f;
+      if (base + tid < re) {
+        v = a.col[base + tid];
+        pv = a.val[base + tid];
+        r0 = a.rptr[v];
+        cnt = a.rptr[v + 1] - r0;
+      }
+      // ---- block-wide exclusive scan of cnt
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      __syncthreads();  // sh.scan / the triples of the previous chunk are still being read
+      if (lane == 63) sh.scan[wave] = incl;
+      __syncthreads();
+      int woff = 0, total = 0;
+      for (int w = 0; w < nwaves; ++w) {
+        const int sw = sh.scan[w];
+        if (w < wave) woff += sw;
+        total += sw;
+      }
+      const int off = woff + incl - cnt;
+      for (int wb = 0; wb < total; wb += kPathWindow) {
         __syncthreads();
-        int woff = 0, total = 0;
-        for (int w = 0; w < nwaves; ++w) {
-          const int sw = sh.scan[w];
-          if (w < wave) woff += sw;
-          total += sw;
+        const int lo = max(off, wb), hi = min(off + cnt, wb + kPathWindow);
+        for (int j = lo; j < hi; ++j) {
+          const int k = j - off;
+          sh.fm[j - wb] = a.r_m[r0 + k];
+          sh.fw[j - wb] = pv * a.r_w[r0 + k];
+          sh.fv[j - wb] = v;
         }
-        const int off = woff + incl - cnt;
-        // ---- windows of kPathWindow triples, each consumed kWin paths at a time
-        for (int wb = 0; wb < total; wb += kPathWindow) {
+        __syncthreads();
+        const int kall = min(kPathWindow, total - wb);
+        for (int sb = 0; sb < kall; sb += kWin) {
+          const int kw = min(kWin, kall - sb);
+          if (sb > 0) __syncthreads();
+          if (tid < kw) { sh.meta.m[tid] = sh.fm[sb + tid]; sh.meta.v[tid] = sh.fv[sb + tid]; sh.meta.w[tid] = sh.fw[sb + tid]; }
           __syncthreads();
-          const int lo = max(off, wb), hi = min(off + cnt, wb + kPathWindow);
-          for (int j = lo; j < hi; ++j) {
-            const int k = j - off;
-            sh.fm[j - wb] = a.r_m[r0 + k];
-            sh.fw[j - wb] = pv * a.r_w[r0 + k];
-            sh.fv[j - wb] = v;
-          }
+          stage_dma(a, sh.win, sh.meta, kw, wave, nwaves, lane);
+          if (tid < 8 * kWin) sh.win.mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta, kw, tid);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
-          const int kall = min(kPathWindow, total - wb);
-          for (int sb = 0; sb < kall; sb += kWin) {
-            const int kw = min(kWin, kall - sb);
-            if (sb > 0) __syncthreads();
-            if (tid < kw) { sh.m[tid] = sh.fm[sb + tid]; sh.v[tid] = sh.fv[sb + tid]; sh.w[tid] = sh.fw[sb + tid]; }
-            __syncthreads();
-            stage_window(a, sh, kw, tid, wave, nwaves, lane);
-            __syncthreads();
-            mfma_window(sh, kw, cls, colv, col_ok, half, a.no_bg != 0, t1, y2);
-          }
+          mfma_window(sh.win, sh.meta, kw, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
         }
       }
     }
-
-    // ---- Y[n][c - c0][col] = W_1[c][col] * T1 + Y2   (C / D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+    // ---- Y[n][c - c0][col] = W_1[c][col] * T1 + Y2
     // (32-bit offsets from two uniform bases; `late` ties the address arithmetic to this point of the program -- hipcc
     //  otherwise computes all 64 addresses at the top of the kernel and spills them around the products)
     int late = 0;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(late));  // a value that exists only from here on
+    asm volatile("v_mov_b32 %0, 0" : "=v"(late));
     float* __restrict__ yn = a.Y + n * int64_t(a.R) * H;
     const float* __restrict__ w1p = a.W1 + int64_t(a.c0) * H;
-    const int row0 = 32 * rt + 4 * half + late;
+    const int row0 = 32 * ro.rt + 4 * ro.half + late;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      const int colc = 64 * cg + 32 * ct + li;
+      const int colc = 64 * ro.cg + 32 * ct + ro.li;
       const bool cok = colc < H;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -366,7 +459,7 @@ __global__ __launch_bounds__(512, 4) void ybuild_kernel(YArgs a) {
         if (cok && row < a.R) yn[o] = w1p[o] * t1[ct][r] + y2[ct][r];
       }
     }
-    if (!LIST) __syncthreads();  // the next node restages the shared buffers
+    __syncthreads();  // the next node restages the shared buffers
   }
 }
 
@@ -577,9 +670,10 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.W1 = h->W[1]; y.Y = ws.planes_a.as<float>(); y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
     const unsigned threads = unsigned(64 * cdiv(H, 64) * cdiv(R, 32));  // (column groups) x (32-class row tiles) waves
-    hipLaunchKernelGGL(ybuild_kernel<true>, dim3(unsigned(N)), dim3(threads), 0, s, y);
+    // one persistent workgroup per CU (its ~100 KiB of LDS admit no second one)
+    hipLaunchKernelGGL(ybuild_pipe_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(threads), 0, s, y);
     // (returns at once unless the path list overflowed its buffer: then this launch does the work, enumerating on the fly)
-    hipLaunchKernelGGL(ybuild_kernel<false>, dim3(unsigned(std::min<int64_t>(N, 1024))), dim3(threads), 0, s, y);
+    hipLaunchKernelGGL(ybuild_kernel, dim3(unsigned(std::min<int64_t>(N, 1024))), dim3(threads), 0, s, y);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the KFAC path (bench.py roofline)
     LGNN_CALL(launch_gram256_stream(y.Y, N * R, H, scratch, ws.path_zeros.as<float>(), s));
