@@ -219,27 +219,48 @@ __device__ __forceinline__ uint32_t load_mask_word(const YArgs& a, const YMeta& 
 }
 
 // The three products of one staged window: wave (rt, cg), lane l: A row i = l & 31 (class), B column = l & 31, k = l >> 5.
+// The LDS operands of step ks + 1 are read before the six MFMAs of step ks are issued (their latency hides behind 384 cycles
+// of matrix work instead of stalling every step).
+struct YOps { float aa, ab, ag, mf[2], bb[2], gg[2]; };
+__device__ __forceinline__ void y_load_ops(const YWin& win, const YMeta& mt, int kw, int ks, int half, int cls,
+                                           const int (&colv)[2], const bool (&col_ok)[2], YOps& o) {
+  const int j = min(2 * ks + half, kWin - 1);   // (past the window's end: a valid row, weight 0)
+  const float wj = 2 * ks + half < kw ? mt.w[j] : 0.f;
+  o.aa = wj * win.coef[j][cls]; o.ab = wj * win.coef[j][kCoefStride + cls]; o.ag = wj * win.coef[j][2 * kCoefStride + cls];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const uint32_t word = win.mask[j][colv[ct] >> 5];
+    o.mf[ct] = (col_ok[ct] && 2 * ks + half < kw && ((word >> (colv[ct] & 31)) & 1u)) ? 1.f : 0.f;
+    o.bb[ct] = o.mf[ct] * win.bg[j][0][colv[ct]];
+    o.gg[ct] = o.mf[ct] * win.bg[j][1][colv[ct]];
+  }
+}
+__device__ __forceinline__ void y_mfma_ops(const YOps& o, bool no_bg, f32x16 (&t1)[2], f32x16 (&y2)[2]) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    t1[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.aa, o.mf[ct], t1[ct], 0, 0, 0);
+    if (!no_bg) {
+      y2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.ab, o.bb[ct], y2[ct], 0, 0, 0);
+      y2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.ag, o.gg[ct], y2[ct], 0, 0, 0);
+    }
+  }
+}
 __device__ __forceinline__ void mfma_window(const YWin& win, const YMeta& mt, int kw, int cls, const int (&colv)[2],
                                             const bool (&col_ok)[2], int half, bool no_bg, f32x16 (&t1)[2], f32x16 (&y2)[2]) {
-  for (int ks = 0; 2 * ks < kw; ++ks) {
-    const int j = 2 * ks + half;
-    const float wj = j < kw ? mt.w[j] : 0.f;
-    const float aa = wj * win.coef[j][cls], ab = wj * win.coef[j][kCoefStride + cls], ag = wj * win.coef[j][2 * kCoefStride + cls];
-    float mf[2], bb[2], gg[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const uint32_t word = win.mask[j][colv[ct] >> 5];
-      mf[ct] = (col_ok[ct] && ((word >> (colv[ct] & 31)) & 1u)) ? 1.f : 0.f;
-      bb[ct] = mf[ct] * win.bg[j][0][colv[ct]];
-      gg[ct] = mf[ct] * win.bg[j][1][colv[ct]];
-    }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      t1[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, mf[ct], t1[ct], 0, 0, 0);
-      if (!no_bg) {
-        y2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab, bb[ct], y2[ct], 0, 0, 0);
-        y2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag, gg[ct], y2[ct], 0, 0, 0);
-      }
+  const int nks = (kw + 1) >> 1;
+  if (nks == 0) return;
+  YOps oa, ob;
+  y_load_ops(win, mt, kw, 0, half, cls, colv, col_ok, oa);
+  for (int ks = 0; ks < nks; ks += 2) {
+    y_load_ops(win, mt, kw, ks + 1, half, cls, colv, col_ok, ob);  // (a step past the end multiplies zeros)
+    __builtin_amdgcn_sched_barrier(0);
+    y_mfma_ops(oa, no_bg, t1, y2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < nks) {
+      y_load_ops(win, mt, kw, ks + 2, half, cls, colv, col_ok, oa);
+      __builtin_amdgcn_sched_barrier(0);
+      y_mfma_ops(ob, no_bg, t1, y2);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -316,12 +337,31 @@ __global__ __launch_bounds__(512, 2) void ybuild_pipe_kernel(YArgs a) {
   float trw = 0.f;
   if (tid < kwn) { trm = a.pm[p0n + tid]; trv = a.pv[p0n + tid]; trw = a.pw[p0n + tid]; }
 
+  // The results of node i - 1 stay in registers across the barrier and are stored at the top of node i, BEFORE node i + 1's
+  // copies are issued: vector-memory operations retire in issue order, so the vmcnt(0) that waits for a window one node
+  // later then finds these stores a whole node old -- stored right after their products they would be the youngest
+  // operations in flight at that wait and every node would pay a store round trip.
+  float yprev[2][16];
+  float* __restrict__ yprev_p = nullptr;
+  auto store_prev = [&]() {
+    if (yprev_p == nullptr) return;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const bool cok = 64 * ro.cg + 32 * ct + ro.li < H;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int drow = (r & 3) + 8 * (r >> 2);
+        if (cok && 32 * ro.rt + 4 * ro.half + drow < a.R) yprev_p[yoff[ct] + drow * H] = yprev[ct][r];
+      }
+    }
+  };
   for (int64_t i = 0; i < cnt; ++i) {
     const int b = int(i & 1), ms = int(i % 3), msn = int((i + 1) % 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // node i's window has landed; node i + 1's triples are in registers
     if (tid < kwn) { sh.meta[msn].m[tid] = trm; sh.meta[msn].v[tid] = trv; sh.meta[msn].w[tid] = trw; }
     __syncthreads();  // window i visible to all waves; everybody is done with node i - 1 (the other buffer, meta slot msn's
                       // previous tenant is three nodes back)
+    store_prev();     // Y[node i - 1], streamed out behind this node's products (128-byte row segments)
     // ---- asynchronous, behind this node's products: node i + 1's window, its mask words, node i + 2's triples
     stage_dma(a, sh.win[b ^ 1], sh.meta[msn], kwn, ro.wave, ro.nwaves, ro.lane);
     uint32_t mwn = 0;
@@ -349,21 +389,17 @@ __global__ __launch_bounds__(512, 2) void ybuild_pipe_kernel(YArgs a) {
       __syncthreads();
       mfma_window(sh.win[b], sh.meta[3], kw, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
     }
-    // ---- Y[n][c - c0][col] = W_1[c][col] * T1 + Y2, streamed out (128-byte row segments)
-    float* __restrict__ yn = a.Y + (blockIdx.x + i * stride) * int64_t(a.R) * H;
+    // ---- Y[n][c - c0][col] = W_1[c][col] * T1 + Y2: kept for the top of the next node
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const bool cok = 64 * ro.cg + 32 * ct + ro.li < H;
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int drow = (r & 3) + 8 * (r >> 2);
-        if (cok && 32 * ro.rt + 4 * ro.half + drow < a.R) yn[yoff[ct] + drow * H] = w1r[ct][r] * t1[ct][r] + y2[ct][r];
-      }
-    }
+      for (int r = 0; r < 16; ++r) yprev[ct][r] = w1r[ct][r] * t1[ct][r] + y2[ct][r];
+    yprev_p = a.Y + (blockIdx.x + i * stride) * int64_t(a.R) * H;
     if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = mwn;  // (readers of that buffer passed this node's barrier)
     p0c = p0n; p1c = p1n; kwc = kwn;
     p0n = p0nn; p1n = p1nn; kwn = kwnn;
   }
+  store_prev();
 }
 
 // The fallback when the batch's path list does not fit its buffer (very large batches on hub-heavy graphs): a grid-stride loop
