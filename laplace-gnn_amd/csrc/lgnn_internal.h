@@ -113,6 +113,7 @@ struct Workspace {
   // and their products with W_1 [2 M][H]; R = P^T[:, batch] as CSR over v (counts / cursors, row pointers, sample, weight)
   DevBuf path_coef, path_up, path_bg, path_cnt, path_rptr, path_rm, path_rw, path_zeros;
   DevBuf path_pcnt, path_pptr, path_pm, path_pv, path_pw;  // the batch's paths per destination node (CSR over n)
+  // (the list's capacity is max(4 nnz, 4 M entries); a batch whose list is longer takes the enumerating route on the device)
   bool path_zeros_set = false;
   DevBuf gram_scratch_res[kMaxLayers];  // res / norm models: per-call partial B of res.{l} (GCN; GraphSAGE shares the conv's)
   DevBuf planes_c;  // GCN with res, >= 3 layers: u_l Wr_l of the level being computed
@@ -358,7 +359,8 @@ bool paths_supported(int kind, int L, const int64_t* dims, int act, int64_t nnz)
 int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce, float* scratch,
                            hipStream_t s);
 // scratch [width, width] (upper 32 x 32 sub-tiles) += Y^T Y for contiguous rows of `width` floats, 128 < width <= 256
-int launch_gram256_stream(const float* Y, int64_t rows, int64_t width, float* scratch, const float* zeros, hipStream_t s);
+int launch_gram256_stream(const float* Y, int64_t rows, int64_t width, float* scratch, const float* zeros, hipStream_t s,
+                          const int32_t* gate = nullptr, int64_t gate_cap = 0);
 // ---- forward.hip ------------------------------------------------------------------------
 int forward_ensure(lgnn_ctx* h, hipStream_t s);
 int forward_ensure_grams(lgnn_ctx* h, hipStream_t s);

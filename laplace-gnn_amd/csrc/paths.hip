@@ -273,13 +273,13 @@ struct YRole {
   int colv[2];
   bool col_ok[2];
 };
-__device__ __forceinline__ YRole y_role(const YArgs& a) {
+__device__ __forceinline__ YRole y_role(const YArgs& a, bool fixed8 = false) {
   YRole r;
   const int tid = threadIdx.x;
   r.lane = tid & 63; r.li = r.lane & 31; r.half = r.lane >> 5;
   r.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   r.nwaves = blockDim.x >> 6;
-  const int ncg = (a.H + 63) >> 6;
+  const int ncg = fixed8 ? 4 : (a.H + 63) >> 6;  // fused kernel: always 4 x 2 roles (waves w and w + 4 share a SIMD)
   r.cg = r.wave % ncg; r.rt = r.wave / ncg;
   // class of this lane's A-operand row (i = lane & 31), clamped into the zero-padded coefficient row; rows past the class
   // range are computed on whatever sits there and never stored
@@ -291,115 +291,6 @@ __device__ __forceinline__ YRole y_role(const YArgs& a) {
     if (!r.col_ok[ct]) r.colv[ct] = 0;
   }
   return r;
-}
-
-// The headline route: ONE persistent workgroup per CU walks its nodes with the window of node i + 1 in flight (LDS-DMA into
-// the other half of a double buffer, its triples loaded one node earlier still) while the eight waves multiply node i: per
-// node one barrier, no exposed memory latency, W_1's slice of the wave in registers for the whole launch.
-// Nodes with more than kWin paths (hubs) restage further windows in place.
-__global__ __launch_bounds__(512, 2) void ybuild_pipe_kernel(YArgs a) {
-  __shared__ struct { YWin win[2]; YMeta meta[4]; } sh;   // ~100 KiB: one workgroup per CU
-  if (int64_t(a.pptr[a.N]) > a.cap) return;               // the list overflowed: ybuild_kernel enumerates on the fly
-  const YRole ro = y_role(a);
-  const int tid = threadIdx.x, H = a.H;
-  const bool no_bg = a.no_bg != 0;
-  // ---- this wave's slice of W_1 (C / D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-  float w1r[2][16];
-  int yoff[2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int colc = 64 * ro.cg + 32 * ct + ro.li;
-    yoff[ct] = (32 * ro.rt + 4 * ro.half) * H + colc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * ro.rt + 4 * ro.half + (r & 3) + 8 * (r >> 2);
-      w1r[ct][r] = (row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * H + colc] : 0.f;
-    }
-  }
-  const int64_t stride = gridDim.x;
-  const int64_t cnt = a.N > int64_t(blockIdx.x) ? (a.N - blockIdx.x + stride - 1) / stride : 0;
-  if (cnt == 0) return;
-  auto range = [&](int64_t i, int32_t& p0, int32_t& p1) {
-    p0 = p1 = 0;
-    if (i < cnt) { const int64_t n = blockIdx.x + i * stride; p0 = a.pptr[n]; p1 = a.pptr[n + 1]; }
-  };
-  // ---- prologue: node 0's first window in flight, node 1's triples in registers
-  int32_t p0c, p1c, p0n, p1n;
-  range(0, p0c, p1c);
-  int kwc = min(kWin, p1c - p0c);
-  if (tid < kwc) { sh.meta[0].m[tid] = a.pm[p0c + tid]; sh.meta[0].v[tid] = a.pv[p0c + tid]; sh.meta[0].w[tid] = a.pw[p0c + tid]; }
-  __syncthreads();
-  stage_dma(a, sh.win[0], sh.meta[0], kwc, ro.wave, ro.nwaves, ro.lane);
-  if (tid < 8 * kWin) sh.win[0].mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta[0], kwc, tid);
-  range(1, p0n, p1n);
-  int kwn = min(kWin, p1n - p0n);
-  int32_t trm = 0, trv = 0;
-  float trw = 0.f;
-  if (tid < kwn) { trm = a.pm[p0n + tid]; trv = a.pv[p0n + tid]; trw = a.pw[p0n + tid]; }
-
-  // The results of node i - 1 stay in registers across the barrier and are stored at the top of node i, BEFORE node i + 1's
-  // copies are issued: vector-memory operations retire in issue order, so the vmcnt(0) that waits for a window one node
-  // later then finds these stores a whole node old -- stored right after their products they would be the youngest
-  // operations in flight at that wait and every node would pay a store round trip.
-  float yprev[2][16];
-  float* __restrict__ yprev_p = nullptr;
-  auto store_prev = [&]() {
-    if (yprev_p == nullptr) return;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const bool cok = 64 * ro.cg + 32 * ct + ro.li < H;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int drow = (r & 3) + 8 * (r >> 2);
-        if (cok && 32 * ro.rt + 4 * ro.half + drow < a.R) yprev_p[yoff[ct] + drow * H] = yprev[ct][r];
-      }
-    }
-  };
-  for (int64_t i = 0; i < cnt; ++i) {
-    const int b = int(i & 1), ms = int(i % 3), msn = int((i + 1) % 3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // node i's window has landed; node i + 1's triples are in registers
-    if (tid < kwn) { sh.meta[msn].m[tid] = trm; sh.meta[msn].v[tid] = trv; sh.meta[msn].w[tid] = trw; }
-    __syncthreads();  // window i visible to all waves; everybody is done with node i - 1 (the other buffer, meta slot msn's
-                      // previous tenant is three nodes back)
-    store_prev();     // Y[node i - 1], streamed out behind this node's products (128-byte row segments)
-    // ---- asynchronous, behind this node's products: node i + 1's window, its mask words, node i + 2's triples
-    stage_dma(a, sh.win[b ^ 1], sh.meta[msn], kwn, ro.wave, ro.nwaves, ro.lane);
-    uint32_t mwn = 0;
-    if (tid < 8 * kWin) mwn = load_mask_word(a, sh.meta[msn], kwn, tid);
-    int32_t p0nn, p1nn;
-    range(i + 2, p0nn, p1nn);
-    const int kwnn = min(kWin, p1nn - p0nn);
-    trm = 0; trv = 0; trw = 0.f;
-    if (tid < kwnn) { trm = a.pm[p0nn + tid]; trv = a.pv[p0nn + tid]; trw = a.pw[p0nn + tid]; }
-    // ---- node i
-    f32x16 t1[2], y2[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
-    mfma_window(sh.win[b], sh.meta[ms], kwc, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
-    for (int32_t wb = p0c + kWin; wb < p1c; wb += kWin) {  // hubs: further windows, restaged in place (not overlapped)
-      const int kw = min(kWin, p1c - wb);
-      __syncthreads();
-      if (tid < kw) { sh.meta[3].m[tid] = a.pm[wb + tid]; sh.meta[3].v[tid] = a.pv[wb + tid]; sh.meta[3].w[tid] = a.pw[wb + tid]; }
-      __syncthreads();
-      stage_dma(a, sh.win[b], sh.meta[3], kw, ro.wave, ro.nwaves, ro.lane);
-      if (tid < 8 * kWin) sh.win[b].mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta[3], kw, tid);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      mfma_window(sh.win[b], sh.meta[3], kw, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
-    }
-    // ---- Y[n][c - c0][col] = W_1[c][col] * T1 + Y2: kept for the top of the next node
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) yprev[ct][r] = w1r[ct][r] * t1[ct][r] + y2[ct][r];
-    yprev_p = a.Y + (blockIdx.x + i * stride) * int64_t(a.R) * H;
-    if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = mwn;  // (readers of that buffer passed this node's barrier)
-    p0c = p0n; p1c = p1n; kwc = kwn;
-    p0n = p0nn; p1n = p1nn; kwn = kwnn;
-  }
-  store_prev();
 }
 
 // The fallback when the batch's path list does not fit its buffer (very large batches on hub-heavy graphs): a grid-stride loop
@@ -520,6 +411,172 @@ __device__ __forceinline__ void part_mfma(const float (&x)[8], f32x16 (&acc)[HI 
     acc[s - LO] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[Tiles256<W>::si[s]], x[Tiles256<W>::sj[s]], acc[s - LO], 0, 0, 0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The headline route, everything of a node on one CU: ONE persistent 512-thread workgroup per CU walks its nodes; per node
+//   (1) the window of <= 16 paths (rows b_m, g_m, coefficient rows: 1 KiB LDS-DMA pieces) is already in LDS -- it was put in
+//       flight one node earlier, its triples loaded one node earlier still -- and the three path products run on the matrix
+//       pipes (wave (rt, cg): 32 classes x 64 columns, v_mfma_f32_32x32x2_f32);
+//   (2) Y[n] = W_1 (.) T1 + Y2 goes to an LDS tile [rows][256] (never to HBM);
+//   (3) all eight waves contract it into the register-resident upper-triangular 256 x 256 accumulators (36 sub-tiles, 5 + 4 per
+//       SIMD pair), S += Y[n]^T Y[n].
+// Two barriers per node, no exposed memory latency; nodes with more than 16 paths (hubs) restage further windows in place.
+constexpr int kYRows = 48;  // classes per launch (LDS: 2 x 48.5 KiB windows + 48 KiB tile = 146 KiB)
+
+struct FusedShared {
+  YWin win[2];
+  YMeta meta[4];
+  float y[kYRows][256];
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int W, int LO, int HI>
+__device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, float* __restrict__ scratch) {
+  constexpr int NT = HI - LO;
+  const YRole ro = y_role(a, true);
+  const int tid = threadIdx.x, H = a.H, lane = ro.lane;
+  const bool no_bg = a.no_bg != 0;
+  const int rtiles = (a.R + 31) >> 5, ncg = (H + 63) >> 6;
+  const bool path_wave = ro.rt < rtiles && ro.cg < ncg;  // (H <= 192 or R <= 32: some waves only stage and contract)
+  const int r2 = (a.R + 1) & ~1;                          // rows the Gram reads (an odd class count: one zero row)
+  f32x16 acc[NT];
+#pragma unroll
+  for (int s = 0; s < NT; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  // ---- this wave's slice of W_1 (C / D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+  float w1r[2][16];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int colc = 64 * ro.cg + 32 * ct + ro.li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * ro.rt + 4 * ro.half + (r & 3) + 8 * (r >> 2);
+      w1r[ct][r] = (path_wave && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * H + colc] : 0.f;
+    }
+  }
+  // the tile is zero where nobody writes: columns >= H, the odd row out
+  for (int q = tid; q < kYRows * 256; q += 512) (&sh.y[0][0])[q] = 0.f;
+
+  const int64_t stride = gridDim.x;
+  const int64_t cnt = a.N > int64_t(blockIdx.x) ? (a.N - blockIdx.x + stride - 1) / stride : 0;
+  auto range = [&](int64_t i, int32_t& p0, int32_t& p1) {
+    p0 = p1 = 0;
+    if (i < cnt) { const int64_t n = blockIdx.x + i * stride; p0 = a.pptr[n]; p1 = a.pptr[n + 1]; }
+  };
+  // ---- prologue: node 0's first window in flight, node 1's triples in registers
+  int32_t p0c, p1c, p0n, p1n;
+  range(0, p0c, p1c);
+  int kwc = min(kWin, p1c - p0c);
+  if (tid < kwc) { sh.meta[0].m[tid] = a.pm[p0c + tid]; sh.meta[0].v[tid] = a.pv[p0c + tid]; sh.meta[0].w[tid] = a.pw[p0c + tid]; }
+  __syncthreads();
+  stage_dma(a, sh.win[0], sh.meta[0], kwc, ro.wave, 8, lane);
+  if (tid < 8 * kWin) sh.win[0].mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta[0], kwc, tid);
+  range(1, p0n, p1n);
+  int kwn = min(kWin, p1n - p0n);
+  int32_t trm = 0, trv = 0;
+  float trw = 0.f;
+  if (tid < kwn) { trm = a.pm[p0n + tid]; trv = a.pv[p0n + tid]; trw = a.pw[p0n + tid]; }
+
+  for (int64_t i = 0; i < cnt; ++i) {
+    const int b = int(i & 1), ms = int(i % 3), msn = int((i + 1) % 3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // node i's window has landed; node i + 1's triples are in registers
+    if (tid < kwn) { sh.meta[msn].m[tid] = trm; sh.meta[msn].v[tid] = trv; sh.meta[msn].w[tid] = trw; }
+    lds_barrier();  // window i visible to all waves; everybody is done with node i - 1 (its Gram, the other window buffer;
+                    // meta slot msn's previous tenant is three nodes back)
+    // ---- asynchronous, behind this node's work: node i + 1's window, its mask words, node i + 2's triples
+    stage_dma(a, sh.win[b ^ 1], sh.meta[msn], kwn, ro.wave, 8, lane);
+    uint32_t mwn = 0;
+    if (tid < 8 * kWin) mwn = load_mask_word(a, sh.meta[msn], kwn, tid);
+    int32_t p0nn, p1nn;
+    range(i + 2, p0nn, p1nn);
+    const int kwnn = min(kWin, p1nn - p0nn);
+    trm = 0; trv = 0; trw = 0.f;
+    if (tid < kwnn) { trm = a.pm[p0nn + tid]; trv = a.pv[p0nn + tid]; trw = a.pw[p0nn + tid]; }
+    // ---- (1) the path products of node i
+    f32x16 t1[2], y2[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
+    if (path_wave) mfma_window(sh.win[b], sh.meta[ms], kwc, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
+    for (int32_t wb = p0c + kWin; wb < p1c; wb += kWin) {  // hubs: further windows, restaged in place (not overlapped)
+      const int kw = min(kWin, p1c - wb);
+      lds_barrier();
+      if (tid < kw) { sh.meta[3].m[tid] = a.pm[wb + tid]; sh.meta[3].v[tid] = a.pv[wb + tid]; sh.meta[3].w[tid] = a.pw[wb + tid]; }
+      lds_barrier();
+      stage_dma(a, sh.win[b], sh.meta[3], kw, ro.wave, 8, lane);
+      if (tid < 8 * kWin) sh.win[b].mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta[3], kw, tid);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();
+      if (path_wave) mfma_window(sh.win[b], sh.meta[3], kw, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
+    }
+    // ---- (2) Y[n] into the LDS tile (readers of the previous node's tile passed this node's first barrier)
+    if (path_wave) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int colc = 64 * ro.cg + 32 * ct + ro.li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * ro.rt + 4 * ro.half + (r & 3) + 8 * (r >> 2);
+          if (colc < H && row < a.R) sh.y[row][colc] = w1r[ct][r] * t1[ct][r] + y2[ct][r];
+        }
+      }
+    }
+    if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = mwn;  // (readers of that buffer passed this node's barrier)
+    lds_barrier();  // raw: a __syncthreads() here would drain the copies in flight for node i + 1
+    // ---- (3) S += Y[n]^T Y[n], rows two at a time (operands of step k + 1 read before the MFMAs of step k)
+    {
+      const float* __restrict__ base = &sh.y[0][0] + (lane >> 5) * 256 + (lane & 31);
+      const int nk = r2 >> 1;
+      float xa[8], xb[8];
+      part_load<W, LO, HI>(base, xa);
+      for (int kk = 0; kk < nk; kk += 2) {
+        if (kk + 1 < nk) part_load<W, LO, HI>(base + (kk + 1) * 512, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        part_mfma<W, LO, HI>(xa, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 1 < nk) {
+          if (kk + 2 < nk) part_load<W, LO, HI>(base + (kk + 2) * 512, xa);
+          __builtin_amdgcn_sched_barrier(0);
+          part_mfma<W, LO, HI>(xb, acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    p0c = p0n; p1c = p1n; kwc = kwn;
+    p0n = p0nn; p1n = p1nn; kwn = kwnn;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int64_t D = H;
+#pragma unroll
+  for (int s = LO; s < HI; ++s) {
+    const int64_t j = Tiles256<W>::sj[s] * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t ii = Tiles256<W>::si[s] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (ii < D && j < D) atomicAdd(&scratch[ii * D + j], acc[s - LO][r]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void paths_fused_kernel(YArgs a, float* __restrict__ scratch) {
+  __shared__ FusedShared sh;  // ONE LDS object (a second one makes hipcc drain vmcnt before its reads)
+  if (int64_t(a.pptr[a.N]) > a.cap) return;  // the path list overflowed its buffer: the enumerating route takes over
+  const int hw = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  switch (hw) {  // hardware waves g and g + 4 share a SIMD: 5 + 4 of the group's 9 sub-tiles
+    case 0: fused_wave<0, 0, 5>(a, sh, scratch); break;
+    case 4: fused_wave<0, 5, 9>(a, sh, scratch); break;
+    case 1: fused_wave<1, 0, 5>(a, sh, scratch); break;
+    case 5: fused_wave<1, 5, 9>(a, sh, scratch); break;
+    case 2: fused_wave<2, 0, 5>(a, sh, scratch); break;
+    case 6: fused_wave<2, 5, 9>(a, sh, scratch); break;
+    case 3: fused_wave<3, 0, 5>(a, sh, scratch); break;
+    default: fused_wave<3, 5, 9>(a, sh, scratch); break;
+  }
+}
+
 constexpr int kSlots = 3;
 constexpr int kBlockRows = 32;
 
@@ -529,6 +586,8 @@ struct GramStreamArgs {
   int width;
   const float* zeros;   // >= 16 bytes of zeros: the source of lanes past the row's end and of rows past the last
   float* scratch;       // [width][width], upper sub-tiles, float atomics
+  const int32_t* gate;  // optional: run only if *gate > gate_cap (the overflow route of the path kernels)
+  int64_t gate_cap;
 };
 
 // the 4 LDS-DMA row copies of block `blk` that this wave issues (rows 4 hw .. 4 hw + 3 of the block) into slot `slot`
@@ -595,6 +654,7 @@ __device__ __forceinline__ void stream_wave(const GramStreamArgs& a, float* tile
 
 __global__ __launch_bounds__(512, 2) void gram256_stream_kernel(GramStreamArgs a) {
   __shared__ float tiles[kSlots * kBlockRows * 256];  // 96 KiB: ONE LDS object (a second one makes hipcc drain vmcnt)
+  if (a.gate != nullptr && int64_t(*a.gate) <= a.gate_cap) return;
   const int lane = threadIdx.x & 63;
   const int hw = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
   const int64_t nblocks = (a.rows + kBlockRows - 1) / kBlockRows;
@@ -620,10 +680,11 @@ bool paths_supported(int kind, int L, const int64_t* dims, int act, int64_t nnz)
          H % 4 == 0;
 }
 
-int launch_gram256_stream(const float* Y, int64_t rows, int64_t width, float* scratch, const float* zeros, hipStream_t s) {
+int launch_gram256_stream(const float* Y, int64_t rows, int64_t width, float* scratch, const float* zeros, hipStream_t s,
+                          const int32_t* gate, int64_t gate_cap) {
   LGNN_REQUIRE(width > 128 && width <= 256 && width % 4 == 0, "internal: streaming Gram width");
   if (rows <= 0) return 0;
-  GramStreamArgs g{Y, rows, int(width), zeros, scratch};
+  GramStreamArgs g{Y, rows, int(width), zeros, scratch, gate, gate_cap};
   const int64_t nblocks = cdiv(rows, kBlockRows);
   hipLaunchKernelGGL(gram256_stream_kernel, dim3(unsigned(std::min<int64_t>(nblocks, 256))), dim3(512), 0, s, g);
   LGNN_HIP_CHECK(hipGetLastError());
@@ -671,7 +732,9 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
                      ws.path_rptr.as<int32_t>(), ws.path_rm.as<int32_t>(), ws.path_rw.as<float>());
   LGNN_HIP_CHECK(hipGetLastError());
   // ---- the paths of every destination node: count (one wave per node), scan, fill -- when they fit the buffer
-  const int64_t cap = std::max<int64_t>(4 * h->nnz, int64_t(1) << 22);  // (arxiv shape: 2.2 M paths per batch of 10 000)
+  // (arxiv shape: 2.2 M paths per batch of 10 000.  LGNN_PATH_LIST_CAP, read per call: tests force the enumerating route)
+  int64_t cap = std::max<int64_t>(4 * h->nnz, int64_t(1) << 22);
+  if (const char* e = getenv("LGNN_PATH_LIST_CAP")) cap = std::max<int64_t>(1, std::min<int64_t>(cap, atoll(e)));
   LGNN_CALL(ws.path_pcnt.reserve(size_t(N + 1) * 4));
   LGNN_CALL(ws.path_pptr.reserve(size_t(N + 1) * 4));
   LGNN_CALL(ws.path_pm.reserve(size_t(cap) * 4));
@@ -688,14 +751,12 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
                      ws.path_rptr.as<int32_t>(), ws.path_rm.as<int32_t>(), ws.path_rw.as<float>(), ws.path_pcnt.as<int32_t>(),
                      ws.path_pptr.as<int32_t>(), cap, ws.path_pm.as<int32_t>(), ws.path_pv.as<int32_t>(), ws.path_pw.as<float>());
   LGNN_HIP_CHECK(hipGetLastError());
-  // ---- class chunks under the workspace cap: Y [N][R][H], then the streaming Gram
-  const int64_t per_class = N * H * 4;
-  const int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(ce - cb, h->ws_limit / std::max<int64_t>(per_class, 1)));
-  LGNN_CALL(ws.planes_a.reserve(size_t(cc_max) * N * H * 4));
-  ws.planes_a_zero_ptr = nullptr;
+  // ---- class chunks of <= kYRows: everything of a node on one CU (paths_fused_kernel).  Only if the path list overflowed its
+  // buffer do the two launches behind it run: the enumerating Y builder (planes in HBM, under the workspace cap) and the
+  // streaming Gram over them; otherwise they return at once and no plane is ever allocated.
   LGNN_REQUIRE(N < (int64_t(1) << 31), "too many nodes for one launch");
-  for (int64_t c0 = cb; c0 < ce; c0 += cc_max) {
-    const int64_t R = std::min(cc_max, ce - c0);
+  for (int64_t c0 = cb; c0 < ce; c0 += kYRows) {
+    const int64_t R = std::min<int64_t>(kYRows, ce - c0);
     YArgs y{};
     y.rowptr = h->PT.rowptr; y.col = h->PT.col; y.val = h->PT.val;
     y.rptr = ws.path_rptr.as<int32_t>(); y.r_m = ws.path_rm.as<int32_t>(); y.r_w = ws.path_rw.as<float>();
@@ -703,17 +764,34 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.pw = ws.path_pw.as<float>(); y.cap = cap;
     y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>(); y.zeros = ws.path_zeros.as<float>();
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
+    y.W1 = h->W[1]; y.Y = nullptr; y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
+    y.no_bg = no_bg ? 1 : 0;
+    if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the KFAC path (bench.py roofline)
+    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y, scratch);
+    LGNN_HIP_CHECK(hipGetLastError());
+    if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
+  }
+  // the overflow route: gated on the device (the host cannot know whether a batch needs it without a synchronisation), so its
+  // planes -- sized under the workspace cap -- exist from the first call on
+  const int64_t per_class = N * H * 4;
+  const int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ce - cb, 64),
+                                                                h->ws_limit / std::max<int64_t>(per_class, 1)));
+  LGNN_CALL(ws.planes_a.reserve(size_t(cc_max) * N * H * 4));
+  ws.planes_a_zero_ptr = nullptr;
+  for (int64_t c0 = cb; c0 < ce; c0 += cc_max) {
+    const int64_t R = std::min(cc_max, ce - c0);
+    YArgs y{};
+    y.rowptr = h->PT.rowptr; y.col = h->PT.col; y.val = h->PT.val;
+    y.rptr = ws.path_rptr.as<int32_t>(); y.r_m = ws.path_rm.as<int32_t>(); y.r_w = ws.path_rw.as<float>();
+    y.pptr = ws.path_pptr.as<int32_t>(); y.cap = cap;
+    y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>(); y.zeros = ws.path_zeros.as<float>();
+    y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
     y.W1 = h->W[1]; y.Y = ws.planes_a.as<float>(); y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
     const unsigned threads = unsigned(64 * cdiv(H, 64) * cdiv(R, 32));  // (column groups) x (32-class row tiles) waves
-    // one persistent workgroup per CU (its ~100 KiB of LDS admit no second one)
-    hipLaunchKernelGGL(ybuild_pipe_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(threads), 0, s, y);
-    // (returns at once unless the path list overflowed its buffer: then this launch does the work, enumerating on the fly)
     hipLaunchKernelGGL(ybuild_kernel, dim3(unsigned(std::min<int64_t>(N, 1024))), dim3(threads), 0, s, y);
     LGNN_HIP_CHECK(hipGetLastError());
-    if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the KFAC path (bench.py roofline)
-    LGNN_CALL(launch_gram256_stream(y.Y, N * R, H, scratch, ws.path_zeros.as<float>(), s));
-    if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
+    LGNN_CALL(launch_gram256_stream(y.Y, N * R, H, scratch, ws.path_zeros.as<float>(), s, ws.path_pptr.as<int32_t>() + N, cap));
   }
   return 0;
 }
