@@ -577,6 +577,120 @@ __global__ __launch_bounds__(512, 2) void paths_fused_kernel(YArgs a, float* __r
   }
 }
 
+// The two-kernel variant of the same route (LGNN_PATHS_SPLIT=1; the overflow route's consumer is the same streaming Gram): the
+// products as in paths_fused_kernel, but Y[n] leaves for HBM -- through the LDS tile, so that every store is 16 bytes per lane
+// and a wave instruction covers 1 KiB of the node's contiguous R x H block (4-byte stores straight from the 32 x 32
+// accumulator layout are store-ISSUE bound: 256 instructions per node, 1.7 ms per batch on their own) -- and it leaves one
+// node late: vector-memory operations retire in issue order, so stores issued right after their products would be the
+// youngest operations in flight at the next window's vmcnt(0) and every node would pay a store round trip.
+__global__ __launch_bounds__(512, 2) void ybuild_wide_kernel(YArgs a) {
+  __shared__ FusedShared sh;
+  if (int64_t(a.pptr[a.N]) > a.cap) return;
+  const YRole ro = y_role(a, true);
+  const int tid = threadIdx.x, H = a.H, lane = ro.lane;
+  const bool no_bg = a.no_bg != 0;
+  const int rtiles = (a.R + 31) >> 5, ncg = (H + 63) >> 6;
+  const bool path_wave = ro.rt < rtiles && ro.cg < ncg;
+  float w1r[2][16];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int colc = 64 * ro.cg + 32 * ct + ro.li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * ro.rt + 4 * ro.half + (r & 3) + 8 * (r >> 2);
+      w1r[ct][r] = (path_wave && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * H + colc] : 0.f;
+    }
+  }
+  const int h4 = H >> 2, npiece = a.R * h4;  // 16-byte pieces of a node's block
+  constexpr int NQ = (kYRows * 64 + 511) / 512;
+  float4 yq[NQ];
+  float* __restrict__ yprev_p = nullptr;
+  auto store_prev = [&]() {
+    if (yprev_p == nullptr) return;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int q = tid + 512 * k;
+      if (q < npiece) *reinterpret_cast<float4*>(yprev_p + 4 * q) = yq[k];
+    }
+  };
+  const int64_t stride = gridDim.x;
+  const int64_t cnt = a.N > int64_t(blockIdx.x) ? (a.N - blockIdx.x + stride - 1) / stride : 0;
+  auto range = [&](int64_t i, int32_t& p0, int32_t& p1) {
+    p0 = p1 = 0;
+    if (i < cnt) { const int64_t n = blockIdx.x + i * stride; p0 = a.pptr[n]; p1 = a.pptr[n + 1]; }
+  };
+  int32_t p0c, p1c, p0n, p1n;
+  range(0, p0c, p1c);
+  int kwc = min(kWin, p1c - p0c);
+  if (tid < kwc) { sh.meta[0].m[tid] = a.pm[p0c + tid]; sh.meta[0].v[tid] = a.pv[p0c + tid]; sh.meta[0].w[tid] = a.pw[p0c + tid]; }
+  __syncthreads();
+  stage_dma(a, sh.win[0], sh.meta[0], kwc, ro.wave, 8, lane);
+  if (tid < 8 * kWin) sh.win[0].mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta[0], kwc, tid);
+  range(1, p0n, p1n);
+  int kwn = min(kWin, p1n - p0n);
+  int32_t trm = 0, trv = 0;
+  float trw = 0.f;
+  if (tid < kwn) { trm = a.pm[p0n + tid]; trv = a.pv[p0n + tid]; trw = a.pw[p0n + tid]; }
+
+  for (int64_t i = 0; i < cnt; ++i) {
+    const int b = int(i & 1), ms = int(i % 3), msn = int((i + 1) % 3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid < kwn) { sh.meta[msn].m[tid] = trm; sh.meta[msn].v[tid] = trv; sh.meta[msn].w[tid] = trw; }
+    lds_barrier();
+    store_prev();  // Y[node i - 1]: 1 KiB per wave instruction, behind this node's products
+    stage_dma(a, sh.win[b ^ 1], sh.meta[msn], kwn, ro.wave, 8, lane);
+    uint32_t mwn = 0;
+    if (tid < 8 * kWin) mwn = load_mask_word(a, sh.meta[msn], kwn, tid);
+    int32_t p0nn, p1nn;
+    range(i + 2, p0nn, p1nn);
+    const int kwnn = min(kWin, p1nn - p0nn);
+    trm = 0; trv = 0; trw = 0.f;
+    if (tid < kwnn) { trm = a.pm[p0nn + tid]; trv = a.pv[p0nn + tid]; trw = a.pw[p0nn + tid]; }
+    f32x16 t1[2], y2[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
+    if (path_wave) mfma_window(sh.win[b], sh.meta[ms], kwc, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
+    for (int32_t wb = p0c + kWin; wb < p1c; wb += kWin) {
+      const int kw = min(kWin, p1c - wb);
+      lds_barrier();
+      if (tid < kw) { sh.meta[3].m[tid] = a.pm[wb + tid]; sh.meta[3].v[tid] = a.pv[wb + tid]; sh.meta[3].w[tid] = a.pw[wb + tid]; }
+      lds_barrier();
+      stage_dma(a, sh.win[b], sh.meta[3], kw, ro.wave, 8, lane);
+      if (tid < 8 * kWin) sh.win[b].mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta[3], kw, tid);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();
+      if (path_wave) mfma_window(sh.win[b], sh.meta[3], kw, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
+    }
+    if (path_wave) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int colc = 64 * ro.cg + 32 * ct + ro.li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * ro.rt + 4 * ro.half + (r & 3) + 8 * (r >> 2);
+          if (colc < H && row < a.R) sh.y[row][colc] = w1r[ct][r] * t1[ct][r] + y2[ct][r];
+        }
+      }
+    }
+    if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = mwn;
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {  // this thread's 16-byte pieces of the node's block, kept for the top of the next node
+      const int q = tid + 512 * k;
+      if (q < npiece) {
+        const int row = q / h4, c4 = q - row * h4;
+        yq[k] = *reinterpret_cast<const float4*>(&sh.y[row][4 * c4]);
+      }
+    }
+    yprev_p = a.Y + (blockIdx.x + i * stride) * int64_t(a.R) * H;
+    p0c = p0n; p1c = p1n; kwc = kwn;
+    p0n = p0nn; p1n = p1nn; kwn = kwnn;
+  }
+  store_prev();
+}
+
 constexpr int kSlots = 3;
 constexpr int kBlockRows = 32;
 
@@ -654,7 +768,11 @@ __device__ __forceinline__ void stream_wave(const GramStreamArgs& a, float* tile
 
 __global__ __launch_bounds__(512, 2) void gram256_stream_kernel(GramStreamArgs a) {
   __shared__ float tiles[kSlots * kBlockRows * 256];  // 96 KiB: ONE LDS object (a second one makes hipcc drain vmcnt)
-  if (a.gate != nullptr && int64_t(*a.gate) <= a.gate_cap) return;
+  // gate_cap >= 0: run only when the path list overflowed (*gate > gate_cap); gate_cap < 0: only when it did not
+  if (a.gate != nullptr) {
+    const int64_t total = *a.gate;
+    if (a.gate_cap >= 0 ? total <= a.gate_cap : total > -a.gate_cap - 1) return;
+  }
   const int lane = threadIdx.x & 63;
   const int hw = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
   const int64_t nblocks = (a.rows + kBlockRows - 1) / kBlockRows;
@@ -755,6 +873,7 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
   // buffer do the two launches behind it run: the enumerating Y builder (planes in HBM, under the workspace cap) and the
   // streaming Gram over them; otherwise they return at once and no plane is ever allocated.
   LGNN_REQUIRE(N < (int64_t(1) << 31), "too many nodes for one launch");
+  const bool split = getenv("LGNN_PATHS_SPLIT") != nullptr;
   for (int64_t c0 = cb; c0 < ce; c0 += kYRows) {
     const int64_t R = std::min<int64_t>(kYRows, ce - c0);
     YArgs y{};
@@ -766,8 +885,17 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
     y.W1 = h->W[1]; y.Y = nullptr; y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
-    if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the KFAC path (bench.py roofline)
-    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y, scratch);
+    if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel(s) of the KFAC path (bench.py roofline)
+    if (!split) {
+      hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y, scratch);
+    } else {  // dev A/B: Y through HBM (wide stores), then the streaming Gram
+      LGNN_CALL(ws.planes_a.reserve(size_t(kYRows) * N * H * 4));
+      ws.planes_a_zero_ptr = nullptr;
+      y.Y = ws.planes_a.as<float>();
+      hipLaunchKernelGGL(ybuild_wide_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y);
+      // (gate inverted: runs when the list did NOT overflow -- a cap of INT64_MAX never lets the gate close)
+      LGNN_CALL(launch_gram256_stream(y.Y, N * R, H, scratch, ws.path_zeros.as<float>(), s, ws.path_pptr.as<int32_t>() + N, -cap - 1));
+    }
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }
