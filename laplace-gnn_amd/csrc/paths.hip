@@ -189,6 +189,8 @@ struct YMeta {                  // the window's triples
   float w[kWin];
 };
 
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ void lds_dma16(const float* src, float* lds_dst) {
   __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
                                             reinterpret_cast<uintptr_t>(lds_dst)), 16, 0, 0);
@@ -265,6 +267,59 @@ __device__ __forceinline__ void mfma_window(const YWin& win, const YMeta& mt, in
   }
 }
 
+// The second row tile (classes 32 .. 47 of the chunk) on v_mfma_f32_16x16x4_f32: a 16-class tile has no padding rows to multiply
+// (C = 40: a 32-row tile would spend three quarters of its work on rows 40 .. 63) and takes half the matrix-pipe time per path.
+// Lane l: A row i = l & 15 (class), B column = l & 15 (four 16-column tiles per wave), k = l >> 4 (four paths per step);
+// C / D: col = l & 15, row = 4 (l >> 4) + r.  Dependent MFMAs on one accumulator are four instructions apart (latency 40 > issue 32).
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+struct YOps16 { float aa, ab, ag, mf[4], bb[4], gg[4]; };
+__device__ __forceinline__ void y_load_ops16(const YWin& win, const YMeta& mt, int kw, int ks, int lane, int cls16, int cg, int H,
+                                             YOps16& o) {
+  const int jr = 4 * ks + (lane >> 4);
+  const bool valid = jr < kw;
+  const int j = valid ? jr : 0;  // (a staged row: what sits past the window's end may not be finite)
+  const float wj = valid ? mt.w[j] : 0.f;
+  o.aa = wj * win.coef[j][cls16]; o.ab = wj * win.coef[j][kCoefStride + cls16]; o.ag = wj * win.coef[j][2 * kCoefStride + cls16];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int col = 64 * cg + 16 * ct + (lane & 15);
+    const int colc = col < H ? col : 0;
+    const uint32_t word = win.mask[j][colc >> 5];
+    o.mf[ct] = (valid && col < H && ((word >> (colc & 31)) & 1u)) ? 1.f : 0.f;
+    o.bb[ct] = o.mf[ct] * win.bg[j][0][colc];
+    o.gg[ct] = o.mf[ct] * win.bg[j][1][colc];
+  }
+}
+__device__ __forceinline__ void y_mfma_ops16(const YOps16& o, bool no_bg, f32x4v (&t1)[4], f32x4v (&y2)[4]) {
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) t1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.aa, o.mf[ct], t1[ct], 0, 0, 0);
+  if (!no_bg) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) y2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.ab, o.bb[ct], y2[ct], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) y2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.ag, o.gg[ct], y2[ct], 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void mfma_window16(const YWin& win, const YMeta& mt, int kw, int lane, int cls16, int cg, int H,
+                                              bool no_bg, f32x4v (&t1)[4], f32x4v (&y2)[4]) {
+  const int nks = (kw + 3) >> 2;
+  if (nks == 0) return;
+  YOps16 oa, ob;
+  y_load_ops16(win, mt, kw, 0, lane, cls16, cg, H, oa);
+  for (int ks = 0; ks < nks; ks += 2) {
+    y_load_ops16(win, mt, kw, ks + 1, lane, cls16, cg, H, ob);  // (past the end: zero weights on a staged row)
+    __builtin_amdgcn_sched_barrier(0);
+    y_mfma_ops16(oa, no_bg, t1, y2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < nks) {
+      y_load_ops16(win, mt, kw, ks + 2, lane, cls16, cg, H, oa);
+      __builtin_amdgcn_sched_barrier(0);
+      y_mfma_ops16(ob, no_bg, t1, y2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // Role of a wave: (rt, cg) owns the 32-class row tile rt (classes c0 + 32 rt ...) and the columns [64 cg, 64 cg + 64) of
 // Y[n]: two 32 x 32 accumulator tiles for the alpha product and two for the beta / gamma products; waves w and w + 4 (the
 // two row tiles of one column group) share a SIMD.
@@ -291,6 +346,126 @@ __device__ __forceinline__ YRole y_role(const YArgs& a, bool fixed8 = false) {
     if (!r.col_ok[ct]) r.colv[ct] = 0;
   }
   return r;
+}
+
+// One node's products into the LDS tile `ytile` [rows][256]: the first window is in win[b] (meta slot ms), further windows
+// (hubs) are restaged in place -- every wave of the workgroup takes part in the barriers of that loop, whatever its role.
+// RT1 = false: the wave owns classes [0, 32) x 64 columns (32 x 32 x 2 MFMA); RT1 = true: classes [32, 48) x 64 columns
+// (16 x 16 x 4 MFMA).  W_1's slice of the wave stays in registers for the whole launch.
+template <bool RT1>
+struct YRegs {
+  float w1r[RT1 ? 4 : 2][RT1 ? 4 : 16];
+};
+template <bool RT1>
+__device__ __forceinline__ void y_load_w1(const YArgs& a, const YRole& ro, bool path_wave, YRegs<RT1>& g) {
+  const int H = a.H;
+  if constexpr (!RT1) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int colc = 64 * ro.cg + 32 * ct + ro.li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 4 * ro.half + (r & 3) + 8 * (r >> 2);
+        g.w1r[ct][r] = (path_wave && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * H + colc] : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int colc = 64 * ro.cg + 16 * ct + (ro.lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 32 + 4 * (ro.lane >> 4) + r;
+        g.w1r[ct][r] = (path_wave && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * H + colc] : 0.f;
+      }
+    }
+  }
+}
+template <bool RT1>
+__device__ __forceinline__ void y_node_products(const YArgs& a, YWin (&win)[2], YMeta (&meta)[4], float (*ytile)[256],
+                                                const YRole& ro, bool path_wave, const YRegs<RT1>& g, int b, int ms, int kwc,
+                                                int32_t p0c, int32_t p1c) {
+  const int tid = threadIdx.x, H = a.H, lane = ro.lane;
+  const bool no_bg = a.no_bg != 0;
+  const int cls16 = min(a.c0 + 32 + (lane & 15), kCoefStride - 1);
+  f32x16 t1[2], y2[2];
+  f32x4v u1[4], u2[4];
+  if constexpr (!RT1) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
+    if (path_wave) mfma_window(win[b], meta[ms], kwc, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { u1[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; u2[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    if (path_wave) mfma_window16(win[b], meta[ms], kwc, lane, cls16, ro.cg, H, no_bg, u1, u2);
+  }
+  for (int32_t wb = p0c + kWin; wb < p1c; wb += kWin) {  // hubs: further windows, restaged in place (not overlapped)
+    const int kw = min(kWin, p1c - wb);
+    lds_barrier();
+    if (tid < kw) { meta[3].m[tid] = a.pm[wb + tid]; meta[3].v[tid] = a.pv[wb + tid]; meta[3].w[tid] = a.pw[wb + tid]; }
+    lds_barrier();
+    stage_dma(a, win[b], meta[3], kw, ro.wave, 8, lane);
+    if (tid < 8 * kWin) win[b].mask[tid >> 3][tid & 7] = load_mask_word(a, meta[3], kw, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (path_wave) {
+      if constexpr (!RT1) mfma_window(win[b], meta[3], kw, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
+      else mfma_window16(win[b], meta[3], kw, lane, cls16, ro.cg, H, no_bg, u1, u2);
+    }
+  }
+  // Y[n] into the LDS tile (readers of the previous node's tile passed this node's first barrier)
+  if (path_wave) {
+    if constexpr (!RT1) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int colc = 64 * ro.cg + 32 * ct + ro.li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 4 * ro.half + (r & 3) + 8 * (r >> 2);
+          if (colc < H && row < a.R) ytile[row][colc] = g.w1r[ct][r] * t1[ct][r] + y2[ct][r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int colc = 64 * ro.cg + 16 * ct + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 32 + 4 * (lane >> 4) + r;
+          if (colc < H && row < a.R) ytile[row][colc] = g.w1r[ct][r] * u1[ct][r] + u2[ct][r];
+        }
+      }
+    }
+  }
+}
+
+// The part of the node loop both persistent kernels share: prologue (node 0's window in flight, node 1's triples in
+// registers) and, per node, the top of the iteration (wait, publish the next triples, barrier, start the next window).
+struct YPipe {
+  int32_t p0c, p1c, p0n, p1n, trm, trv;
+  float trw;
+  int kwc, kwn;
+  uint32_t mwn;
+};
+__device__ __forceinline__ void y_range(const YArgs& a, int64_t cnt, int64_t i, int32_t& p0, int32_t& p1) {
+  p0 = p1 = 0;
+  if (i < cnt) { const int64_t n = blockIdx.x + i * int64_t(gridDim.x); p0 = a.pptr[n]; p1 = a.pptr[n + 1]; }
+}
+__device__ __forceinline__ void y_pipe_prologue(const YArgs& a, YWin (&win)[2], YMeta (&meta)[4], const YRole& ro, int64_t cnt,
+                                                YPipe& pp) {
+  const int tid = threadIdx.x;
+  y_range(a, cnt, 0, pp.p0c, pp.p1c);
+  pp.kwc = min(kWin, pp.p1c - pp.p0c);
+  if (tid < pp.kwc) { meta[0].m[tid] = a.pm[pp.p0c + tid]; meta[0].v[tid] = a.pv[pp.p0c + tid]; meta[0].w[tid] = a.pw[pp.p0c + tid]; }
+  __syncthreads();
+  stage_dma(a, win[0], meta[0], pp.kwc, ro.wave, 8, ro.lane);
+  if (tid < 8 * kWin) win[0].mask[tid >> 3][tid & 7] = load_mask_word(a, meta[0], pp.kwc, tid);
+  y_range(a, cnt, 1, pp.p0n, pp.p1n);
+  pp.kwn = min(kWin, pp.p1n - pp.p0n);
+  pp.trm = 0; pp.trv = 0; pp.trw = 0.f;
+  if (tid < pp.kwn) { pp.trm = a.pm[pp.p0n + tid]; pp.trv = a.pv[pp.p0n + tid]; pp.trw = a.pw[pp.p0n + tid]; }
 }
 
 // The fallback when the batch's path list does not fit its buffer (very large batches on hub-heavy graphs): a grid-stride loop
@@ -428,15 +603,13 @@ struct FusedShared {
   float y[kYRows][256];
 };
 
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 template <int W, int LO, int HI>
 __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, float* __restrict__ scratch) {
   constexpr int NT = HI - LO;
+  constexpr bool RT1 = LO != 0;  // hardware waves 4 .. 7: the second class tile, the second half of the SIMD pair's sub-tiles
   const YRole ro = y_role(a, true);
   const int tid = threadIdx.x, H = a.H, lane = ro.lane;
-  const bool no_bg = a.no_bg != 0;
-  const int rtiles = (a.R + 31) >> 5, ncg = (H + 63) >> 6;
+  const int rtiles = a.R > 32 ? 2 : 1, ncg = (H + 63) >> 6;
   const bool path_wave = ro.rt < rtiles && ro.cg < ncg;  // (H <= 192 or R <= 32: some waves only stage and contract)
   const int r2 = (a.R + 1) & ~1;                          // rows the Gram reads (an odd class count: one zero row)
   f32x16 acc[NT];
@@ -444,86 +617,32 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
   for (int s = 0; s < NT; ++s)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-  // ---- this wave's slice of W_1 (C / D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-  float w1r[2][16];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int colc = 64 * ro.cg + 32 * ct + ro.li;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * ro.rt + 4 * ro.half + (r & 3) + 8 * (r >> 2);
-      w1r[ct][r] = (path_wave && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * H + colc] : 0.f;
-    }
-  }
+  YRegs<RT1> g;
+  y_load_w1<RT1>(a, ro, path_wave, g);
   // the tile is zero where nobody writes: columns >= H, the odd row out
   for (int q = tid; q < kYRows * 256; q += 512) (&sh.y[0][0])[q] = 0.f;
-
   const int64_t stride = gridDim.x;
   const int64_t cnt = a.N > int64_t(blockIdx.x) ? (a.N - blockIdx.x + stride - 1) / stride : 0;
-  auto range = [&](int64_t i, int32_t& p0, int32_t& p1) {
-    p0 = p1 = 0;
-    if (i < cnt) { const int64_t n = blockIdx.x + i * stride; p0 = a.pptr[n]; p1 = a.pptr[n + 1]; }
-  };
-  // ---- prologue: node 0's first window in flight, node 1's triples in registers
-  int32_t p0c, p1c, p0n, p1n;
-  range(0, p0c, p1c);
-  int kwc = min(kWin, p1c - p0c);
-  if (tid < kwc) { sh.meta[0].m[tid] = a.pm[p0c + tid]; sh.meta[0].v[tid] = a.pv[p0c + tid]; sh.meta[0].w[tid] = a.pw[p0c + tid]; }
-  __syncthreads();
-  stage_dma(a, sh.win[0], sh.meta[0], kwc, ro.wave, 8, lane);
-  if (tid < 8 * kWin) sh.win[0].mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta[0], kwc, tid);
-  range(1, p0n, p1n);
-  int kwn = min(kWin, p1n - p0n);
-  int32_t trm = 0, trv = 0;
-  float trw = 0.f;
-  if (tid < kwn) { trm = a.pm[p0n + tid]; trv = a.pv[p0n + tid]; trw = a.pw[p0n + tid]; }
-
+  YPipe pp;
+  y_pipe_prologue(a, sh.win, sh.meta, ro, cnt, pp);
   for (int64_t i = 0; i < cnt; ++i) {
     const int b = int(i & 1), ms = int(i % 3), msn = int((i + 1) % 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // node i's window has landed; node i + 1's triples are in registers
-    if (tid < kwn) { sh.meta[msn].m[tid] = trm; sh.meta[msn].v[tid] = trv; sh.meta[msn].w[tid] = trw; }
+    if (tid < pp.kwn) { sh.meta[msn].m[tid] = pp.trm; sh.meta[msn].v[tid] = pp.trv; sh.meta[msn].w[tid] = pp.trw; }
     lds_barrier();  // window i visible to all waves; everybody is done with node i - 1 (its Gram, the other window buffer;
                     // meta slot msn's previous tenant is three nodes back)
     // ---- asynchronous, behind this node's work: node i + 1's window, its mask words, node i + 2's triples
-    stage_dma(a, sh.win[b ^ 1], sh.meta[msn], kwn, ro.wave, 8, lane);
-    uint32_t mwn = 0;
-    if (tid < 8 * kWin) mwn = load_mask_word(a, sh.meta[msn], kwn, tid);
+    stage_dma(a, sh.win[b ^ 1], sh.meta[msn], pp.kwn, ro.wave, 8, lane);
+    pp.mwn = 0;
+    if (tid < 8 * kWin) pp.mwn = load_mask_word(a, sh.meta[msn], pp.kwn, tid);
     int32_t p0nn, p1nn;
-    range(i + 2, p0nn, p1nn);
+    y_range(a, cnt, i + 2, p0nn, p1nn);
     const int kwnn = min(kWin, p1nn - p0nn);
-    trm = 0; trv = 0; trw = 0.f;
-    if (tid < kwnn) { trm = a.pm[p0nn + tid]; trv = a.pv[p0nn + tid]; trw = a.pw[p0nn + tid]; }
-    // ---- (1) the path products of node i
-    f32x16 t1[2], y2[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
-    if (path_wave) mfma_window(sh.win[b], sh.meta[ms], kwc, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
-    for (int32_t wb = p0c + kWin; wb < p1c; wb += kWin) {  // hubs: further windows, restaged in place (not overlapped)
-      const int kw = min(kWin, p1c - wb);
-      lds_barrier();
-      if (tid < kw) { sh.meta[3].m[tid] = a.pm[wb + tid]; sh.meta[3].v[tid] = a.pv[wb + tid]; sh.meta[3].w[tid] = a.pw[wb + tid]; }
-      lds_barrier();
-      stage_dma(a, sh.win[b], sh.meta[3], kw, ro.wave, 8, lane);
-      if (tid < 8 * kWin) sh.win[b].mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta[3], kw, tid);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      lds_barrier();
-      if (path_wave) mfma_window(sh.win[b], sh.meta[3], kw, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
-    }
-    // ---- (2) Y[n] into the LDS tile (readers of the previous node's tile passed this node's first barrier)
-    if (path_wave) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const int colc = 64 * ro.cg + 32 * ct + ro.li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 32 * ro.rt + 4 * ro.half + (r & 3) + 8 * (r >> 2);
-          if (colc < H && row < a.R) sh.y[row][colc] = w1r[ct][r] * t1[ct][r] + y2[ct][r];
-        }
-      }
-    }
-    if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = mwn;  // (readers of that buffer passed this node's barrier)
+    pp.trm = 0; pp.trv = 0; pp.trw = 0.f;
+    if (tid < kwnn) { pp.trm = a.pm[p0nn + tid]; pp.trv = a.pv[p0nn + tid]; pp.trw = a.pw[p0nn + tid]; }
+    // ---- (1) + (2): the path products of node i, Y[n] into the LDS tile
+    y_node_products<RT1>(a, sh.win, sh.meta, sh.y, ro, path_wave, g, b, ms, pp.kwc, pp.p0c, pp.p1c);
+    if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = pp.mwn;  // (readers of that buffer passed this node's barrier)
     lds_barrier();  // raw: a __syncthreads() here would drain the copies in flight for node i + 1
     // ---- (3) S += Y[n]^T Y[n], rows two at a time (operands of step k + 1 read before the MFMAs of step k)
     {
@@ -544,8 +663,8 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
         }
       }
     }
-    p0c = p0n; p1c = p1n; kwc = kwn;
-    p0n = p0nn; p1n = p1nn; kwn = kwnn;
+    pp.p0c = pp.p0n; pp.p1c = pp.p1n; pp.kwc = pp.kwn;
+    pp.p0n = p0nn; pp.p1n = p1nn; pp.kwn = kwnn;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -583,24 +702,15 @@ __global__ __launch_bounds__(512, 2) void paths_fused_kernel(YArgs a, float* __r
 // accumulator layout are store-ISSUE bound: 256 instructions per node, 1.7 ms per batch on their own) -- and it leaves one
 // node late: vector-memory operations retire in issue order, so stores issued right after their products would be the
 // youngest operations in flight at the next window's vmcnt(0) and every node would pay a store round trip.
-__global__ __launch_bounds__(512, 2) void ybuild_wide_kernel(YArgs a) {
-  __shared__ FusedShared sh;
-  if (int64_t(a.pptr[a.N]) > a.cap) return;
+template <bool RT1>
+__device__ __forceinline__ void wide_wave(const YArgs& a, FusedShared& sh) {
   const YRole ro = y_role(a, true);
   const int tid = threadIdx.x, H = a.H, lane = ro.lane;
-  const bool no_bg = a.no_bg != 0;
-  const int rtiles = (a.R + 31) >> 5, ncg = (H + 63) >> 6;
+  const int rtiles = a.R > 32 ? 2 : 1, ncg = (H + 63) >> 6;
   const bool path_wave = ro.rt < rtiles && ro.cg < ncg;
-  float w1r[2][16];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int colc = 64 * ro.cg + 32 * ct + ro.li;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * ro.rt + 4 * ro.half + (r & 3) + 8 * (r >> 2);
-      w1r[ct][r] = (path_wave && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * H + colc] : 0.f;
-    }
-  }
+  YRegs<RT1> g;
+  y_load_w1<RT1>(a, ro, path_wave, g);
+  for (int q = tid; q < kYRows * 256; q += 512) (&sh.y[0][0])[q] = 0.f;
   const int h4 = H >> 2, npiece = a.R * h4;  // 16-byte pieces of a node's block
   constexpr int NQ = (kYRows * 64 + 511) / 512;
   float4 yq[NQ];
@@ -615,66 +725,24 @@ __global__ __launch_bounds__(512, 2) void ybuild_wide_kernel(YArgs a) {
   };
   const int64_t stride = gridDim.x;
   const int64_t cnt = a.N > int64_t(blockIdx.x) ? (a.N - blockIdx.x + stride - 1) / stride : 0;
-  auto range = [&](int64_t i, int32_t& p0, int32_t& p1) {
-    p0 = p1 = 0;
-    if (i < cnt) { const int64_t n = blockIdx.x + i * stride; p0 = a.pptr[n]; p1 = a.pptr[n + 1]; }
-  };
-  int32_t p0c, p1c, p0n, p1n;
-  range(0, p0c, p1c);
-  int kwc = min(kWin, p1c - p0c);
-  if (tid < kwc) { sh.meta[0].m[tid] = a.pm[p0c + tid]; sh.meta[0].v[tid] = a.pv[p0c + tid]; sh.meta[0].w[tid] = a.pw[p0c + tid]; }
-  __syncthreads();
-  stage_dma(a, sh.win[0], sh.meta[0], kwc, ro.wave, 8, lane);
-  if (tid < 8 * kWin) sh.win[0].mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta[0], kwc, tid);
-  range(1, p0n, p1n);
-  int kwn = min(kWin, p1n - p0n);
-  int32_t trm = 0, trv = 0;
-  float trw = 0.f;
-  if (tid < kwn) { trm = a.pm[p0n + tid]; trv = a.pv[p0n + tid]; trw = a.pw[p0n + tid]; }
-
+  YPipe pp;
+  y_pipe_prologue(a, sh.win, sh.meta, ro, cnt, pp);
   for (int64_t i = 0; i < cnt; ++i) {
     const int b = int(i & 1), ms = int(i % 3), msn = int((i + 1) % 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid < kwn) { sh.meta[msn].m[tid] = trm; sh.meta[msn].v[tid] = trv; sh.meta[msn].w[tid] = trw; }
+    if (tid < pp.kwn) { sh.meta[msn].m[tid] = pp.trm; sh.meta[msn].v[tid] = pp.trv; sh.meta[msn].w[tid] = pp.trw; }
     lds_barrier();
     store_prev();  // Y[node i - 1]: 1 KiB per wave instruction, behind this node's products
-    stage_dma(a, sh.win[b ^ 1], sh.meta[msn], kwn, ro.wave, 8, lane);
-    uint32_t mwn = 0;
-    if (tid < 8 * kWin) mwn = load_mask_word(a, sh.meta[msn], kwn, tid);
+    stage_dma(a, sh.win[b ^ 1], sh.meta[msn], pp.kwn, ro.wave, 8, lane);
+    pp.mwn = 0;
+    if (tid < 8 * kWin) pp.mwn = load_mask_word(a, sh.meta[msn], pp.kwn, tid);
     int32_t p0nn, p1nn;
-    range(i + 2, p0nn, p1nn);
+    y_range(a, cnt, i + 2, p0nn, p1nn);
     const int kwnn = min(kWin, p1nn - p0nn);
-    trm = 0; trv = 0; trw = 0.f;
-    if (tid < kwnn) { trm = a.pm[p0nn + tid]; trv = a.pv[p0nn + tid]; trw = a.pw[p0nn + tid]; }
-    f32x16 t1[2], y2[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
-    if (path_wave) mfma_window(sh.win[b], sh.meta[ms], kwc, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
-    for (int32_t wb = p0c + kWin; wb < p1c; wb += kWin) {
-      const int kw = min(kWin, p1c - wb);
-      lds_barrier();
-      if (tid < kw) { sh.meta[3].m[tid] = a.pm[wb + tid]; sh.meta[3].v[tid] = a.pv[wb + tid]; sh.meta[3].w[tid] = a.pw[wb + tid]; }
-      lds_barrier();
-      stage_dma(a, sh.win[b], sh.meta[3], kw, ro.wave, 8, lane);
-      if (tid < 8 * kWin) sh.win[b].mask[tid >> 3][tid & 7] = load_mask_word(a, sh.meta[3], kw, tid);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      lds_barrier();
-      if (path_wave) mfma_window(sh.win[b], sh.meta[3], kw, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
-    }
-    if (path_wave) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const int colc = 64 * ro.cg + 32 * ct + ro.li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 32 * ro.rt + 4 * ro.half + (r & 3) + 8 * (r >> 2);
-          if (colc < H && row < a.R) sh.y[row][colc] = w1r[ct][r] * t1[ct][r] + y2[ct][r];
-        }
-      }
-    }
-    if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = mwn;
+    pp.trm = 0; pp.trv = 0; pp.trw = 0.f;
+    if (tid < kwnn) { pp.trm = a.pm[p0nn + tid]; pp.trv = a.pv[p0nn + tid]; pp.trw = a.pw[p0nn + tid]; }
+    y_node_products<RT1>(a, sh.win, sh.meta, sh.y, ro, path_wave, g, b, ms, pp.kwc, pp.p0c, pp.p1c);
+    if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = pp.mwn;
     lds_barrier();
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {  // this thread's 16-byte pieces of the node's block, kept for the top of the next node
@@ -685,10 +753,16 @@ __global__ __launch_bounds__(512, 2) void ybuild_wide_kernel(YArgs a) {
       }
     }
     yprev_p = a.Y + (blockIdx.x + i * stride) * int64_t(a.R) * H;
-    p0c = p0n; p1c = p1n; kwc = kwn;
-    p0n = p0nn; p1n = p1nn; kwn = kwnn;
+    pp.p0c = pp.p0n; pp.p1c = pp.p1n; pp.kwc = pp.kwn;
+    pp.p0n = p0nn; pp.p1n = p1nn; pp.kwn = kwnn;
   }
   store_prev();
+}
+__global__ __launch_bounds__(512, 2) void ybuild_wide_kernel(YArgs a) {
+  __shared__ FusedShared sh;
+  if (int64_t(a.pptr[a.N]) > a.cap) return;
+  if (threadIdx.x < 256) wide_wave<false>(a, sh);
+  else wide_wave<true>(a, sh);
 }
 
 constexpr int kSlots = 3;
