@@ -625,16 +625,16 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
   const int64_t cnt = a.N > int64_t(blockIdx.x) ? (a.N - blockIdx.x + stride - 1) / stride : 0;
   YPipe pp;
   y_pipe_prologue(a, sh.win, sh.meta, ro, cnt, pp);
+  // Per node: [wait, publish node i + 1's triples, barrier] path products of node i, tile write [barrier] Gram of node i.
+  // What node i + 1 needs from memory is started at the head of the GRAM phase by waves 4 .. 7 -- they own 4 of their SIMD's 9
+  // sub-tiles and wait for the matrix pipe anyway -- so the products start on operands that landed a whole Gram ago and
+  // nothing but LDS reads stands between a barrier and the first MFMA behind it.
   for (int64_t i = 0; i < cnt; ++i) {
     const int b = int(i & 1), ms = int(i % 3), msn = int((i + 1) % 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // node i's window has landed; node i + 1's triples are in registers
     if (tid < pp.kwn) { sh.meta[msn].m[tid] = pp.trm; sh.meta[msn].v[tid] = pp.trv; sh.meta[msn].w[tid] = pp.trw; }
-    lds_barrier();  // window i visible to all waves; everybody is done with node i - 1 (its Gram, the other window buffer;
-                    // meta slot msn's previous tenant is three nodes back)
-    // ---- asynchronous, behind this node's work: node i + 1's window, its mask words, node i + 2's triples
-    stage_dma(a, sh.win[b ^ 1], sh.meta[msn], pp.kwn, ro.wave, 8, lane);
-    pp.mwn = 0;
-    if (tid < 8 * kWin) pp.mwn = load_mask_word(a, sh.meta[msn], pp.kwn, tid);
+    lds_barrier();  // window i visible to all waves; everybody is done with node i - 1's Gram; meta slot msn's previous
+                    // tenant is three nodes back
     int32_t p0nn, p1nn;
     y_range(a, cnt, i + 2, p0nn, p1nn);
     const int kwnn = min(kWin, p1nn - p0nn);
@@ -642,8 +642,15 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
     if (tid < kwnn) { pp.trm = a.pm[p0nn + tid]; pp.trv = a.pv[p0nn + tid]; pp.trw = a.pw[p0nn + tid]; }
     // ---- (1) + (2): the path products of node i, Y[n] into the LDS tile
     y_node_products<RT1>(a, sh.win, sh.meta, sh.y, ro, path_wave, g, b, ms, pp.kwc, pp.p0c, pp.p1c);
-    if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = pp.mwn;  // (readers of that buffer passed this node's barrier)
-    lds_barrier();  // raw: a __syncthreads() here would drain the copies in flight for node i + 1
+    lds_barrier();  // raw: a __syncthreads() would drain vector-memory operations in flight
+    // ---- node i + 1's window and mask words into the other buffer (its last readers: node i - 1's products)
+    if constexpr (RT1) {
+      const int t4 = tid - 256;
+      uint32_t mw = 0;
+      if (t4 < 8 * kWin) mw = load_mask_word(a, sh.meta[msn], pp.kwn, t4);  // (issued ahead of the copies: its wait is not theirs)
+      stage_dma(a, sh.win[b ^ 1], sh.meta[msn], pp.kwn, ro.wave - 4, 4, lane);
+      if (t4 < 8 * kWin) sh.win[b ^ 1].mask[t4 >> 3][t4 & 7] = mw;
+    }
     // ---- (3) S += Y[n]^T Y[n], rows two at a time (operands of step k + 1 read before the MFMAs of step k)
     {
       const float* __restrict__ base = &sh.y[0][0] + (lane >> 5) * 256 + (lane & 31);
@@ -694,75 +701,6 @@ __global__ __launch_bounds__(512, 2) void paths_fused_kernel(YArgs a, float* __r
     case 3: fused_wave<3, 0, 5>(a, sh, scratch); break;
     default: fused_wave<3, 5, 9>(a, sh, scratch); break;
   }
-}
-
-// The two-kernel variant of the same route (LGNN_PATHS_SPLIT=1; the overflow route's consumer is the same streaming Gram): the
-// products as in paths_fused_kernel, but Y[n] leaves for HBM -- through the LDS tile, so that every store is 16 bytes per lane
-// and a wave instruction covers 1 KiB of the node's contiguous R x H block (4-byte stores straight from the 32 x 32
-// accumulator layout are store-ISSUE bound: 256 instructions per node, 1.7 ms per batch on their own) -- and it leaves one
-// node late: vector-memory operations retire in issue order, so stores issued right after their products would be the
-// youngest operations in flight at the next window's vmcnt(0) and every node would pay a store round trip.
-template <bool RT1>
-__device__ __forceinline__ void wide_wave(const YArgs& a, FusedShared& sh) {
-  const YRole ro = y_role(a, true);
-  const int tid = threadIdx.x, H = a.H, lane = ro.lane;
-  const int rtiles = a.R > 32 ? 2 : 1, ncg = (H + 63) >> 6;
-  const bool path_wave = ro.rt < rtiles && ro.cg < ncg;
-  YRegs<RT1> g;
-  y_load_w1<RT1>(a, ro, path_wave, g);
-  for (int q = tid; q < kYRows * 256; q += 512) (&sh.y[0][0])[q] = 0.f;
-  const int h4 = H >> 2, npiece = a.R * h4;  // 16-byte pieces of a node's block
-  constexpr int NQ = (kYRows * 64 + 511) / 512;
-  float4 yq[NQ];
-  float* __restrict__ yprev_p = nullptr;
-  auto store_prev = [&]() {
-    if (yprev_p == nullptr) return;
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-      const int q = tid + 512 * k;
-      if (q < npiece) *reinterpret_cast<float4*>(yprev_p + 4 * q) = yq[k];
-    }
-  };
-  const int64_t stride = gridDim.x;
-  const int64_t cnt = a.N > int64_t(blockIdx.x) ? (a.N - blockIdx.x + stride - 1) / stride : 0;
-  YPipe pp;
-  y_pipe_prologue(a, sh.win, sh.meta, ro, cnt, pp);
-  for (int64_t i = 0; i < cnt; ++i) {
-    const int b = int(i & 1), ms = int(i % 3), msn = int((i + 1) % 3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid < pp.kwn) { sh.meta[msn].m[tid] = pp.trm; sh.meta[msn].v[tid] = pp.trv; sh.meta[msn].w[tid] = pp.trw; }
-    lds_barrier();
-    store_prev();  // Y[node i - 1]: 1 KiB per wave instruction, behind this node's products
-    stage_dma(a, sh.win[b ^ 1], sh.meta[msn], pp.kwn, ro.wave, 8, lane);
-    pp.mwn = 0;
-    if (tid < 8 * kWin) pp.mwn = load_mask_word(a, sh.meta[msn], pp.kwn, tid);
-    int32_t p0nn, p1nn;
-    y_range(a, cnt, i + 2, p0nn, p1nn);
-    const int kwnn = min(kWin, p1nn - p0nn);
-    pp.trm = 0; pp.trv = 0; pp.trw = 0.f;
-    if (tid < kwnn) { pp.trm = a.pm[p0nn + tid]; pp.trv = a.pv[p0nn + tid]; pp.trw = a.pw[p0nn + tid]; }
-    y_node_products<RT1>(a, sh.win, sh.meta, sh.y, ro, path_wave, g, b, ms, pp.kwc, pp.p0c, pp.p1c);
-    if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = pp.mwn;
-    lds_barrier();
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {  // this thread's 16-byte pieces of the node's block, kept for the top of the next node
-      const int q = tid + 512 * k;
-      if (q < npiece) {
-        const int row = q / h4, c4 = q - row * h4;
-        yq[k] = *reinterpret_cast<const float4*>(&sh.y[row][4 * c4]);
-      }
-    }
-    yprev_p = a.Y + (blockIdx.x + i * stride) * int64_t(a.R) * H;
-    pp.p0c = pp.p0n; pp.p1c = pp.p1n; pp.kwc = pp.kwn;
-    pp.p0n = p0nn; pp.p1n = p1nn; pp.kwn = kwnn;
-  }
-  store_prev();
-}
-__global__ __launch_bounds__(512, 2) void ybuild_wide_kernel(YArgs a) {
-  __shared__ FusedShared sh;
-  if (int64_t(a.pptr[a.N]) > a.cap) return;
-  if (threadIdx.x < 256) wide_wave<false>(a, sh);
-  else wide_wave<true>(a, sh);
 }
 
 constexpr int kSlots = 3;
@@ -842,11 +780,7 @@ __device__ __forceinline__ void stream_wave(const GramStreamArgs& a, float* tile
 
 __global__ __launch_bounds__(512, 2) void gram256_stream_kernel(GramStreamArgs a) {
   __shared__ float tiles[kSlots * kBlockRows * 256];  // 96 KiB: ONE LDS object (a second one makes hipcc drain vmcnt)
-  // gate_cap >= 0: run only when the path list overflowed (*gate > gate_cap); gate_cap < 0: only when it did not
-  if (a.gate != nullptr) {
-    const int64_t total = *a.gate;
-    if (a.gate_cap >= 0 ? total <= a.gate_cap : total > -a.gate_cap - 1) return;
-  }
+  if (a.gate != nullptr && int64_t(*a.gate) <= a.gate_cap) return;  // (the overflow route of the path kernels)
   const int lane = threadIdx.x & 63;
   const int hw = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
   const int64_t nblocks = (a.rows + kBlockRows - 1) / kBlockRows;
@@ -947,7 +881,6 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
   // buffer do the two launches behind it run: the enumerating Y builder (planes in HBM, under the workspace cap) and the
   // streaming Gram over them; otherwise they return at once and no plane is ever allocated.
   LGNN_REQUIRE(N < (int64_t(1) << 31), "too many nodes for one launch");
-  const bool split = getenv("LGNN_PATHS_SPLIT") != nullptr;
   for (int64_t c0 = cb; c0 < ce; c0 += kYRows) {
     const int64_t R = std::min<int64_t>(kYRows, ce - c0);
     YArgs y{};
@@ -960,16 +893,7 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.W1 = h->W[1]; y.Y = nullptr; y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel(s) of the KFAC path (bench.py roofline)
-    if (!split) {
-      hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y, scratch);
-    } else {  // dev A/B: Y through HBM (wide stores), then the streaming Gram
-      LGNN_CALL(ws.planes_a.reserve(size_t(kYRows) * N * H * 4));
-      ws.planes_a_zero_ptr = nullptr;
-      y.Y = ws.planes_a.as<float>();
-      hipLaunchKernelGGL(ybuild_wide_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y);
-      // (gate inverted: runs when the list did NOT overflow -- a cap of INT64_MAX never lets the gate close)
-      LGNN_CALL(launch_gram256_stream(y.Y, N * R, H, scratch, ws.path_zeros.as<float>(), s, ws.path_pptr.as<int32_t>() + N, -cap - 1));
-    }
+    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y, scratch);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }
