@@ -625,16 +625,16 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
   const int64_t cnt = a.N > int64_t(blockIdx.x) ? (a.N - blockIdx.x + stride - 1) / stride : 0;
   YPipe pp;
   y_pipe_prologue(a, sh.win, sh.meta, ro, cnt, pp);
-  // Per node: [wait, publish node i + 1's triples, barrier] path products of node i, tile write [barrier] Gram of node i.
-  // What node i + 1 needs from memory is started at the head of the GRAM phase by waves 4 .. 7 -- they own 4 of their SIMD's 9
-  // sub-tiles and wait for the matrix pipe anyway -- so the products start on operands that landed a whole Gram ago and
-  // nothing but LDS reads stands between a barrier and the first MFMA behind it.
   for (int64_t i = 0; i < cnt; ++i) {
     const int b = int(i & 1), ms = int(i % 3), msn = int((i + 1) % 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // node i's window has landed; node i + 1's triples are in registers
     if (tid < pp.kwn) { sh.meta[msn].m[tid] = pp.trm; sh.meta[msn].v[tid] = pp.trv; sh.meta[msn].w[tid] = pp.trw; }
-    lds_barrier();  // window i visible to all waves; everybody is done with node i - 1's Gram; meta slot msn's previous
-                    // tenant is three nodes back
+    lds_barrier();  // window i visible to all waves; everybody is done with node i - 1 (its Gram, the other window buffer;
+                    // meta slot msn's previous tenant is three nodes back)
+    // ---- asynchronous, behind this node's work: node i + 1's window, its mask words, node i + 2's triples
+    stage_dma(a, sh.win[b ^ 1], sh.meta[msn], pp.kwn, ro.wave, 8, lane);
+    pp.mwn = 0;
+    if (tid < 8 * kWin) pp.mwn = load_mask_word(a, sh.meta[msn], pp.kwn, tid);
     int32_t p0nn, p1nn;
     y_range(a, cnt, i + 2, p0nn, p1nn);
     const int kwnn = min(kWin, p1nn - p0nn);
@@ -642,15 +642,8 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
     if (tid < kwnn) { pp.trm = a.pm[p0nn + tid]; pp.trv = a.pv[p0nn + tid]; pp.trw = a.pw[p0nn + tid]; }
     // ---- (1) + (2): the path products of node i, Y[n] into the LDS tile
     y_node_products<RT1>(a, sh.win, sh.meta, sh.y, ro, path_wave, g, b, ms, pp.kwc, pp.p0c, pp.p1c);
-    lds_barrier();  // raw: a __syncthreads() would drain vector-memory operations in flight
-    // ---- node i + 1's window and mask words into the other buffer (its last readers: node i - 1's products)
-    if constexpr (RT1) {
-      const int t4 = tid - 256;
-      uint32_t mw = 0;
-      if (t4 < 8 * kWin) mw = load_mask_word(a, sh.meta[msn], pp.kwn, t4);  // (issued ahead of the copies: its wait is not theirs)
-      stage_dma(a, sh.win[b ^ 1], sh.meta[msn], pp.kwn, ro.wave - 4, 4, lane);
-      if (t4 < 8 * kWin) sh.win[b ^ 1].mask[t4 >> 3][t4 & 7] = mw;
-    }
+    if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = pp.mwn;  // (readers of that buffer passed this node's barrier)
+    lds_barrier();  // raw: a __syncthreads() here would drain the copies in flight for node i + 1
     // ---- (3) S += Y[n]^T Y[n], rows two at a time (operands of step k + 1 read before the MFMAs of step k)
     {
       const float* __restrict__ base = &sh.y[0][0] + (lane >> 5) * 256 + (lane & 31);
