@@ -696,294 +696,6 @@ __global__ __launch_bounds__(512, 2) void paths_fused_kernel(YArgs a, float* __r
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Producer / consumer form of the same route -- the default.  The waves of a SIMD pair split the work by KIND instead of both
-// alternating between the two phases of a node: hardware waves 0 .. 3 only contract (all 9 sub-tiles of their group, 144
-// accumulator registers), waves 4 .. 7 only build Y (wave 4 + cg: columns [64 cg, 64 cg + 64) of BOTH class tiles).  The tile
-// is double buffered, so the products of node i + 1 and the Gram of node i share one barrier interval and the matrix pipe of
-// every SIMD always has a second, independent instruction stream to draw from (paths_fused_kernel: 57 % MFMA busy, two
-// barriers per node, both waves of a SIMD in the same phase).  What a path wave reads is private to it -- its 64-column
-// slices of the rows b_m / g_m (LDS-DMA, two paths per 1 KiB piece, per-lane source rows), its mask words, the coefficient
-// values of its classes (registers, loaded a whole interval before use) -- so it restages for the next node, and for the
-// further windows of a hub, on its own vmcnt / lgkmcnt with no workgroup barrier.
-struct PcShared {
-  float y[2][kYRows][256];   // 96 KiB: Y[node i] is written while Y[node i - 1] is contracted
-  float bg[4][kWin][2][64];  // 32 KiB: per path wave, (b_m | g_m) slices of the window's paths
-  uint32_t mask[4][kWin][2];
-};
-
-template <int W>
-__device__ __forceinline__ void pc_gram_wave(const YArgs& a, PcShared& sh, float* __restrict__ scratch, int64_t cnt) {
-  const int lane = threadIdx.x & 63;
-  const int r2 = (a.R + 1) & ~1;
-  f32x16 acc[9];
-#pragma unroll
-  for (int s = 0; s < 9; ++s)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-  for (int64_t i = 0; i <= cnt; ++i) {
-    if (i > 0) {
-      const float* __restrict__ base = &sh.y[(i - 1) & 1][0][0] + (lane >> 5) * 256 + (lane & 31);
-      const int nk = r2 >> 1;
-      float xa[8], xb[8];
-      part_load<W, 0, 9>(base, xa);
-      for (int kk = 0; kk < nk; kk += 2) {
-        if (kk + 1 < nk) part_load<W, 0, 9>(base + (kk + 1) * 512, xb);
-        __builtin_amdgcn_sched_barrier(0);
-        part_mfma<W, 0, 9>(xa, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kk + 1 < nk) {
-          if (kk + 2 < nk) part_load<W, 0, 9>(base + (kk + 2) * 512, xa);
-          __builtin_amdgcn_sched_barrier(0);
-          part_mfma<W, 0, 9>(xb, acc);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    lds_barrier();
-  }
-  const int l31 = lane & 31, lhi = lane >> 5;
-  const int64_t D = a.H;
-#pragma unroll
-  for (int s = 0; s < 9; ++s) {
-    const int64_t j = Tiles256<W>::sj[s] * 32 + l31;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t ii = Tiles256<W>::si[s] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      if (ii < D && j < D) atomicAdd(&scratch[ii * D + j], acc[s][r]);
-    }
-  }
-}
-
-// Coefficient values of a window for this lane's classes: raw table values and the path weight, loaded when the window is
-// staged, multiplied when used (rt0: paths 2 ks + half, class c0 + li; rt1: paths 4 ks + (lane >> 4), class c0 + 32 + (lane & 15)).
-struct PcCoef {
-  float c0[8][3], w0[8];
-  float c1[4][3], w1[4];
-};
-
-struct PcTriple { int32_t m, v; float w; };  // lanes 0 .. kw-1 hold the window's triples
-
-__device__ __forceinline__ PcTriple pc_load_triples(const YArgs& a, int32_t p, int kw, int lane) {
-  PcTriple t{0, 0, 0.f};
-  if (lane < kw) { t.m = a.pm[p + lane]; t.v = a.pv[p + lane]; t.w = a.pw[p + lane]; }
-  return t;
-}
-
-// Stage a window (kw <= kWin paths, triples in lanes 0 .. kw-1 of `t`) for path wave cg: LDS-DMA of the (b | g) slices -- two
-// paths per 1 KiB piece, lane l: path 2 q + (l >> 5), row b or g by (l >> 4) & 1, 16 bytes at column 64 cg + 4 (l & 15) --
-// the two mask words per path, and the coefficient loads into registers.  Everything asynchronous.
-__device__ __forceinline__ void pc_stage(const YArgs& a, float* bgw, uint32_t* mkw, const PcTriple& t, int kw, int cg, int lane,
-                                         bool has_rt1, PcCoef& cf) {
-  const int H = a.H, li = lane & 31, half = lane >> 5;
-  const int kw4 = (kw + 3) & ~3;  // the 16 x 16 x 4 tile reads four paths per step: stage zeros up to there
-  // mask words first (their wait is then not the copies')
-  uint32_t word = 0;
-  if (lane < 2 * kWin) {
-    const int j = lane >> 1, wd = 2 * cg + (lane & 1);
-    const int32_t vj = __shfl(t.v, j);
-    if (j < kw && wd < a.mask_words) word = a.mask[int64_t(vj) * a.mask_words + wd];
-  }
-  const int col = 64 * cg + 4 * (lane & 15);
-  for (int q = 0; 2 * q < kw4; ++q) {
-    const int jj = 2 * q + half, part = (lane >> 4) & 1;
-    const int32_t mj = __shfl(t.m, jj);
-    const float* src = a.zeros;
-    if (jj < kw && col < H && !a.no_bg) src = a.bg + ((part ? a.M : 0) + int64_t(mj)) * H + col;
-    lds_dma16(src, bgw + q * 256);
-  }
-  const int cls0 = min(a.c0 + li, kCoefStride - 1), cls1 = min(a.c0 + 32 + (lane & 15), kCoefStride - 1);
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    const int j = 2 * ks + half;
-    const int32_t mj = __shfl(t.m, j);
-    const float wj = __shfl(t.w, j);
-    const bool ok = j < kw;
-    cf.w0[ks] = ok ? wj : 0.f;
-    const float* __restrict__ cm = a.coef + int64_t(ok ? mj : 0) * kCoefRow + cls0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) cf.c0[ks][k] = cm[k * kCoefStride];
-  }
-  if (has_rt1) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int j = 4 * ks + (lane >> 4);
-      const int32_t mj = __shfl(t.m, j);
-      const float wj = __shfl(t.w, j);
-      const bool ok = j < kw;
-      cf.w1[ks] = ok ? wj : 0.f;
-      const float* __restrict__ cm = a.coef + int64_t(ok ? mj : 0) * kCoefRow + cls1;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) cf.c1[ks][k] = cm[k * kCoefStride];
-    }
-  }
-  if (lane < 2 * kWin) mkw[lane] = word;
-}
-
-// The products of one staged window for path wave cg (operands: its LDS slices and `cf`).
-__device__ __forceinline__ void pc_window(const float* __restrict__ bgw, const uint32_t* __restrict__ mkw, const PcCoef& cf,
-                                          int kw, int cg, int H, int lane, bool no_bg, bool has_rt1, f32x16 (&t1)[2],
-                                          f32x16 (&y2)[2], f32x4v (&u1)[4], f32x4v (&u2)[4]) {
-  const int li = lane & 31, half = lane >> 5;
-  const int nks = (kw + 1) >> 1;
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    if (ks < nks) {  // (wave uniform)
-      const int j = 2 * ks + half;
-      const float wj = cf.w0[ks];
-      const float aa = wj * cf.c0[ks][0], ab = wj * cf.c0[ks][1], ag = wj * cf.c0[ks][2];
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const uint32_t wd = mkw[2 * j + ct];
-        const float mf = (64 * cg + 32 * ct + li < H && wj != 0.f && ((wd >> li) & 1u)) ? 1.f : 0.f;
-        t1[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa, mf, t1[ct], 0, 0, 0);
-        if (!no_bg) {
-          const float bb = mf * bgw[j * 128 + 32 * ct + li], gg = mf * bgw[j * 128 + 64 + 32 * ct + li];
-          y2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab, bb, y2[ct], 0, 0, 0);
-          y2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag, gg, y2[ct], 0, 0, 0);
-        }
-      }
-    }
-  }
-  if (has_rt1) {
-    const int nk4 = (kw + 3) >> 2, l15 = lane & 15;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < nk4) {
-        const int j = 4 * ks + (lane >> 4);
-        const float wj = cf.w1[ks];
-        const float aa = wj * cf.c1[ks][0], ab = wj * cf.c1[ks][1], ag = wj * cf.c1[ks][2];
-        float mf[4], bb[4], gg[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          const int c16 = 16 * ct + l15;
-          const uint32_t wd = mkw[2 * j + (c16 >> 5)];
-          mf[ct] = (64 * cg + c16 < H && wj != 0.f && ((wd >> (c16 & 31)) & 1u)) ? 1.f : 0.f;
-          bb[ct] = mf[ct] * bgw[j * 128 + c16];
-          gg[ct] = mf[ct] * bgw[j * 128 + 64 + c16];
-        }
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) u1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, mf[ct], u1[ct], 0, 0, 0);
-        if (!no_bg) {
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct) u2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab, bb[ct], u2[ct], 0, 0, 0);
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct) u2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, gg[ct], u2[ct], 0, 0, 0);
-        }
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ void pc_path_wave(const YArgs& a, PcShared& sh, int cg, int64_t cnt) {
-  const int lane = threadIdx.x & 63, li = lane & 31, half = lane >> 5, H = a.H;
-  const bool no_bg = a.no_bg != 0, has_rt1 = a.R > 32;
-  const bool active = 64 * cg < H;
-  float* bgw = &sh.bg[cg][0][0][0];
-  uint32_t* mkw = &sh.mask[cg][0][0];
-  // W_1 slices of the wave's two class tiles, in registers for the whole launch
-  float w1a[2][16], w1b[4][4];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int colc = 64 * cg + 32 * ct + li;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 4 * half + (r & 3) + 8 * (r >> 2);
-      w1a[ct][r] = (active && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * H + colc] : 0.f;
-    }
-  }
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct) {
-    const int colc = 64 * cg + 16 * ct + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 32 + 4 * (lane >> 4) + r;
-      w1b[ct][r] = (active && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * H + colc] : 0.f;
-    }
-  }
-  int32_t p0c, p1c, p0n, p1n;
-  y_range(a, cnt, 0, p0c, p1c);
-  y_range(a, cnt, 1, p0n, p1n);
-  PcCoef cf;
-  PcTriple tn = pc_load_triples(a, p0n, min(kWin, p1n - p0n), lane);
-  if (active) {
-    const PcTriple t0 = pc_load_triples(a, p0c, min(kWin, p1c - p0c), lane);
-    pc_stage(a, bgw, mkw, t0, min(kWin, p1c - p0c), cg, lane, has_rt1, cf);
-  }
-  for (int64_t i = 0; i <= cnt; ++i) {
-    if (i < cnt && active) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this node's window (staged one interval ago) is in place
-      int32_t p0nn, p1nn;
-      y_range(a, cnt, i + 2, p0nn, p1nn);
-      const PcTriple tnn = pc_load_triples(a, p0nn, min(kWin, p1nn - p0nn), lane);  // two nodes ahead
-      f32x16 t1[2], y2[2];
-      f32x4v u1[4], u2[4];
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) { u1[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; u2[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
-      pc_window(bgw, mkw, cf, min(kWin, p1c - p0c), cg, H, lane, no_bg, has_rt1, t1, y2, u1, u2);
-      for (int32_t wb = p0c + kWin; wb < p1c; wb += kWin) {  // hubs: further windows, restaged in place by this wave alone
-        const int kw = min(kWin, p1c - wb);
-        const PcTriple tw = pc_load_triples(a, wb, kw, lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous window's LDS reads are done
-        pc_stage(a, bgw, mkw, tw, kw, cg, lane, has_rt1, cf);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        pc_window(bgw, mkw, cf, kw, cg, H, lane, no_bg, has_rt1, t1, y2, u1, u2);
-      }
-      // Y[n] into this interval's tile (its last readers: the Gram of two intervals ago)
-      float (*yt)[256] = sh.y[i & 1];
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const int colc = 64 * cg + 32 * ct + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 4 * half + (r & 3) + 8 * (r >> 2);
-          if (colc < H && row < a.R) yt[row][colc] = w1a[ct][r] * t1[ct][r] + y2[ct][r];
-        }
-      }
-      if (has_rt1) {
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          const int colc = 64 * cg + 16 * ct + (lane & 15);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 32 + 4 * (lane >> 4) + r;
-            if (colc < H && row < a.R) yt[row][colc] = w1b[ct][r] * u1[ct][r] + u2[ct][r];
-          }
-        }
-      }
-      // stage node i + 1 (the slices are this wave's own: its reads of them are done)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (i + 1 < cnt) pc_stage(a, bgw, mkw, tn, min(kWin, p1n - p0n), cg, lane, has_rt1, cf);
-      p0c = p0n; p1c = p1n; p0n = p0nn; p1n = p1nn;
-      tn = tnn;
-    }
-    lds_barrier();
-  }
-}
-
-__global__ __launch_bounds__(512, 2) void paths_pc_kernel(YArgs a, float* __restrict__ scratch) {
-  __shared__ PcShared sh;  // ~129 KiB: one workgroup per CU
-  if (int64_t(a.pptr[a.N]) > a.cap) return;  // the path list overflowed its buffer: the enumerating route takes over
-  const int tid = threadIdx.x;
-  // the tiles are zero where nobody writes: columns >= H, the odd row out
-  for (int q = tid; q < 2 * kYRows * 256; q += 512) (&sh.y[0][0][0])[q] = 0.f;
-  __syncthreads();
-  const int64_t stride = gridDim.x;
-  const int64_t cnt = a.N > int64_t(blockIdx.x) ? (a.N - blockIdx.x + stride - 1) / stride : 0;
-  const int hw = __builtin_amdgcn_readfirstlane(int(tid >> 6));
-  switch (hw) {  // hardware waves g and g + 4 share a SIMD: one contracts, one builds
-    case 0: pc_gram_wave<0>(a, sh, scratch, cnt); break;
-    case 1: pc_gram_wave<1>(a, sh, scratch, cnt); break;
-    case 2: pc_gram_wave<2>(a, sh, scratch, cnt); break;
-    case 3: pc_gram_wave<3>(a, sh, scratch, cnt); break;
-    default: pc_path_wave(a, sh, hw - 4, cnt); break;
-  }
-}
-
 constexpr int kSlots = 3;
 constexpr int kBlockRows = 32;
 
@@ -1174,10 +886,7 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.W1 = h->W[1]; y.Y = nullptr; y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel(s) of the KFAC path (bench.py roofline)
-    if (getenv("LGNN_PATHS_PHASED") != nullptr)  // dev A/B: all eight waves alternate between the two phases of a node
-      hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y, scratch);
-    else
-      hipLaunchKernelGGL(paths_pc_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y, scratch);
+    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y, scratch);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }
