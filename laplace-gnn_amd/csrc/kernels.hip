@@ -697,6 +697,11 @@ int launch_gram_batched(const float* X, int64_t ld, int64_t R, int64_t D, float*
   if (R <= 0 || D <= 0 || nz <= 0) return 0;
   LGNN_REQUIRE(nz < 65536, "too many Grams in one batched launch");
   const bool vec = (ld % 4 == 0) && aligned16(X);
+  // one plain Gram of many 129 .. 256 wide rows: the streaming kernel (eight MFMA waves per CU, LDS-DMA row blocks) runs at
+  // 0.78 of the fp32 MFMA peak by the nominal count where the register-staged kernel below reaches 0.33
+  if (nz == 1 && row_scale == nullptr && zscale == nullptr && scale == 1.0f && D > 128 && D <= 256 && D % 4 == 0 && vec &&
+      R >= 8192)
+    return launch_gram256_stream(X, ld, R, D, out, s);
   int dt = D <= 64 ? 64 : (D <= 128 ? 128 : (D <= 256 ? 256 : 128));
   const int ntile = int(cdiv(D, dt));
   const int npairs = ntile * (ntile + 1) / 2;

@@ -358,8 +358,9 @@ bool paths_supported(int kind, int L, const int64_t* dims, int act, int64_t nnz)
 // scratch [H, H] += B_0 of this batch's class columns [cb, ce) (seed_mode: 0 upstream, 1 fork exact, 2 regression)
 int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce, float* scratch,
                            hipStream_t s);
-// scratch [width, width] (upper 32 x 32 sub-tiles) += Y^T Y for contiguous rows of `width` floats, 128 < width <= 256
-int launch_gram256_stream(const float* Y, int64_t rows, int64_t width, float* scratch, const float* zeros, hipStream_t s,
+// scratch [width, width] (upper 32 x 32 sub-tiles) += Y^T Y for rows of `width` floats (row stride ld), 128 < width <= 256:
+// all eight waves of a persistent workgroup per CU on the matrix pipes, row blocks by LDS-DMA (paths.hip)
+int launch_gram256_stream(const float* Y, int64_t ld, int64_t rows, int64_t width, float* scratch, hipStream_t s,
                           const int32_t* gate = nullptr, int64_t gate_cap = 0);
 // ---- forward.hip ------------------------------------------------------------------------
 int forward_ensure(lgnn_ctx* h, hipStream_t s);

@@ -699,9 +699,12 @@ __global__ __launch_bounds__(512, 2) void paths_fused_kernel(YArgs a, float* __r
 constexpr int kSlots = 3;
 constexpr int kBlockRows = 32;
 
+__device__ float g_stream_zeros[256];  // (zero initialised) the source of copies past a row's end / past the last row
+
 struct GramStreamArgs {
-  const float* Y;       // [rows][width]
+  const float* Y;       // [rows][ld], `width` floats used per row
   int64_t rows;
+  int64_t ld;
   int width;
   const float* zeros;   // >= 16 bytes of zeros: the source of lanes past the row's end and of rows past the last
   float* scratch;       // [width][width], upper sub-tiles, float atomics
@@ -716,7 +719,7 @@ __device__ __forceinline__ void issue_block(const GramStreamArgs& a, float* tile
   for (int q = 0; q < 4; ++q) {
     const int r = 4 * hw + q;
     const int64_t row = blk * kBlockRows + r;
-    const float* src = (lane_ok && row < a.rows) ? a.Y + row * a.width + 4 * lane : a.zeros;
+    const float* src = (lane_ok && row < a.rows) ? a.Y + row * a.ld + 4 * lane : a.zeros;
     float* dst = tiles + (slot * kBlockRows + r) * 256;  // wave-uniform LDS base; lane l lands at + 4 l floats
     __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
                                               reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
@@ -799,11 +802,17 @@ bool paths_supported(int kind, int L, const int64_t* dims, int act, int64_t nnz)
          H % 4 == 0;
 }
 
-int launch_gram256_stream(const float* Y, int64_t rows, int64_t width, float* scratch, const float* zeros, hipStream_t s,
+int launch_gram256_stream(const float* Y, int64_t ld, int64_t rows, int64_t width, float* scratch, hipStream_t s,
                           const int32_t* gate, int64_t gate_cap) {
-  LGNN_REQUIRE(width > 128 && width <= 256 && width % 4 == 0, "internal: streaming Gram width");
+  LGNN_REQUIRE(width > 128 && width <= 256 && width % 4 == 0 && ld % 4 == 0 && ld >= width, "internal: streaming Gram width");
   if (rows <= 0) return 0;
-  GramStreamArgs g{Y, rows, int(width), zeros, scratch, gate, gate_cap};
+  static const float* zeros = nullptr;  // address of the device-side zero block (per process; one device per process)
+  if (zeros == nullptr) {
+    void* p = nullptr;
+    LGNN_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_stream_zeros)));
+    zeros = static_cast<const float*>(p);
+  }
+  GramStreamArgs g{Y, rows, ld, int(width), zeros, scratch, gate, gate_cap};
   const int64_t nblocks = cdiv(rows, kBlockRows);
   hipLaunchKernelGGL(gram256_stream_kernel, dim3(unsigned(std::min<int64_t>(nblocks, 256))), dim3(512), 0, s, g);
   LGNN_HIP_CHECK(hipGetLastError());
@@ -910,7 +919,7 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     const unsigned threads = unsigned(64 * cdiv(H, 64) * cdiv(R, 32));  // (column groups) x (32-class row tiles) waves
     hipLaunchKernelGGL(ybuild_kernel, dim3(unsigned(std::min<int64_t>(N, 1024))), dim3(threads), 0, s, y);
     LGNN_HIP_CHECK(hipGetLastError());
-    LGNN_CALL(launch_gram256_stream(y.Y, N * R, H, scratch, ws.path_zeros.as<float>(), s, ws.path_pptr.as<int32_t>() + N, cap));
+    LGNN_CALL(launch_gram256_stream(y.Y, H, N * R, H, scratch, s, ws.path_pptr.as<int32_t>() + N, cap));
   }
   return 0;
 }
