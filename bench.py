@@ -218,8 +218,8 @@ def _median(xs):
 def _pmc_traffic(workload, structure, units_per_launch):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass of this same command
     (counters cannot be collected inside the timed run); null when no summary for this workload is committed."""
-    names = ["r02_arxiv_pmc_fused.json", "r01_h_pmc_fused.json"] if (workload, structure) == ("arxiv", "kron") \
-        else [f"r02_{workload}_pmc_dominant.json"]
+    names = ["r03_arxiv_pmc_fused.json"] if (workload, structure) == ("arxiv", "kron") \
+        else [f"r03_{workload}_pmc_dominant.json", f"r02_{workload}_pmc_dominant.json"]
     if structure != DEFAULT_STRUCTURE[workload]:
         names = []
     for name in names:
@@ -228,8 +228,11 @@ def _pmc_traffic(workload, structure, units_per_launch):
             with open(path) as fh:
                 pj = json.load(fh)
             per = pj.get("planes_per_launch") or pj.get("units_per_launch") or units_per_launch
-            return pj["traffic_bytes_per_launch"] * units_per_launch / per, f"profiles/{name} ((2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction)"
-    return None, None
+            if os.environ.get("LGNN_NO_PATHS", "") not in ("", "0") and "paths" in pj.get("kernel", ""):
+                continue  # the committed counters are the path route's
+            return (pj["traffic_bytes_per_launch"] * units_per_launch / per,
+                    f"profiles/{name} ((2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction)", pj)
+    return None, None, None
 
 
 def main():
@@ -343,7 +346,7 @@ def main():
         if launches > 0 and kern_ms > 0:
             avg_ms = kern_ms / launches
             upl = units / launches
-            traffic, traffic_src = _pmc_traffic(args.workload, structure, upl)
+            traffic, traffic_src, pmc = _pmc_traffic(args.workload, structure, upl)
             common = {"traffic": traffic, "traffic_source": traffic_src, "launches": launches, "avg_launch_ms": avg_ms,
                       "kernel_share_of_wall": kern_ms * 1e-3 / elapsed}
             if structure == "kron":
@@ -353,17 +356,33 @@ def main():
                 flops = (2.0 * nnz * H + 2.0 * N * H * H) * units
                 bytes_ = (nnz * 8.0 + (N + 1) * 4.0 + N * H * 4.0) * units
                 ach = flops / (kern_ms * 1e-3) / 1e12
+                paths = eng.kfac_plan()["paths"]  # 2-layer GCN: B_0 from the batch's two-hop paths, no class planes
                 roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_MFMA_F32_TFLOPS, **common,
-                            "kernel": "spmm_gram256_kernel" if H > 128 else "spmm_gram_kernel",
+                            "kernel": "paths_fused_kernel" if paths else ("spmm_gram256_kernel" if H > 128 else "spmm_gram_kernel"),
                             "planes_per_launch": upl, "algorithmic_bytes_per_launch": bytes_ / launches,
-                            "algorithmic_GBps": bytes_ / (kern_ms * 1e-3) / 1e9,
-                            "executed_frac_of_peak": ach / PEAK_MFMA_F32_TFLOPS * 36.0 / 64.0 if H > 128 else None,
-                            "note": "the kernel executes the 36 of 64 symmetric 32x32 sub-tiles of the Gram; 'achieved' "
-                                    "credits the full 2*N*H^2 as SURVEY.md 8(d) prescribes"
-                                    + ("; GraphSAGE: it also visits only the rows that can be non-zero (batch nodes and "
-                                       "their neighbours), so frac can exceed 1 and executed_frac_of_peak overstates by the "
-                                       "share of skipped rows" if w.get("kind") == "sage" else "")}
+                            "algorithmic_GBps": bytes_ / (kern_ms * 1e-3) / 1e9}
+                if paths:
+                    # executed work: the 36 of 64 symmetric sub-tiles of every node's Gram plus the three path products
+                    # (incl. their tile padding); measured, not modelled: SQ_VALU_MFMA_BUSY_CYCLES of the committed counter
+                    # pass x 64 flop per busy cycle and SIMD, over this run's launch time
+                    busy = (pmc or {}).get("SQ_VALU_MFMA_BUSY_CYCLES_avg")
+                    per = (pmc or {}).get("planes_per_launch", upl)
+                    exe = busy * 64.0 * (upl / per) / (avg_ms * 1e-3) / 1e12 if busy else None
+                    roofline.update({
+                        "executed_TFLOPs": exe, "executed_frac_of_peak": exe / PEAK_MFMA_F32_TFLOPS if exe else None,
+                        "note": "'achieved' credits the SURVEY.md 8(d) count of what the kernel replaces (C planes x (2 nnz H + 2 N "
+                                "H^2), no credit for symmetry); executed_* = matrix-pipe busy cycles (rocprofv3 counter pass of "
+                                "this command, profiles/) x 64 flop: the kernel runs 36/64 of the Gram's sub-tiles plus the path "
+                                "products; its HBM traffic is below the algorithmic bytes because no class plane exists"})
+                else:
+                    roofline.update({
+                        "executed_frac_of_peak": ach / PEAK_MFMA_F32_TFLOPS * 36.0 / 64.0 if H > 128 else None,
+                        "note": "the kernel executes the 36 of 64 symmetric 32x32 sub-tiles of the Gram; 'achieved' "
+                                "credits the full 2*N*H^2 as SURVEY.md 8(d) prescribes"
+                                + ("; GraphSAGE: it also visits only the rows that can be non-zero (batch nodes and "
+                                   "their neighbours), so frac can exceed 1 and executed_frac_of_peak overstates by the "
+                                   "share of skipped rows" if w.get("kind") == "sage" else "")})
             elif structure == "diag":
                 # dominant kernel: diag_first_layer_kernel, one launch per batch.  ALGORITHMIC bytes per launch
                 # (SURVEY.md 8(d) "Diag (C2)"): N*F*4 + nnz*8 + 2*P*4; flops 2*M*dbar*H*(F+1).  HBM bound by that count
