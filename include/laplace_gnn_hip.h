@@ -62,6 +62,10 @@ extern "C" {
 #define LGNN_FLAG_NO_FUSE 2u         /* debugging: run SpMM^T and the Gram contraction as separate kernels    */
 #define LGNN_FLAG_NO_PATHS 4u        /* 2-layer GCN: keep the class-plane route (backward GEMM + fused SpMM^T -> Gram) instead
                                         of the two-hop path route (csrc/paths.hip); same results up to fp32 reassociation */
+#define LGNN_FLAG_FORCE_PATHS 8u     /* take the path route wherever the model's shape allows it, also on hub-heavy graphs where
+                                        the library would choose the planes (its default weighs the batch's expected number of
+                                        2-hop paths per node); the first eligible call counts the graph's 2-hop paths once and
+                                        synchronises the stream that one time                                            */
 
 typedef struct lgnn_ctx lgnn_ctx; /* opaque: graph + bound model + forward cache + workspace */
 

@@ -15,7 +15,7 @@ KIND_GCN, KIND_SAGE = 0, 1
 ACT_RELU, ACT_TANH = 0, 1
 LIK_CLASSIFICATION, LIK_REGRESSION = 0, 1
 NORM_NONE, NORM_LAYER, NORM_BATCH = 0, 1, 2
-FLAG_FORK_EXACT_SEED, FLAG_NO_FUSE, FLAG_NO_PATHS = 1, 2, 4
+FLAG_FORK_EXACT_SEED, FLAG_NO_FUSE, FLAG_NO_PATHS, FLAG_FORCE_PATHS = 1, 2, 4, 8
 
 # name -> (restype, argtypes); mirrors include/laplace_gnn_hip.h one to one
 _vp, _i64, _i32, _u32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint32

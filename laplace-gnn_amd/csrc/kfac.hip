@@ -793,8 +793,14 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   LGNN_REQUIRE(M < INT32_MAX, "batch too large");
 
   const bool fork_exact = (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0;
-  const KfacPlan plan = plan_kfac(h->kind, L, N, h->nnz, h->dims, h->act, no_fuse, h->ws_limit,
-                                  (flags & LGNN_FLAG_NO_PATHS) != 0 || fisher != nullptr);
+  // the two-hop path route (paths.hip) where the shape allows it and the batch's expected number of paths makes it pay
+  bool no_paths = (flags & LGNN_FLAG_NO_PATHS) != 0 || fisher != nullptr || no_fuse ||
+                  !paths_supported(h->kind, L, h->dims, h->act, h->nnz);
+  if (!no_paths) {
+    LGNN_CALL(two_hop_ensure(h, s));
+    no_paths = !paths_pay(h, M) && (flags & LGNN_FLAG_FORCE_PATHS) == 0;
+  }
+  const KfacPlan plan = plan_kfac(h->kind, L, N, h->nnz, h->dims, h->act, no_fuse, h->ws_limit, no_paths);
   // GCN, fused path: the top-layer kernel rebuilds each sample's C x C seed block from its probabilities and logits,
   // so the blocks are never written (64 MB per arxiv-shaped batch); every other path reads them from ws.seeds
   const bool seeds_on_the_fly = plan.seeds_on_the_fly && !fisher;  // the on-the-fly rebuild knows the GGN blocks only

@@ -165,6 +165,7 @@ struct lgnn_ctx {
   lgnn::Workspace ws;
   int64_t ws_limit = int64_t(32) << 30;  // backward planes (ping + pong) per class chunk: 288 GB of HBM, keep chunks large
   // rows of P^T with more than kLongRow stored entries (hubs), built once on first use (longrows.hip)
+  double two_hop = -1.0;           // number of 2-hop paths n <- v <- m of the graph (-1: not counted yet; paths.hip)
   int64_t n_long = -1;             // -1: not looked at yet
   int64_t n_long_tasks = 0;
   lgnn::DevBuf long_rows, long_slot, long_tasks, hub;
@@ -355,6 +356,8 @@ int batch_epilogue(lgnn_ctx* h, const int64_t* idx, int64_t M, hipStream_t s);
 int record_event(lgnn_ctx* h, hipStream_t s);
 // ---- paths.hip ----------------------------------------------------------------------------
 bool paths_supported(int kind, int L, const int64_t* dims, int act, int64_t nnz);
+int two_hop_ensure(lgnn_ctx* h, hipStream_t s);   // h->two_hop = 2-hop paths of the graph, counted once (one synchronisation)
+bool paths_pay(const lgnn_ctx* h, int64_t M);     // expected paths per destination node of a batch of M small enough
 // scratch [H, H] += B_0 of this batch's class columns [cb, ce) (seed_mode: 0 upstream, 1 fork exact, 2 regression)
 int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce, float* scratch,
                            hipStream_t s);

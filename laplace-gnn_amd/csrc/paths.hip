@@ -796,6 +796,49 @@ __global__ __launch_bounds__(512, 2) void gram256_stream_kernel(GramStreamArgs a
 
 }  // namespace
 
+namespace {
+// S2 = sum_v (entries of row v of P) * (entries of row v of P^T): the number of 2-hop paths n <- v <- m of the whole graph
+__global__ void two_hop_count_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ rpt, int64_t N,
+                                     unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0;
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; v < N; v += stride)
+    acc += (unsigned long long)(rp[v + 1] - rp[v]) * (unsigned long long)(rpt[v + 1] - rpt[v]);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+}  // namespace
+
+// The path route's cost grows with the batch's number of 2-hop paths (about 1 ns each at C = 40 on top of the per-node Gram),
+// the plane route's with the graph's entries: on hub-heavy graphs (sum of squared degrees) the planes win -- arxiv sizes with
+// power-law degrees: 183.7 ms per fit on paths against 107.2 ms on planes; uniform degrees: 84 against 95.  The expected
+// paths per destination node, S2 / N * M / N, decides; S2 is counted once per graph (one stream synchronisation, like the long-row
+// list).
+int two_hop_ensure(lgnn_ctx* h, hipStream_t s) {
+  if (h->two_hop >= 0) return 0;
+  h->two_hop = 0;
+  if (h->nnz <= 0) return 0;
+  DevBuf acc;
+  LGNN_CALL(acc.reserve(64));
+  unsigned long long host = 0;
+  int rc = 0;
+  if (hipMemsetAsync(acc.p, 0, 8, s) != hipSuccess) rc = 1;
+  if (!rc) {
+    hipLaunchKernelGGL(two_hop_count_kernel, dim3(unsigned(std::min<int64_t>(cdiv(h->N, 256), 1024))), dim3(256), 0, s,
+                       h->P.rowptr, h->PT.rowptr, h->N, acc.as<unsigned long long>());
+    if (hipMemcpyAsync(&host, acc.p, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = 1;
+  }
+  acc.release();
+  if (rc) { set_error("two-hop path count failed"); return 1; }
+  h->two_hop = double(host);
+  return 0;
+}
+bool paths_pay(const lgnn_ctx* h, int64_t M) {
+  static const double limit = getenv("LGNN_PATHS_PER_NODE") ? atof(getenv("LGNN_PATHS_PER_NODE")) : 24.0;  // dev: move the switch
+  const double N = double(h->N);
+  return h->two_hop >= 0 && h->two_hop / N * double(M) / N <= limit;
+}
+
 bool paths_supported(int kind, int L, const int64_t* dims, int act, int64_t nnz) {
   const int64_t C = dims[L], H = L >= 2 ? dims[L - 1] : 0;
   return kind == LGNN_KIND_GCN && L == 2 && act == LGNN_ACT_RELU && nnz > 0 && C <= kCoefStride && H > 128 && H <= 256 &&

@@ -333,9 +333,11 @@ class GraphEngine:
         self._sync_versions()
         idx = idx.contiguous()
         yp = self._labels(y, idx.shape[0])
-        no_paths = _no_paths_default() if paths is None else not paths  # (2-layer GCN: two-hop path route, csrc/paths.hip)
+        # 2-layer GCN: two-hop path route (csrc/paths.hip).  paths=None: the library decides (shape and the batch's expected
+        # paths per node; LGNN_NO_PATHS=1 keeps the planes); True / False force one route where the shape allows
+        no_paths = _no_paths_default() if paths is None else not paths
         flags = (_lib.FLAG_FORK_EXACT_SEED if fork_exact else 0) | (0 if fuse else _lib.FLAG_NO_FUSE) | \
-            (_lib.FLAG_NO_PATHS if no_paths else 0)
+            (_lib.FLAG_NO_PATHS if no_paths else 0) | (_lib.FLAG_FORCE_PATHS if paths else 0)
         A = _lib.ptr_array([a.data_ptr() for a, _ in views])
         B = _lib.ptr_array([b.data_ptr() for _, b in views])
         cb, ce = (0, self.dims[-1]) if classes is None else (int(classes[0]), int(classes[1]))
