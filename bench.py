@@ -356,7 +356,7 @@ def main():
                 flops = (2.0 * nnz * H + 2.0 * N * H * H) * units
                 bytes_ = (nnz * 8.0 + (N + 1) * 4.0 + N * H * 4.0) * units
                 ach = flops / (kern_ms * 1e-3) / 1e12
-                paths = eng.kfac_plan()["paths"]  # 2-layer GCN: B_0 from the batch's two-hop paths, no class planes
+                paths = eng.last_kfac_used_paths  # 2-layer GCN: B_0 from the batch's two-hop paths, no class planes
                 roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_MFMA_F32_TFLOPS, **common,
                             "kernel": "paths_fused_kernel" if paths else ("spmm_gram256_kernel" if H > 128 else "spmm_gram_kernel"),

@@ -90,6 +90,9 @@ LGNN_API int64_t lgnn_num_nodes(const lgnn_ctx* h);
 /* Rows of the backward propagation matrix with more than 64 stored entries (hubs): the 256-wide fused kernel receives
  * them finished from a side kernel instead of gathering them in one wave.  -1 until the first KFAC call built the list. */
 LGNN_API int64_t lgnn_num_long_rows(const lgnn_ctx* h);
+/* 1 if the last lgnn_kfac_accumulate* call on this context took the two-hop path route (csrc/paths.hip), 0 if it built class
+ * planes: which of the two implementations of curvlinops/kfac.py:653-661, 777-817 ran (measurement labels; host value). */
+LGNN_API int lgnn_kfac_last_route(const lgnn_ctx* h);
 /* 1 if the stored adjacency equals its transpose (then forward and backward share one CSR) */
 LGNN_API int lgnn_is_symmetric(const lgnn_ctx* h);
 

@@ -285,6 +285,7 @@ extern "C" int64_t lgnn_nnz(const lgnn_ctx* h) { return h ? h->nnz : -1; }
 extern "C" int64_t lgnn_num_nodes(const lgnn_ctx* h) { return h ? h->N : -1; }
 extern "C" int lgnn_is_symmetric(const lgnn_ctx* h) { return h && h->sym ? 1 : 0; }
 extern "C" int64_t lgnn_num_long_rows(const lgnn_ctx* h) { return h ? h->n_long : -1; }
+extern "C" int lgnn_kfac_last_route(const lgnn_ctx* h) { return h && h->last_route_paths ? 1 : 0; }
 
 extern "C" int lgnn_bind_model(lgnn_ctx* h, int num_layers, const int64_t* dims, const float* const* weights,
                                const float* const* biases, const float* X, int activation, int likelihood) {

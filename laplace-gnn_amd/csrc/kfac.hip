@@ -885,6 +885,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
 
   // ---- 2-layer GCN: B_0 from the batch's 2-hop paths -- no class planes (paths.hip) -------------------------
   const bool paths_route = plan.paths && !fisher && seeds_on_the_fly;
+  h->last_route_paths = paths_route;
   if (paths_route)
     LGNN_CALL(kfac_paths_first_layer(h, idx, M, h->lik == LGNN_LIK_REGRESSION ? 2 : (fork_exact ? 1 : 0), cb, ce,
                                      h->ws.gram_scratch[0].as<float>(), s));

@@ -119,6 +119,11 @@ class GraphEngine:
         """Rows with more than 64 stored entries that the 256-wide fused kernel takes from the side kernel (-1: not built)."""
         return int(self.lib.lgnn_num_long_rows(self._h))
 
+    @property
+    def last_kfac_used_paths(self) -> bool:
+        """Whether the last KFAC accumulate took the two-hop path route (csrc/paths.hip) rather than class planes."""
+        return bool(self.lib.lgnn_kfac_last_route(self._h))
+
     def export_adj(self):
         nnz = self.nnz
         rows = torch.empty(nnz, dtype=torch.int64, device=self.device)
