@@ -356,7 +356,12 @@ def main():
                 flops = (2.0 * nnz * H + 2.0 * N * H * H) * units
                 bytes_ = (nnz * 8.0 + (N + 1) * 4.0 + N * H * 4.0) * units
                 ach = flops / (kern_ms * 1e-3) / 1e12
-                paths = eng.last_kfac_used_paths  # 2-layer GCN: B_0 from the batch's two-hop paths, no class planes
+                # which route a FULL batch takes (2-layer GCN: B_0 from the batch's two-hop paths, no class planes -- unless the
+                # graph's hubs make the planes cheaper; a short last batch may take the other route): one untimed accumulate
+                _, pv, pl = eng.new_kfac_buffers()
+                xb, yb = next(iter(loader))
+                eng.kfac_accumulate(xb, yb, w["n_train"], pv, pl)
+                paths = eng.last_kfac_used_paths
                 roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_MFMA_F32_TFLOPS, **common,
                             "kernel": "paths_fused_kernel" if paths else ("spmm_gram256_kernel" if H > 128 else "spmm_gram_kernel"),
