@@ -12,9 +12,20 @@
  *   - every pointer is a DEVICE pointer (HIP, one GPU per process) unless marked "host";
  *     tensors are row-major, fp32 / int64 exactly as PyTorch hands them over;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
- *     all work is enqueued asynchronously on it, no hidden device synchronisation
- *     (the two graph-ingest calls that must learn `nnz` on the host are the exception
- *     and say so);
+ *     all work is enqueued asynchronously on it.  The calls that DO synchronise `stream` -- a
+ *     count has to reach the host before the next launch or allocation can be sized -- are,
+ *     completely:
+ *       lgnn_create, lgnn_adj_to_edge_index     the deduplicated nnz / the off-diagonal count;
+ *       lgnn_check_async_errors                 by design (reports the sticky error flags);
+ *       the FIRST KFAC / adjacency-gradient call on a graph, once per graph: the list of rows with
+ *         more than 64 stored entries (hubs) and the graph's number of 2-hop paths;
+ *       lgnn_kfac_accumulate* on GraphSAGE models of three or more layers, once per batch: the
+ *         number of rows the second backward level can reach sizes its gather / GEMM / scatter
+ *         (a host-side bound would be N on hub-heavy graphs: 5x the buffers at the products shape);
+ *       lgnn_kfac_adjgrad_batch on GraphSAGE models, once per batch: the active-row count sizes a
+ *         library GEMM;   lgnn_glm_variance, once per call: the size of the rotated-row table.
+ *     The headline paths -- 2-layer GCN / GraphSAGE KFAC, diagonal and last-layer GGN, forward,
+ *     Jacobians -- enqueue only; workspaces grow on first use of a shape and are reused after;
  *   - every function returns 0 on success, non-zero on error; the message is available
  *     from lgnn_last_error() (thread-local).  No C++ exception crosses the boundary;
  *   - borrowed pointers (weights, features, indices, outputs) are owned by the caller
