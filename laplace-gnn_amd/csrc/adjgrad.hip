@@ -903,6 +903,7 @@ int sage_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0
                         float* grad_cand, float* grad_cand_adj, hipStream_t s) {
   const int64_t N = h->N, C = h->dims[2], H = h->dims[1], F = h->dims[0];
   LGNN_CALL(forward_ensure_aux(h, s));
+  LGNN_CALL(ensure_wt(h, s));
   const float* cat0 = h->fc.lin_in_p[0];  // [N, 2F]: X | P X
   const float* cat1 = h->fc.lin_in_p[1];  // [N, 2H]: H1 | P H1
   LGNN_REQUIRE(h->fc.lin_in_ld[0] == 2 * F && h->fc.lin_in_ld[1] == 2 * H, "internal: unexpected cat row stride");
@@ -957,6 +958,7 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   LGNN_CALL(check_model(h));
   LGNN_REQUIRE(M > 0 && idx && y && gamma_B0 && gamma_B1 && grad_P && out_bar, "empty batch or null pointers");
   LGNN_CALL(forward_ensure_aux(h, s));  // act'(h_1) is part of the auxiliary forward products
+  LGNN_CALL(ensure_wt(h, s));
   const int64_t N = h->N, C = h->dims[2], H = h->dims[1], CC = C * C;
   const bool fork_exact = (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0;
   if (h->kind == LGNN_KIND_SAGE)
@@ -1108,6 +1110,7 @@ int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0, con
                                grad_cand_adj, s);
   }
   LGNN_CALL(forward_ensure(h, s));
+  LGNN_CALL(ensure_wt(h, s));
   const int64_t N = h->N, C = h->dims[2], H = h->dims[1], F = h->dims[0];
   // Z1 = H1 W1^T + b1 and Z0 = X W0^T + b0 (the forward keeps neither: one scratch serves both)
   const int64_t zw = std::max(H, C);

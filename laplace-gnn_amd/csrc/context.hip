@@ -31,10 +31,68 @@ int DevBuf::reserve(size_t want) {
   bytes = sz;
   return 0;
 }
+// Pinned, device-visible host memory (the sticky error flags: kernels store to it only when something is wrong, the
+// host reads it after a stream synchronisation -- no device-to-host copy, no clearing launch)
+int DevBuf::reserve_host(size_t want) {
+  if (want <= bytes && p && host) return 0;
+  release();
+  size_t sz = std::max<size_t>(want, 256);
+  hipError_t e = hipHostMalloc(&p, sz, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e != hipSuccess) {
+    p = nullptr;
+    set_error("hipHostMalloc(" + std::to_string(sz) + " B): " + hipGetErrorString(e));
+    return 1;
+  }
+  host = true;
+  bytes = sz;
+  return 0;
+}
 void DevBuf::release() {
-  if (p) (void)hipFree(p);
+  if (p) (void)(host ? hipHostFree(p) : hipFree(p));
   p = nullptr;
   bytes = 0;
+  host = false;
+}
+
+// GCN: what the first Linear reads.  X itself, or -- unaligned feature rows -- a zero padded copy made once per binding
+int forward_input_view(lgnn_ctx* h, hipStream_t s) {
+  ForwardCache& fc = h->fc;
+  const int64_t N = h->N;
+  fc.lin_in_p[0] = h->X;
+  fc.lin_in_ld[0] = h->dims[0];
+  if (h->dims[0] % 4 != 0) {
+    const int64_t ldx = cdiv(h->dims[0], 4) * 4;
+    if (!fc.x_valid) {
+      LGNN_CALL(fc.Xpad.reserve(size_t(N) * ldx * 4));
+      LGNN_HIP_CHECK(hipMemsetAsync(fc.Xpad.p, 0, size_t(N) * ldx * 4, s));
+      LGNN_HIP_CHECK(hipMemcpy2DAsync(fc.Xpad.p, size_t(ldx) * 4, h->X, size_t(h->dims[0]) * 4, size_t(h->dims[0]) * 4,
+                                      size_t(N), hipMemcpyDeviceToDevice, s));
+    }
+    fc.lin_in_p[0] = fc.Xpad.as<float>();
+    fc.lin_in_ld[0] = ldx;
+  }
+  return 0;
+}
+
+// W_l^T [in_l, out_l]: the forward GEMM's operand (and the adjacency gradient's); built once per weight version
+int ensure_wt(lgnn_ctx* h, hipStream_t s) {
+  if (h->fc.wt_valid) return 0;
+  for (int l = 0; l < h->L; ++l) {
+    LGNN_CALL(h->Wt[l].reserve(size_t(h->in_dim[l]) * h->dims[l + 1] * 4));
+    const float* W = h->W[l];
+    if (h->has_res && l < h->L - 1) {
+      if (h->kind == LGNN_KIND_SAGE) {
+        LGNN_CALL(build_sage_res_weights(h, l, s));
+        W = h->Wcomb[l].as<float>();
+      } else {
+        LGNN_CALL(h->Wrt[l].reserve(size_t(h->dims[l]) * h->dims[l + 1] * 4));
+        LGNN_CALL(launch_transpose(h->Wr[l], h->dims[l + 1], h->dims[l], h->Wrt[l].as<float>(), s));
+      }
+    }
+    LGNN_CALL(launch_transpose(W, h->dims[l + 1], h->in_dim[l], h->Wt[l].as<float>(), s));
+  }
+  h->fc.wt_valid = true;
+  return 0;
 }
 
 static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
@@ -52,19 +110,7 @@ static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
 
   if (h->kind == LGNN_KIND_GCN) {
     LGNN_CALL(fc.tmp.reserve(size_t(N) * maxw * 4));
-    fc.lin_in_p[0] = h->X;
-    fc.lin_in_ld[0] = h->dims[0];
-    if (h->dims[0] % 4 != 0) {  // unaligned feature rows: a padded copy, made once per binding
-      const int64_t ldx = cdiv(h->dims[0], 4) * 4;
-      if (!fc.x_valid) {
-        LGNN_CALL(fc.Xpad.reserve(size_t(N) * ldx * 4));
-        LGNN_HIP_CHECK(hipMemsetAsync(fc.Xpad.p, 0, size_t(N) * ldx * 4, s));
-        LGNN_HIP_CHECK(hipMemcpy2DAsync(fc.Xpad.p, size_t(ldx) * 4, h->X, size_t(h->dims[0]) * 4, size_t(h->dims[0]) * 4,
-                                        size_t(N), hipMemcpyDeviceToDevice, s));
-      }
-      fc.lin_in_p[0] = fc.Xpad.as<float>();
-      fc.lin_in_ld[0] = ldx;
-    }
+    LGNN_CALL(forward_input_view(h, s));
     for (int l = 0; l < L; ++l) {
       const int64_t din = h->dims[l], dout = h->dims[l + 1];
       GemmEpilogue ep;
@@ -162,30 +208,30 @@ static int gcn_or_sage_forward(lgnn_ctx* h, hipStream_t s) {
   return 0;
 }
 
-int forward_ensure(lgnn_ctx* h, hipStream_t s) {
-  LGNN_REQUIRE(h->L > 0 && h->X, "no model bound (call lgnn_bind_model first)");
-  if (h->fc.valid) return 0;
-  for (int l = 0; l < h->L; ++l) {
-    LGNN_CALL(h->Wt[l].reserve(size_t(h->in_dim[l]) * h->dims[l + 1] * 4));
-    const float* W = h->W[l];
-    if (h->has_res && l < h->L - 1) {
-      if (h->kind == LGNN_KIND_SAGE) {
-        LGNN_CALL(build_sage_res_weights(h, l, s));
-        W = h->Wcomb[l].as<float>();
-      } else {
-        LGNN_CALL(h->Wrt[l].reserve(size_t(h->dims[l]) * h->dims[l + 1] * 4));
-        LGNN_CALL(launch_transpose(h->Wr[l], h->dims[l + 1], h->dims[l], h->Wrt[l].as<float>(), s));
-      }
-    }
-    LGNN_CALL(launch_transpose(W, h->dims[l + 1], h->in_dim[l], h->Wt[l].as<float>(), s));
-  }
-  LGNN_CALL(gcn_or_sage_forward(h, s));
+static void forward_mark_valid(lgnn_ctx* h) {
   h->fc.valid = true;
   h->fc.aux_valid = false;
   // layer 0 of a GCN sees X itself: its input Gram and P X do not depend on the weights
   const bool keep0 = h->fc.x_valid && h->kind == LGNN_KIND_GCN;
   for (int l = 0; l < kMaxLayers; ++l) h->fc.gram_valid[l] = (l == 0 && keep0) ? h->fc.gram_valid[0] : false;
   h->fc.x_valid = true;
+}
+
+int forward_ensure(lgnn_ctx* h, hipStream_t s) {
+  LGNN_REQUIRE(h->L > 0 && h->X, "no model bound (call lgnn_bind_model first)");
+  if (h->fc.valid) return 0;
+  if (gcn2_small_forward_supported(h)) {
+    // small plain 2-layer GCN: the pass through the cached P X (gcn2_forward.hip) leaves the auxiliary products of
+    // forward_ensure_aux behind as well, in four launches
+    LGNN_CALL(gcn2_forward_through_px(h, s));
+    forward_mark_valid(h);
+    h->fc.px_valid = true;
+    h->fc.aux_valid = true;
+    return 0;
+  }
+  LGNN_CALL(ensure_wt(h, s));
+  LGNN_CALL(gcn_or_sage_forward(h, s));
+  forward_mark_valid(h);
   return 0;
 }
 
@@ -253,11 +299,8 @@ extern "C" int lgnn_create(lgnn_ctx** out, int64_t num_nodes, const int64_t* edg
   if (rc == 0) {
     rc = h->ws.pos.reserve(size_t(num_nodes) * 4);
     if (rc == 0) rc = launch_fill_i32(h->ws.pos.as<int32_t>(), num_nodes, INT32_MAX, static_cast<hipStream_t>(stream));
-    if (rc == 0) rc = h->ws.flags.reserve(64);  // sticky asynchronous error flags, zero = clean
-    if (rc == 0 && hipMemsetAsync(h->ws.flags.p, 0, 64, static_cast<hipStream_t>(stream)) != hipSuccess) {
-      set_error("hipMemsetAsync(flags) failed");
-      rc = 1;
-    }
+    if (rc == 0) rc = h->ws.flags.reserve_host(64);  // sticky asynchronous error flags, zero = clean
+    if (rc == 0) memset(h->ws.flags.p, 0, 64);
   }
   if (rc != 0) { lgnn_destroy(h); return rc; }
   *out = h;
@@ -328,6 +371,7 @@ extern "C" int lgnn_invalidate(lgnn_ctx* h) {
   if (!h) { set_error("null context"); return 2; }
   h->fc.valid = false;
   h->fc.aux_valid = false;
+  h->fc.wt_valid = false;
   const bool keep0 = h->fc.x_valid && h->kind == LGNN_KIND_GCN;
   for (int l = 0; l < kMaxLayers; ++l) h->fc.gram_valid[l] = (l == 0 && keep0) ? h->fc.gram_valid[0] : false;
   return 0;
@@ -375,10 +419,11 @@ extern "C" int lgnn_check_async_errors(lgnn_ctx* h, void* stream) {
   if (!h) { set_error("null context"); return 2; }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!h->ws.flags.p) return 0;
-  int flags[4] = {0, 0, 0, 0};
-  LGNN_HIP_CHECK(hipMemcpyAsync(flags, h->ws.flags.p, sizeof(flags), hipMemcpyDeviceToHost, s));
+  // the flags live in pinned host memory the kernels store to directly: wait for the stream, read, clear
   LGNN_HIP_CHECK(hipStreamSynchronize(s));
-  LGNN_HIP_CHECK(hipMemsetAsync(h->ws.flags.p, 0, 64, s));
+  int flags[4];
+  volatile int* dev = h->ws.flags.as<int>();
+  for (int i = 0; i < 4; ++i) { flags[i] = dev[i]; dev[i] = 0; }
   LGNN_REQUIRE(flags[1] == 0 && flags[0] != 1 && flags[2] == 0, "a batch contained a node index outside [0, num_nodes)");
   LGNN_REQUIRE(flags[0] != 2, "a batch contained a label outside [0, num_classes)");
   return 0;

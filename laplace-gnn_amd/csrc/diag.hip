@@ -112,6 +112,78 @@ __global__ void ef_last_weights_kernel(const float* __restrict__ r, int64_t n, f
   if (t < n) w[t] = scale * r[t] * r[t];
 }
 
+// Classification batches of the closed-form diagonal: what batch_prologue + q_kernel did in five launches (mark, clear,
+// seed, q, unmark) as one.  One wave per sample: p = softmax(logits[idx[m]]) -> probs, loss += logsumexp - f[y]
+// (CrossEntropyLoss(reduction='sum')), the q rows of q_kernel from the probabilities in LDS, and the sticky flags the
+// prologue raises (word 1: node id out of range, word 0 = 2: label out of range).  The diagonal needs neither the batch
+// positions nor the multiplicities of duplicated ids (every occurrence is its own sample), so nothing is marked.
+__global__ __launch_bounds__(256) void diag_prologue_kernel(const float* __restrict__ logits, int64_t C,
+                                                            const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
+                                                            int64_t M, int64_t N, const float* __restrict__ W1, int64_t ldw,
+                                                            int64_t d, int64_t off_self, int64_t off_neigh, int has_self,
+                                                            float* __restrict__ probs, float* __restrict__ q,
+                                                            float* __restrict__ loss, int* __restrict__ bad) {
+  extern __shared__ float sm[];
+  __shared__ float loss_part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* p_s = sm + size_t(wave) * C;
+  float loss_acc = 0.f;
+  for (int64_t m = int64_t(blockIdx.x) * 4 + wave; m < M; m += int64_t(gridDim.x) * 4) {
+    const int64_t n = idx[m];
+    if (n < 0 || n >= N) {  // no entries in the first-layer kernel, zero weight in the last-layer kernel
+      if (lane == 0) bad[1] = 1;
+      for (int64_t k = lane; k < C; k += 64) probs[m * C + k] = 0.f;
+      for (int64_t j = lane; j < (has_self ? 3 : 1) * d; j += 64) q[(j / d) * M * d + m * d + (j % d)] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int64_t k = lane; k < C; k += 64) { const float v = logits[n * C + k]; p_s[k] = v; mx = fmaxf(mx, v); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float fy = 0.f;
+    if (lane == 0) {
+      const int64_t yy = y[m];
+      if (yy < 0 || yy >= C) *bad = 2;
+      else fy = logits[n * C + yy];
+    }
+    float se = 0.f;
+    for (int64_t k = lane; k < C; k += 64) { const float e = expf(p_s[k] - mx); p_s[k] = e; se += e; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+    const float inv = 1.0f / se;
+    for (int64_t k = lane; k < C; k += 64) { const float p = p_s[k] * inv; p_s[k] = p; probs[m * C + k] = p; }
+    if (lane == 0) loss_acc += logf(se) + mx - fy;
+    // p_s is read across lanes below: same wave, LDS executes a wave's operations in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int64_t j = lane; j < d; j += 64) {  // q_kernel's centred form, same summation order
+      float sn = 0.f, ss = 0.f, snn = 0.f, sss = 0.f, ssn = 0.f;
+      for (int64_t k = 0; k < C; ++k) {
+        sn += p_s[k] * W1[k * ldw + off_neigh + j];
+        if (has_self) ss += p_s[k] * W1[k * ldw + off_self + j];
+      }
+      for (int64_t k = 0; k < C; ++k) {
+        const float p = p_s[k];
+        const float dn = W1[k * ldw + off_neigh + j] - sn;
+        snn += p * dn * dn;
+        if (has_self) {
+          const float dsf = W1[k * ldw + off_self + j] - ss;
+          sss += p * dsf * dsf;
+          ssn += p * dsf * dn;
+        }
+      }
+      q[m * d + j] = snn;
+      if (has_self) { q[M * d + m * d + j] = ssn; q[2 * M * d + m * d + j] = sss; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the next sample overwrites p_s
+  }
+  if (lane == 0) loss_part[wave] = loss_acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (loss_part[0] + loss_part[1]) + (loss_part[2] + loss_part[3]));
+}
+
 constexpr int JPT = 16;  // hidden units per thread
 constexpr int DCH = 32;  // (sample, neighbour) entries staged per chunk
 
@@ -229,6 +301,194 @@ __global__ __launch_bounds__(256) void diag_first_layer_kernel(
 #pragma unroll
   for (int jj = 0; jj < JPT; ++jj) {
     const int64_t j = j0 + jg * JPT + jj;
+    if (j < H) {
+      if (i < E.width) atomicAdd(&diag_w[j * E.width + i], acc[jj]);
+      else atomicAdd(&diag_b[j], acc[jj]);
+    }
+  }
+}
+
+// ---- the same contraction, rows by LDS-DMA, the wave-uniform operand by v_readlane --------------------------------------
+// diag_first_layer_kernel above stages a chunk of entries, waits for it, computes, and starts over.  Measured at the Cora
+// shape (0.131 ms for a ~10-20 us VALU floor): (1) per chunk one exposed round trip for the entries (row pointer ->
+// column / value) and one for their rows; (2) in the FMA loop every thread reads the 16 act' values of its wave with
+// four ds_read_b128 that all 64 lanes address identically -- 1 KB of LDS bandwidth per instruction for 64 B of data,
+// 3 GB of LDS reads per launch -- and waits for LDS twice per entry (closing mark, then data).  Here
+// (a) ALL entries of a slab are resolved up front, in parallel, into LDS (one chain per workgroup, not one per chunk);
+// (b) the entries' rows -- E for the lanes' 64 input columns, act' (or, for the entry that closes a GCN sample, q) for
+//     the tile's 64 hidden units -- are copied global -> LDS by the DMA path (global_load_lds, one dword per lane: the
+//     [entry][64 lanes] layout, no data registers) into a ring of NBUF slots, NBUF - 1 chunks ahead of the FMAs, behind
+//     counted s_waitcnt vmcnt -- every wave issues the same number of copies per chunk (padding entries copy a zero
+//     word) so that the count is a compile-time constant -- and one raw barrier per chunk;
+// (c) both rows are read ONE dword per lane (conflict free, 512 B per entry and wave instead of 4.3 KB); the hidden-unit
+//     operand, which is the same for all lanes, is taken out of the row register with v_readlane (an SGPR operand of the
+//     FMA): 16 readlanes + 8 packed FMAs per entry, no LDS broadcast, and the next entry's two dwords are loaded while
+//     the current one computes.
+// (Tried and measured slower: the uniform operand through the scalar cache, s_load_dwordx16 per entry -- 0.111 ms: the
+//  scalar data cache has little miss parallelism, and its out-of-order returns force lgkmcnt(0) waits.)
+__device__ float g_diag_consts[2] = {0.f, 1.f};
+
+__device__ __forceinline__ void lds_dma4(const float* src, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                            reinterpret_cast<uintptr_t>(lds_dst)), 4, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ float lane_value(float x, int l) {  // x of lane l (wave uniform l) as a scalar operand
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+
+constexpr int kDiagMaxEntries = 512;  // entries resolved per pass (a slab of 64 Cora samples has ~380)
+
+template <int HAS_SELF, int DCH, int NBUF>
+__global__ __launch_bounds__(256) void diag_first_layer_dma_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    const int64_t* __restrict__ idx, int64_t M, int64_t slab, FeatView E, const float* __restrict__ dact,
+    int64_t H, const float* __restrict__ q, float* __restrict__ diag_w, float* __restrict__ diag_b) {
+  constexpr int ARR = HAS_SELF ? 5 : 2;  // arrays per slot: E rows, act' rows (GCN closing entry: its q row) [, 3 q rows]
+  constexpr int BUF = ARR * DCH * 64;    // floats per ring slot
+  constexpr int NI = (DCH / 4) * ARR;    // DMA instructions per wave and chunk
+  constexpr int MAXE = kDiagMaxEntries;
+  static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * NI <= 63 && (DCH & (DCH - 1)) == 0, "ring: vmcnt is a 6-bit counter");
+  // ONE LDS object (hipcc drains vmcnt before reads of a second one): ring | entries {column, weight, closing mark} | slab tables
+  __shared__ float smem[NBUF * BUF + 4 * (MAXE + 2) + 65 + 64 + 64 + 63];
+  float* __restrict__ ring = smem;
+  // (read as scalars: a vector-typed LDS read makes hipcc wait for every LDS-DMA copy in flight)
+  int32_t* __restrict__ smeta = reinterpret_cast<int32_t*>(smem + NBUF * BUF);
+  int32_t* __restrict__ soff = reinterpret_cast<int32_t*>(smem + NBUF * BUF + 4 * (MAXE + 2));
+  int32_t* __restrict__ snode = soff + 65;
+  int32_t* __restrict__ sbase = snode + 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int jg = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t i = int64_t(blockIdx.x) * 64 + lane;
+  const int64_t j0 = int64_t(blockIdx.y) * 64;
+  const bool i_ok = i <= E.width, j_ok = j0 + lane < H;
+  const int64_t m_begin = int64_t(blockIdx.z) * slab, m_end = min(M, m_begin + slab);
+  const int ns = int(m_end - m_begin);  // <= 64
+  if (tid < 64) {
+    int32_t len = 0, node = -1, base = 0;
+    if (tid < ns) {
+      const int64_t n = idx[m_begin + tid];
+      if (n >= 0 && n < E.nrows) { node = int32_t(n); base = rowptr[n]; len = rowptr[n + 1] - base + 1; }
+    }
+    snode[tid] = node;
+    sbase[tid] = base;
+    int32_t incl = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    soff[tid + 1] = incl;
+    if (tid == 0) soff[0] = 0;
+  }
+  __syncthreads();
+  const int32_t etot = soff[64];
+  float acc[JPT], T[JPT];
+#pragma unroll
+  for (int jj = 0; jj < JPT; ++jj) { acc[jj] = 0.f; T[jj] = 0.f; }
+  const float* __restrict__ zero = g_diag_consts;
+  // this lane's column of E: a feature column, the bias column (rowsum(P) per node, or the constant 1), or nothing
+  const float* __restrict__ ecol = !i_ok ? nullptr : (i < E.width ? E.base + i : E.bias_col);
+  const int64_t estride = !i_ok ? 0 : (i < E.width ? E.ld : (E.bias_col ? 1 : 0));
+  if (i_ok && i == E.width && !E.bias_col) ecol = g_diag_consts + 1;
+  const float* __restrict__ dcol = dact + j0 + lane;               // this lane's hidden unit of the act' rows ...
+  const float* __restrict__ qcol = q + m_begin * H + j0 + lane;    // ... and of the slab's q rows
+  const int jb = jg * JPT;  // this wave's 16 hidden units sit in lanes jb .. jb + 15 of a row register
+
+  for (int32_t sb0 = 0; sb0 < etot; sb0 += MAXE) {
+    const int ne = min(MAXE, int(etot - sb0));
+    for (int e = tid; e < ne + 2; e += 256) {  // (a) every entry of this pass: sample by bisection, then column / value
+      const int32_t g = sb0 + e;
+      struct { int32_t x, y, z; } m = {0, 0, -1};  // past the end: two entries of weight 0 for the look-ahead
+      if (e < ne) {
+        int lo = 0, hi = ns;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (soff[mid] <= g) lo = mid; else hi = mid; }
+        const int32_t r = g - soff[lo], len = soff[lo + 1] - soff[lo] - 1;
+        m.x = snode[lo]; m.z = lo;  // the virtual entry: the node itself, closes sample lo, weight 0
+        if (r < len) { const int32_t p = sbase[lo] + r; m.x = col[p]; m.y = __builtin_bit_cast(int, val[p]); m.z = -1; }
+      }
+      smeta[4 * e] = m.x; smeta[4 * e + 1] = m.y; smeta[4 * e + 2] = m.z;
+    }
+    __syncthreads();
+    const int nch = (ne + DCH - 1) / DCH;
+    auto issue = [&](int c) {  // (b) chunk c -> ring slot c % NBUF; wave jg copies the rows of entries jg, jg + 4, ...
+      float* __restrict__ slot = ring + (c % NBUF) * BUF;
+#pragma unroll
+      for (int k = 0; k < DCH / 4; ++k) {
+        const int el = jg + 4 * k, e = c * DCH + el, em = min(e, MAXE + 1);
+        const bool ok = e < ne;
+        const int64_t v = smeta[4 * em];
+        const int mk = smeta[4 * em + 2];
+        const bool nb = ok && mk < 0, cl = ok && mk >= 0;
+        lds_dma4(((nb || (HAS_SELF && cl)) && i_ok) ? ecol + v * estride : zero, slot + el * 64);
+        if (HAS_SELF) {
+          lds_dma4((ok && j_ok) ? dcol + v * H : zero, slot + (DCH + el) * 64);
+#pragma unroll
+          for (int z = 0; z < 3; ++z)
+            lds_dma4((cl && j_ok) ? qcol + int64_t(mk) * H + int64_t(z) * M * H : zero, slot + ((2 + z) * DCH + el) * 64);
+        } else {  // the entry that closes a GCN sample reads no act' row: its row is the sample's q row
+          lds_dma4(j_ok ? (nb ? dcol + v * H : (cl ? qcol + int64_t(mk) * H : zero)) : zero, slot + (DCH + el) * 64);
+        }
+      }
+    };
+    for (int c = 0; c < NBUF - 1 && c < nch; ++c) issue(c);
+    // (c) entry g computes while entry g + 1's dwords are on their way from LDS
+    float ev0 = 0.f, r0 = 0.f, a0 = 0.f, ev1 = 0.f, r1 = 0.f, a1 = 0.f;
+    int mk0 = -1, rmk1 = -1, g = 0;
+    auto fetch = [&]() {  // ring step at a chunk's first entry; the next entry's dwords (same chunk) start their way
+      const int el = g & (DCH - 1), c = g / DCH;
+      const float* __restrict__ slot = ring + (c % NBUF) * BUF;
+      if (el == 0) {
+        const int ahead = min(NBUF - 2, nch - 1 - c);  // chunks after c whose copies are in flight
+        if (NBUF >= 4 && ahead >= 2) wait_vmcnt<(NBUF >= 4 ? 2 : 0) * NI>();
+        else if (ahead == 1) wait_vmcnt<NI>();
+        else wait_vmcnt<0>();
+        asm volatile("s_barrier" ::: "memory");  // chunk c has landed for all waves; chunk c - 1 is consumed
+        if (c + NBUF - 1 < nch) issue(c + NBUF - 1);
+        ev0 = slot[lane]; r0 = slot[DCH * 64 + lane];  // (a chunk's first rows are read behind its barrier)
+        a0 = __builtin_bit_cast(float, smeta[4 * g + 1]);
+      }
+      if (el + 1 < DCH) {
+        ev1 = slot[(el + 1) * 64 + lane]; r1 = slot[(DCH + el + 1) * 64 + lane];
+        a1 = __builtin_bit_cast(float, smeta[4 * (g + 1) + 1]);
+      }
+      rmk1 = smeta[4 * (g + 1) + 2];
+      return slot + el * 64 + lane;
+    };
+    auto rotate = [&]() { ev0 = ev1; r0 = r1; a0 = a1; mk0 = __builtin_amdgcn_readfirstlane(rmk1); ++g; };
+    mk0 = __builtin_amdgcn_readfirstlane(smeta[2]);
+    while (g < ne) {
+      while (mk0 < 0 && g < ne) {  // neighbour entries: T += act'(h_1[v]) (x) a E[v]
+        fetch();
+        const float ea = ev0 * a0;
+#pragma unroll
+        for (int jj = 0; jj < JPT; ++jj) T[jj] = fmaf(lane_value(r0, jb + jj), ea, T[jj]);
+        rotate();
+      }
+      if (g < ne) {  // the entry that closes its sample folds the finished T into the accumulator
+        const float* __restrict__ mine = fetch();
+        if (HAS_SELF) {
+          const float q0v = mine[2 * DCH * 64], q1v = mine[3 * DCH * 64], q2v = mine[4 * DCH * 64];
+#pragma unroll
+          for (int jj = 0; jj < JPT; ++jj) {
+            const float sf = lane_value(r0, jb + jj) * ev0;
+            acc[jj] += lane_value(q0v, jb + jj) * T[jj] * T[jj] + 2.f * lane_value(q1v, jb + jj) * sf * T[jj] +
+                       lane_value(q2v, jb + jj) * sf * sf;
+            T[jj] = 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < JPT; ++jj) { acc[jj] = fmaf(lane_value(r0, jb + jj) * T[jj], T[jj], acc[jj]); T[jj] = 0.f; }
+        }
+        rotate();
+      }
+    }
+    __syncthreads();  // the next pass overwrites the entry table and the ring
+  }
+  if (!i_ok) return;
+#pragma unroll
+  for (int jj = 0; jj < JPT; ++jj) {
+    const int64_t j = j0 + jb + jj;
     if (j < H) {
       if (i < E.width) atomicAdd(&diag_w[j * E.width + i], acc[jj]);
       else atomicAdd(&diag_b[j], acc[jj]);
@@ -460,7 +720,10 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
     return 0;
   }
   LGNN_CALL(forward_ensure_aux(h, s));
-  LGNN_CALL(batch_prologue(h, idx, y, M, false, false, loss_out, s));
+  // classification: probabilities, loss, q and the id / label checks in ONE launch (diag_prologue_kernel); regression
+  // (Lambda = I, no probabilities) keeps the shared prologue
+  const bool light = !regression;
+  if (!light) LGNN_CALL(batch_prologue(h, idx, y, M, false, false, loss_out, s));
   // regression: Lambda = I, i.e. q = sum_k w_kj^2 and unit weights in the last layer (the interface's factor is the caller's)
   const float* probs = regression ? nullptr : h->ws.probs.as<float>();
   // Samples per workgroup slab.  A thread walks its slab's samples and their neighbours one after the other (dependent
@@ -471,29 +734,53 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
   // (measured at the Cora shape: 1 024 - 2 048 workgroups are the optimum -- fewer lengthen the per-workgroup chain,
   //  more multiply the float atomics of the flush: 0.13 ms at 2 048, 0.26 ms at 8 192)
   int64_t slab = std::max<int64_t>(8, std::min<int64_t>(64, cdiv(M * tiles, 2048)));
+  // the LDS-DMA kernel hides the chain: longer slabs, fewer atomics (~768 workgroups, three per CU)
+  if (getenv("LGNN_DIAG_STAGED") == nullptr) slab = std::max<int64_t>(8, std::min<int64_t>(64, cdiv(M * tiles, 768)));
+  if (const char* e = getenv("LGNN_DIAG_SLAB")) slab = std::max<int64_t>(1, std::min<int64_t>(64, atoll(e)));
   const unsigned nslab = unsigned(cdiv(M, slab));
 
   int64_t off = 0;
-  if (L == 2) {
-    const int64_t H = h->dims[1], in0 = h->in_dim[0];
+  {
+    const int64_t H = L == 2 ? h->dims[1] : 0, in0 = h->in_dim[0];
     const int has_self = h->kind == LGNN_KIND_SAGE ? 1 : 0;
     LGNN_CALL(h->ws.misc.reserve(size_t(3) * M * H * 4 + size_t(M) * C * 4));
     float* q = h->ws.misc.as<float>();
-    hipLaunchKernelGGL(q_kernel, dim3(unsigned(cdiv(M * H, 256))), dim3(256), 0, s, probs, M, C, h->W[1],
-                       h->in_dim[1], H, int64_t(0), has_self ? H : int64_t(0), has_self, q);
-    FeatView E;
-    feat_views(h, 0, E);
-    const dim3 grid{unsigned(cdiv(E.width + 1, 64)), unsigned(cdiv(H, 64)), nslab};
-    if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the diagonal path (bench.py roofline)
-    if (has_self)
-      hipLaunchKernelGGL(diag_first_layer_kernel<1>, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab, E,
-                         h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
-    else
-      hipLaunchKernelGGL(diag_first_layer_kernel<0>, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab, E,
-                         h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
-    LGNN_HIP_CHECK(hipGetLastError());
-    if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += M; }
-    off = H * in0 + H;
+    if (light) {
+      LGNN_CALL(h->ws.probs.reserve(size_t(M) * C * 4));
+      probs = h->ws.probs.as<float>();
+      LGNN_REQUIRE(4 * C * 4 <= 60 * 1024, "too many classes for the prologue kernel");
+      hipLaunchKernelGGL(diag_prologue_kernel, dim3(unsigned(std::min<int64_t>(cdiv(M, 4), 4096))), dim3(256),
+                         size_t(4 * C) * 4, s, h->fc.out.as<float>(), C, idx, static_cast<const int64_t*>(y), M, h->N,
+                         L == 2 ? h->W[1] : nullptr, L == 2 ? h->in_dim[1] : 0, H, int64_t(0), has_self ? H : int64_t(0),
+                         has_self, h->ws.probs.as<float>(), q, loss_out, h->ws.flags.as<int>());
+      LGNN_HIP_CHECK(hipGetLastError());
+    } else if (L == 2) {
+      hipLaunchKernelGGL(q_kernel, dim3(unsigned(cdiv(M * H, 256))), dim3(256), 0, s, probs, M, C, h->W[1],
+                         h->in_dim[1], H, int64_t(0), has_self ? H : int64_t(0), has_self, q);
+    }
+    if (L == 2) {
+      FeatView E;
+      feat_views(h, 0, E);
+      const dim3 grid{unsigned(cdiv(E.width + 1, 64)), unsigned(cdiv(H, 64)), nslab};
+      if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the diagonal path (bench.py roofline)
+      if (getenv("LGNN_DIAG_STAGED") != nullptr) {  // the register-staged kernel (A/B runs)
+        if (has_self)
+          hipLaunchKernelGGL(diag_first_layer_kernel<1>, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab,
+                             E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
+        else
+          hipLaunchKernelGGL(diag_first_layer_kernel<0>, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab,
+                             E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
+      } else if (has_self) {
+        hipLaunchKernelGGL((diag_first_layer_dma_kernel<1, 16, 3>), grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx,
+                           M, slab, E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
+      } else {
+        hipLaunchKernelGGL((diag_first_layer_dma_kernel<0, 16, 4>), grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx,
+                           M, slab, E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
+      }
+      LGNN_HIP_CHECK(hipGetLastError());
+      if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += M; }
+      off = H * in0 + H;
+    }
   }
   {
     FeatView Phi;
@@ -511,7 +798,7 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
                        diag_out + off, diag_out + off + C * Phi.width, wgt);
     LGNN_HIP_CHECK(hipGetLastError());
   }
-  LGNN_CALL(batch_epilogue(h, idx, M, s));
+  if (!light) LGNN_CALL(batch_epilogue(h, idx, M, s));
   return 0;
 }
 

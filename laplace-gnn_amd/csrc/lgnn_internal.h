@@ -42,7 +42,9 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool host = false;  // reserve_host: pinned host memory the device reads and writes in place (same address on both sides)
   int reserve(size_t want);
+  int reserve_host(size_t want);
   void release();
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -59,6 +61,7 @@ constexpr int kMaxLayers = 8;
 struct ForwardCache {
   bool valid = false;
   bool aux_valid = false;            // rowsum / propagated inputs for diag + last layer
+  bool wt_valid = false;             // lgnn_ctx::Wt (transposed weights) match the bound weights' current version
   // What depends on the graph and X only -- not on the weights -- survives lgnn_invalidate and is rebuilt at bind time:
   bool x_valid = false;              // Xpad, gram_raw[0] (GCN: X^T X)
   bool px_valid = false;             // rowsum, prop_in[0] (GCN: P X)
@@ -370,6 +373,11 @@ int launch_gram256_stream(const float* Y, int64_t ld, int64_t rows, int64_t widt
 int forward_ensure(lgnn_ctx* h, hipStream_t s);
 int forward_ensure_grams(lgnn_ctx* h, hipStream_t s);
 int forward_ensure_aux(lgnn_ctx* h, hipStream_t s);
+int forward_input_view(lgnn_ctx* h, hipStream_t s);  // GCN: lin_in_p[0] / lin_in_ld[0] (X or its padded copy)
+int ensure_wt(lgnn_ctx* h, hipStream_t s);           // transposed weights (forward GEMM, adjacency gradient)
+// gcn2_forward.hip: small plain 2-layer GCN, forward + auxiliary products through the cached P X
+bool gcn2_small_forward_supported(const lgnn_ctx* h);
+int gcn2_forward_through_px(lgnn_ctx* h, hipStream_t s);
 // ---- diag.hip ---------------------------------------------------------------------------
 int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags, float* diag_out,
                     float* loss_out, hipStream_t s);

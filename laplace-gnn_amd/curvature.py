@@ -194,6 +194,14 @@ class HipCurvatureInterface:
         eng.diag_accumulate(x, y, H, loss)
         return self.factor * loss[0], H
 
+    def diag_accumulate_(self, H: torch.Tensor, loss_buf: torch.Tensor, x: torch.Tensor, y: torch.Tensor):
+        """Diagonal GGN of one batch added IN PLACE to the caller's ``H`` and the raw loss sum to ``loss_buf`` (the caller
+        applies ``factor``): no temporaries, no torch kernels per batch (laplace/curvature/curvature.py:412-432)."""
+        if self.stochastic:
+            raise NotImplementedError("in-place accumulation exists for the GGN diagonal")
+        self.engine.set_likelihood(self.likelihood)
+        self.engine.diag_accumulate(x, y, H, loss_buf)
+
     # ---- full (last layer) ---------------------------------------------------------------------
     def full(self, x: torch.Tensor, y: torch.Tensor, mc_labels=None, **kwargs: Any):
         if self.stochastic and not self.last_layer:

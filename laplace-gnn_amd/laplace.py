@@ -120,6 +120,10 @@ class BaseLaplace:
         raise ValueError("Mismatch of prior and model. Diagonal, scalar, or per-layer prior.")
 
 
+def _is_zero_number(v) -> bool:
+    return isinstance(v, (int, float)) and v == 0
+
+
 class ParametricLaplace(BaseLaplace):
     def _init_H(self):
         raise NotImplementedError
@@ -136,15 +140,22 @@ class ParametricLaplace(BaseLaplace):
             self._init_H()
             self.loss = 0
             self.n_data = 0
-        self.model.eval()
+        if self.model.training:
+            self.model.eval()
         self.mean = parameters_to_vector(self.params).detach()
-        X0 = next(iter(train_loader))[0]
-        with torch.no_grad():
-            try:
-                out = self.model(X0[:1].to(self._device))
-            except (TypeError, AttributeError):
-                out = self.model(X0.to(self._device))
-        self.n_outputs = out.shape[-1]
+        dev = self._device
+        # the reference finds the output width with a forward pass of one sample (laplace/baselaplace.py:806-816); a model
+        # that states it (laplace_gnn_amd.models.BaseGNN.n_outputs) saves that pass' launches -- a Cora-shaped fit is
+        # launch bound
+        self.n_outputs = getattr(self.model, "n_outputs", None)
+        if self.n_outputs is None:
+            X0 = next(iter(train_loader))[0]
+            with torch.no_grad():
+                try:
+                    out = self.model(X0[:1].to(dev))
+                except (TypeError, AttributeError):
+                    out = self.model(X0.to(dev))
+            self.n_outputs = out.shape[-1]
         setattr(self.model, "output_size", self.n_outputs)
         N = len(train_loader.dataset)
         rank, world = _dist_info(process_group)
@@ -153,13 +164,13 @@ class ParametricLaplace(BaseLaplace):
         H_prev = None
         if not override and world > 1 and torch.is_tensor(getattr(self, "H", None)):
             H_prev, self.H = self.H, torch.zeros_like(self.H)
-        loss = torch.zeros((), dtype=torch.float32, device=self._device)
+        loss = None  # stays None for in-place backends (they add the raw loss to a buffer of their own)
         plan = self._shard_plan(train_loader, rank, world)
         for t, (X, y) in enumerate(train_loader):
             todo = plan(t, X.shape[0])
             if todo is None:
                 continue
-            X, y = X.to(self._device), y.to(self._device)
+            X, y = X.to(dev), y.to(dev)
             if isinstance(todo, slice):  # sample-additive structures: this rank's slice of the batch
                 X, y = X[todo], y[todo]
                 loss_batch, H_batch = self._curv_closure(X, y, N=N)
@@ -167,7 +178,8 @@ class ParametricLaplace(BaseLaplace):
                 loss_batch, H_batch = self._curv_closure(X, y, N=N)
             else:  # (class_begin, class_end): an exact additive share of the batch's KFAC factors
                 loss_batch, H_batch = self._curv_closure(X, y, N=N, classes=todo)
-            loss = loss + loss_batch
+            if H_batch is not None or torch.is_tensor(loss_batch):  # (in-place backends return (0.0, None): nothing to add)
+                loss = loss_batch if loss is None else loss + loss_batch
             self._accumulate(H_batch)
         self._finish_accumulate()
         if getattr(self, "_on_accumulated", None) is not None:
@@ -181,6 +193,7 @@ class ParametricLaplace(BaseLaplace):
             phase = getattr(self, "_on_phase", None)  # measurement hook (bench.py): brackets the factor all-reduce
             if phase is not None:
                 phase("reduce_begin")
+            loss = torch.as_tensor(0.0 if loss is None else loss, dtype=torch.float32, device=dev)
             all_reduce_flat_(self._reduce_tensors() + [loss], process_group)
             if phase is not None:
                 phase("reduce_end")
@@ -189,7 +202,8 @@ class ParametricLaplace(BaseLaplace):
         if H_prev is not None:
             H_prev += self.H
             self.H = H_prev
-        self.loss = self.loss + loss
+        if loss is not None:
+            self.loss = loss if _is_zero_number(self.loss) else self.loss + loss
         self.n_data += N
 
     # how the work of one fit is dealt to the ranks of the process group
@@ -712,13 +726,46 @@ class DiagLaplace(ParametricLaplace):
     _sample_additive = True  # einsum('bcp,bck,bkp->p') is a sum over b: batches may be sliced by samples
 
     def _init_H(self):
-        self.H = torch.zeros(self.n_params, device=self._device)
+        # H and the raw loss share one flat buffer [H | loss]: one fill per fit, one all-reduce message
+        self._hl = torch.zeros(self.n_params + 1, device=self._device)
+        self.H = self._hl[:self.n_params]
+
+    def _inplace_backend(self) -> bool:
+        """The HIP backend adds a batch's diagonal GGN and raw loss straight into caller-owned buffers (no per-batch
+        temporaries, no per-batch torch kernels: a Cora-shaped fit is launch bound); other backends return (loss, H)."""
+        be = self.backend
+        return (hasattr(be, "diag_accumulate_") and not getattr(be, "stochastic", False) and not self._asdl_fisher_kwargs
+                and type(be).diag is getattr(HipGGN, "diag", None) and getattr(self, "_hl", None) is not None
+                and self.H.data_ptr() == self._hl.data_ptr())
 
     def _curv_closure(self, X, y, N):
+        if self._inplace_backend():
+            self.backend.diag_accumulate_(self.H, self._hl[self.n_params:], X, y)
+            return 0.0, None
         return self.backend.diag(X, y, N=N, **self._asdl_fisher_kwargs)
 
+    def _accumulate(self, H_batch):
+        if H_batch is not None:
+            self.H += H_batch
+
     def _reduce_tensors(self):
+        if getattr(self, "_hl", None) is not None and self.H.data_ptr() == self._hl.data_ptr():
+            return [self._hl]
         return [self.H]
+
+    def fit(self, train_loader, override: bool = True, progress_bar: bool = False, process_group=None) -> None:
+        if not override and getattr(self, "_hl", None) is not None:
+            slot = self._hl[self.n_params:]
+            if torch.is_tensor(self.loss) and self.loss.data_ptr() == slot.data_ptr():
+                self.loss = self.loss.clone()  # the earlier fit handed the slot itself out
+            slot.zero_()  # the loss slot restarts; H keeps the earlier fits
+        super().fit(train_loader, override=override, progress_bar=progress_bar, process_group=process_group)
+        if getattr(self, "_hl", None) is not None and self.H.data_ptr() == self._hl.data_ptr():
+            # override=True allocated _hl for this fit: its loss slot can be handed out as it is (no kernel); a buffer that
+            # the next override=False fit zeroes again must be copied
+            raw = self._hl[self.n_params] if override else self._hl[self.n_params].clone()
+            batch_loss = raw if self.backend.factor == 1.0 else self.backend.factor * raw
+            self.loss = batch_loss if _is_zero_number(self.loss) else self.loss + batch_loss
 
     @property
     def posterior_precision(self) -> torch.Tensor:

@@ -129,6 +129,12 @@ class BaseGNN(nn.Module):
         adj[rows, cols] = 1
         return adj
 
+    @property
+    def n_outputs(self) -> int:
+        """Width of the logits: Laplace.fit reads it instead of running the one-sample forward pass the reference uses to
+        find it (laplace/baselaplace.py:806-816)."""
+        return self.out_channels
+
     def forward_adj(self) -> torch.Tensor:
         """Propagation matrix as a sparse COO tensor (normalize_adj / mean_agg result)."""
         r, c, v = self.engine.export_propagation()
