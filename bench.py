@@ -389,14 +389,16 @@ def main():
                                    "their neighbours), so frac can exceed 1 and executed_frac_of_peak overstates by the "
                                    "share of skipped rows" if w.get("kind") == "sage" else "")})
             elif structure == "diag":
-                # dominant kernel: diag_first_layer_kernel, one launch per batch.  ALGORITHMIC bytes per launch
-                # (SURVEY.md 8(d) "Diag (C2)"): N*F*4 + nnz*8 + 2*P*4; flops 2*M*dbar*H*(F+1).  HBM bound by that count
-                # (in practice latency bound: ~16 MB per launch).
+                # dominant kernel: the first-layer contraction (GCN: diag_first_layer_mfma_kernel, GraphSAGE:
+                # diag_first_layer_dma_kernel), one launch per batch.  ALGORITHMIC bytes per launch (SURVEY.md 8(d)
+                # "Diag (C2)"): N*F*4 + nnz*8 + 2*P*4; flops 2*M*dbar*H*(F+1).  HBM bound by that count (in practice latency
+                # bound: ~16 MB per launch; DESIGN.md has the phase breakdown).
                 P = eng.n_params
                 bytes_l = N * F * 4.0 + nnz * 8.0 + 2.0 * P * 4.0
                 ach = bytes_l * launches / (kern_ms * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": ach / PEAK_HBM_GBS, **common, "kernel": "diag_first_layer_kernel",
+                            "frac": ach / PEAK_HBM_GBS, **common,
+                            "kernel": "diag_first_layer_dma_kernel" if w.get("kind") == "sage" else "diag_first_layer_mfma_kernel",
                             "samples_per_launch": upl, "algorithmic_bytes_per_launch": bytes_l,
                             "algorithmic_TFLOPs": 2.0 * units * (nnz / N) * H * (F + 1) / (kern_ms * 1e-3) / 1e12}
             else:

@@ -74,6 +74,33 @@ int forward_input_view(lgnn_ctx* h, hipStream_t s) {
   return 0;
 }
 
+__global__ void set_column_kernel(float* __restrict__ A, int64_t ld, int64_t col, const float* __restrict__ x, int64_t n) {
+  const int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r < n) A[r * ld + col] = x[r];
+}
+
+// What depends on the graph and the features only (ForwardCache::px_valid): rowsum(P) and, for a GCN, the first Linear's
+// input seen from an output node WITH its bias entry, E = [P X | rowsum(P) | 0 ..] as one matrix of row stride
+// round_up(F + 1, 4) -- the closed-form diagonal's matrix-core kernel copies a row block with one 16-byte-per-lane DMA
+// (diag.hip); everybody else reads the first F columns.
+int build_px(lgnn_ctx* h, hipStream_t s) {
+  ForwardCache& fc = h->fc;
+  const int64_t N = h->N;
+  LGNN_CALL(fc.rowsum.reserve(size_t(N) * 4));
+  LGNN_CALL(launch_csr_rowsum(h->P, N, fc.rowsum.as<float>(), s));
+  if (h->kind != LGNN_KIND_GCN) return 0;
+  const int64_t F = h->dims[0], d_in = fc.lin_in_ld[0], ldE = cdiv(F + 1, 4) * 4;
+  fc.prop_ld[0] = ldE;
+  LGNN_CALL(fc.prop_in[0].reserve(size_t(N) * ldE * 4));
+  LGNN_HIP_CHECK(hipMemsetAsync(fc.prop_in[0].p, 0, size_t(N) * ldE * 4, s));
+  // (the padded width of an unaligned X is propagated as a whole: its padding columns are zero)
+  LGNN_CALL(launch_spmm(h->P, N, fc.lin_in_p[0], d_in, fc.prop_in[0].as<float>(), ldE, d_in, 0, s));
+  hipLaunchKernelGGL(set_column_kernel, dim3(unsigned(cdiv(N, 256))), dim3(256), 0, s, fc.prop_in[0].as<float>(), ldE, F,
+                     fc.rowsum.as<float>(), N);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 // W_l^T [in_l, out_l]: the forward GEMM's operand (and the adjacency gradient's); built once per weight version
 int ensure_wt(lgnn_ctx* h, hipStream_t s) {
   if (h->fc.wt_valid) return 0;
@@ -253,15 +280,10 @@ int forward_ensure_aux(lgnn_ctx* h, hipStream_t s) {
   const bool had_x = h->fc.x_valid && h->fc.px_valid;
   LGNN_CALL(forward_ensure(h, s));
   if (h->fc.aux_valid) return 0;
-  if (!had_x) {
-    LGNN_CALL(h->fc.rowsum.reserve(size_t(h->N) * 4));
-    LGNN_CALL(launch_csr_rowsum(h->P, h->N, h->fc.rowsum.as<float>(), s));
-  }
+  if (!had_x) LGNN_CALL(build_px(h, s));  // rowsum(P), P X: the graph and X only, kept across weight updates
   if (h->kind == LGNN_KIND_GCN) {
-    for (int l = 0; l < h->L; ++l) {
-      if (l == 0 && had_x) continue;  // P X depends on the graph and X only: kept across weight updates
-      // (the padded width of an unaligned X is propagated as a whole: the padding columns stay zero)
-      const int64_t d = l == 0 ? h->fc.lin_in_ld[0] : h->dims[l];
+    for (int l = 1; l < h->L; ++l) {
+      const int64_t d = h->dims[l];
       h->fc.prop_ld[l] = d;
       LGNN_CALL(h->fc.prop_in[l].reserve(size_t(h->N) * d * 4));
       LGNN_CALL(launch_spmm(h->P, h->N, h->fc.lin_in_p[l], h->fc.lin_in_ld[l], h->fc.prop_in[l].as<float>(), d, d, 0, s));

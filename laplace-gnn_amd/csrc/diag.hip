@@ -333,6 +333,15 @@ __device__ __forceinline__ void lds_dma4(const float* src, float* lds_dst) {
                                             reinterpret_cast<uintptr_t>(lds_dst)), 4, 0, 0);
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// all but the youngest `ahead` chunks' copies (NI instructions each) have landed; ahead <= MAXA (wave uniform)
+template <int NI, int MAXA> __device__ __forceinline__ void wait_chunks(int ahead) {
+  if constexpr (MAXA == 0) {
+    wait_vmcnt<0>();
+  } else {
+    if (ahead >= MAXA) wait_vmcnt<MAXA * NI>();
+    else wait_chunks<NI, MAXA - 1>(ahead);
+  }
+}
 __device__ __forceinline__ float lane_value(float x, int l) {  // x of lane l (wave uniform l) as a scalar operand
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
 }
@@ -494,6 +503,191 @@ __global__ __launch_bounds__(256) void diag_first_layer_dma_kernel(
       else atomicAdd(&diag_b[j], acc[jj]);
     }
   }
+}
+
+// ---- GCN: the per-sample outer products on the matrix cores ---------------------------------------------------------------
+// T_n = sum_v P[n, v] act'(h_1[v]) (x) E[v] is a [64 hidden x 64 input] product with K = the sample's row length: with
+// v_mfma_f32_32x32x2_f32 a pair of entries is one K step, lane l supplying A[j = l & 31][k = l >> 5] = act'(h_1[v_k, j]) and
+// B[k][i = l & 31] = P[n, v_k] E[v_k, i] -- BOTH operands are one dword per lane straight from the staged rows; no operand
+// is wave uniform, so none of the broadcast traffic (LDS b128, scalar cache, v_readlane: see above) exists.  The VALU
+// kernel's counters at the Cora shape (profiles/r03_cora_sq_counters_valu.txt): 30 M VALU instructions for 5.6 M packed
+// FMAs -- 11 M of them v_readlane -- 54 % VALU busy for 0.12 ms; here the VALU only folds a finished sample,
+// acc += q[j] T[j, i]^2 on the accumulator layout, 64 packed instructions per sample.  Measured at the Cora shape
+// (1 299 samples, 42 slabs x 6 column blocks = 252 workgroups): 0.067 ms against 0.131 ms for the round-2 kernel; by
+// switching phases off (DESIGN.md has the table): prologue 8 us, entry resolution + operand reads 21 us, row copies 7 us,
+// MFMAs 14 us, folds 8 us, the 64 float atomics per lane of the flush 15 us -- a latency chain of one wave per SIMD, not
+// a throughput bound: shorter slabs overlap more workgroups per CU but multiply the atomics (5.6 us per million).
+//   * a wave owns a 64 x 64 tile of (hidden, input) pairs: T and the running sum are 4 + 4 accumulator tiles (128 VGPRs);
+//     the 4 waves of a workgroup share the slab's entry stream and the act' rows and take 4 adjacent column blocks;
+//   * E = [P X | rowsum(P) | 0] is ONE padded matrix (the bias column sits in the first pad column: context.hip
+//     build_px), so a row's 256-column block is one 16-byte-per-lane LDS-DMA copy;
+//   * samples are padded to an even number of entries (weight 0) so that a K step never straddles two samples;
+//   * entries resolved up front, rows through the NBUF-slot DMA ring with counted vmcnt waits, as in the VALU kernel.
+__device__ float g_diag_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+using f32x16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
+
+__device__ __forceinline__ void lds_dma16(const float* src, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                            reinterpret_cast<uintptr_t>(lds_dst)), 16, 0, 0);
+}
+
+template <int DCH, int NBUF>
+__global__ __launch_bounds__(256) void diag_first_layer_mfma_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    const int64_t* __restrict__ idx, int64_t M, int64_t slab, const float* __restrict__ E, int64_t ldE, int64_t F, int64_t N,
+    const float* __restrict__ dact, int64_t H, const float* __restrict__ q, float* __restrict__ diag_w,
+    float* __restrict__ diag_b) {
+  constexpr int ROW = 256 + 64;        // floats per staged entry: 256 columns of E, 64 hidden units of act'
+  constexpr int BUF = DCH * ROW;       // floats per ring slot
+  constexpr int NI = DCH / 2;          // DMA instructions per wave and chunk (DCH / 4 entries x 2 rows)
+  constexpr int NP = DCH / 2;          // K steps (pairs of entries) per chunk
+  constexpr int MAXE = kDiagMaxEntries;
+  static_assert(NBUF >= 2 && (NBUF - 2) * NI <= 63 && DCH % 4 == 0 && MAXE % DCH == 0, "ring: vmcnt is a 6-bit counter");
+  // ONE LDS object (hipcc drains vmcnt before reads of a second one):
+  // ring | q rows of the slab [64][64] | entries {column, weight, pair record} | slab tables
+  __shared__ float smem[NBUF * BUF + 64 * 64 + 3 * MAXE + 65 + 3 * 64 + 63];
+  float* __restrict__ ring = smem;
+  float* __restrict__ sq = smem + NBUF * BUF;
+  int32_t* __restrict__ sv = reinterpret_cast<int32_t*>(sq + 64 * 64);
+  float* __restrict__ sa = sq + 64 * 64 + MAXE;
+  // record of the K step that starts at an even entry: sample | 256 (first step of its sample) | 512 (last); -1 past the end
+  int32_t* __restrict__ sflag = reinterpret_cast<int32_t*>(sa + MAXE);
+  int32_t* __restrict__ soff = sflag + MAXE;  // padded (even) entry offsets of the samples
+  int32_t* __restrict__ snode = soff + 65;
+  int32_t* __restrict__ sbase = snode + 64;
+  int32_t* __restrict__ slen = sbase + 64;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t cblk = int64_t(blockIdx.x) * 256;   // the workgroup's 256 columns of E; wave w: cblk + 64 w .. + 63
+  const int64_t j0 = int64_t(blockIdx.y) * 64;
+  const int64_t m_begin = int64_t(blockIdx.z) * slab, m_end = min(M, m_begin + slab);
+  const int ns = int(m_end - m_begin);  // <= 64
+  if (tid < 64) {
+    int32_t len = 0, node = -1, base = 0;
+    if (tid < ns) {
+      const int64_t n = idx[m_begin + tid];
+      if (n >= 0 && n < N) { node = int32_t(n); base = rowptr[n]; len = rowptr[n + 1] - base; }
+    }
+    snode[tid] = node;
+    sbase[tid] = base;
+    slen[tid] = len;
+    int32_t incl = (len + 1) & ~1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    soff[tid + 1] = incl;
+    if (tid == 0) soff[0] = 0;
+  }
+  for (int f = tid; f < 64 * 64; f += 256) {  // q rows of the slab's samples (zero past the slab / past H)
+    const int sidx = f >> 6, j = f & 63;
+    sq[f] = (sidx < ns && j0 + j < H) ? q[(m_begin + sidx) * H + j0 + j] : 0.f;
+  }
+  __syncthreads();
+  const int32_t etot = soff[64];
+  f32x16 T[2][2], acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { T[a][b][r] = 0.f; acc[a][b][r] = 0.f; }
+  // DMA sources of this lane: 4 columns of E (16 bytes), one hidden unit of act'
+  const bool e_ok = cblk + 4 * lane < ldE, j_ok = j0 + lane < H;
+  const float* __restrict__ esrc = E + cblk + 4 * lane;
+  const float* __restrict__ dsrc = dact + j0 + lane;
+
+  for (int32_t sb0 = 0; sb0 < etot; sb0 += MAXE) {
+    const int ne = min(MAXE, int(etot - sb0));  // even
+    const int nch = (ne + DCH - 1) / DCH;
+    for (int e = tid; e < nch * DCH; e += 256) {  // every entry of this pass: sample by bisection, then column / value
+      const int32_t g = sb0 + e;
+      int32_t v = 0, fl = -1;
+      float a = 0.f;
+      if (e < ne) {
+        int lo = 0, hi = ns;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (soff[mid] <= g) lo = mid; else hi = mid; }
+        const int32_t r = g - soff[lo], len = slen[lo];
+        v = snode[lo];  // (the padding entry of an odd row: weight 0)
+        if (r < len) { const int32_t p = sbase[lo] + r; v = col[p]; a = val[p]; }
+        fl = lo | (r == 0 ? 256 : 0) | (r + 2 >= len ? 512 : 0);
+      }
+      sv[e] = v; sa[e] = a; sflag[e] = fl;
+    }
+    __syncthreads();
+    auto issue = [&](int c) {  // chunk c -> ring slot c % NBUF; wave w copies the rows of entries w, w + 4, ...
+      float* __restrict__ slot = ring + (c % NBUF) * BUF;
+#pragma unroll
+      for (int k = 0; k < DCH / 4; ++k) {
+        const int el = wave + 4 * k, e = c * DCH + el;
+        const bool ok = e < ne;
+        const int64_t v = sv[e];
+        lds_dma16((ok && e_ok) ? esrc + v * ldE : g_diag_zero16, slot + el * ROW);
+        lds_dma4((ok && j_ok) ? dsrc + v * H : g_diag_zero16, slot + el * ROW + 256);
+      }
+    };
+    for (int c = 0; c < NBUF - 1 && c < nch; ++c) issue(c);
+    for (int c = 0; c < nch; ++c) {
+      wait_chunks<NI, NBUF - 2>(min(NBUF - 2, nch - 1 - c));  // chunks after c whose copies are in flight
+      asm volatile("s_barrier" ::: "memory");  // chunk c has landed for all waves; chunk c - 1 is consumed
+      if (c + NBUF - 1 < nch) issue(c + NBUF - 1);
+      // the chunk's K steps: all operands on their way before the first product (one LDS round trip per chunk, not per step)
+      const float* __restrict__ slot = ring + (c % NBUF) * BUF + lhi * ROW;  // this lane's K index: entry 2 p + lhi
+      float A0[NP], A1[NP], B0[NP], B1[NP];
+      int fl[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const float* __restrict__ row = slot + 2 * p * ROW;
+        const float w = sa[c * DCH + 2 * p + lhi];
+        A0[p] = row[256 + l31]; A1[p] = row[256 + 32 + l31];
+        B0[p] = w * row[wave * 64 + l31]; B1[p] = w * row[wave * 64 + 32 + l31];
+        fl[p] = __builtin_amdgcn_readfirstlane(sflag[c * DCH + 2 * p]);
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if (fl[p] < 0) break;  // past the last entry
+        if (fl[p] & 256) {     // a sample's first step starts from zero
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          T[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[p], B0[p], z, 0, 0, 0);
+          T[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[p], B1[p], z, 0, 0, 0);
+          T[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[p], B0[p], z, 0, 0, 0);
+          T[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[p], B1[p], z, 0, 0, 0);
+        } else {
+          T[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[p], B0[p], T[0][0], 0, 0, 0);
+          T[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[p], B1[p], T[0][1], 0, 0, 0);
+          T[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[p], B0[p], T[1][0], 0, 0, 0);
+          T[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[p], B1[p], T[1][1], 0, 0, 0);
+        }
+        if (fl[p] & 512) {  // the sample is complete: acc += q[j] T[j, i]^2
+          // accumulator register r: j = 32 jt + 8 (r >> 2) + 4 lhi + (r & 3)
+          const float* __restrict__ qs = sq + (fl[p] & 255) * 64 + 4 * lhi;
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float qv = qs[32 * jt + 8 * (r >> 2) + (r & 3)];
+#pragma unroll
+              for (int it = 0; it < 2; ++it) acc[jt][it][r] = fmaf(qv * T[jt][it][r], T[jt][it][r], acc[jt][it][r]);
+            }
+        }
+      }
+    }
+    __syncthreads();  // the next pass overwrites the entry table and the ring
+  }
+  // flush: accumulator register r of tile (jt, it) is (hidden j0 + 32 jt + 8 (r >> 2) + 4 lhi + (r & 3), column + 32 it + l31)
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int64_t i = cblk + wave * 64 + it * 32 + l31;
+      if (i > F) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t j = j0 + 32 * jt + 8 * (r >> 2) + 4 * lhi + (r & 3);
+        if (j < H) atomicAdd(i < F ? &diag_w[j * F + i] : &diag_b[j], acc[jt][it][r]);
+      }
+    }
 }
 
 // grid (i-chunks of 256, C, slabs): diag(W)[k,i] += sum_n wgt[n,k] phi[n,i]^2 ; bias with s_n.
@@ -770,12 +964,22 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
         else
           hipLaunchKernelGGL(diag_first_layer_kernel<0>, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab,
                              E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
-      } else if (has_self) {
-        hipLaunchKernelGGL((diag_first_layer_dma_kernel<1, 16, 3>), grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx,
-                           M, slab, E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
+      } else if (has_self || getenv("LGNN_DIAG_VALU") != nullptr) {
+        if (has_self)
+          hipLaunchKernelGGL((diag_first_layer_dma_kernel<1, 16, 3>), grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val,
+                             idx, M, slab, E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
+        else
+          hipLaunchKernelGGL((diag_first_layer_dma_kernel<0, 16, 4>), grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val,
+                             idx, M, slab, E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
       } else {
-        hipLaunchKernelGGL((diag_first_layer_dma_kernel<0, 16, 4>), grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx,
-                           M, slab, E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
+        // GCN: the matrix-core kernel; E = [P X | rowsum(P) | 0] is one padded matrix (context.hip build_px)
+        LGNN_REQUIRE(E.ld >= E.width + 1 && E.ld % 4 == 0, "internal: P X without its bias column");
+        const unsigned gx = unsigned(cdiv(E.width + 1, 256)), gy = unsigned(cdiv(H, 64));
+        int64_t sl = std::max<int64_t>(4, std::min<int64_t>(64, cdiv(M * gx * gy, 512)));
+        if (const char* e = getenv("LGNN_DIAG_SLAB")) sl = std::max<int64_t>(1, std::min<int64_t>(64, atoll(e)));
+        hipLaunchKernelGGL((diag_first_layer_mfma_kernel<8, 3>), dim3(gx, gy, unsigned(cdiv(M, sl))), dim3(256), 0, s,
+                           h->P.rowptr, h->P.col, h->P.val, idx, M, sl, E.base, E.ld, E.width, h->N,
+                           h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
       }
       LGNN_HIP_CHECK(hipGetLastError());
       if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += M; }
@@ -785,7 +989,10 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
   {
     FeatView Phi;
     feat_views(h, L - 1, Phi);
-    const dim3 grid{unsigned(cdiv(Phi.width + 1, 256)), unsigned(C), nslab};
+    // a thread walks its slab's samples one dependent load chain after the other (id -> feature): short slabs while
+    // there are CUs to fill (Cora shape: 16.5 us with 39-sample slabs, the outputs are only C x (width + 1) atomics each)
+    const int64_t slab_last = std::max<int64_t>(1, std::min<int64_t>(slab, cdiv(M * cdiv(Phi.width + 1, 256) * C, 4096)));
+    const dim3 grid{unsigned(cdiv(Phi.width + 1, 256)), unsigned(C), unsigned(cdiv(M, slab_last))};
     const float* wgt = nullptr;
     if (regression) {
       const int64_t Hq = L == 2 ? h->dims[1] : 0;
@@ -794,7 +1001,7 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
       LGNN_CALL(launch_fill_i32(reinterpret_cast<int32_t*>(ones), M * C, 0x3f800000, s));  // 1.0f
       wgt = ones;
     }
-    hipLaunchKernelGGL(diag_last_layer_kernel, grid, dim3(256), 0, s, h->ws.probs.as<float>(), idx, M, C, slab, Phi,
+    hipLaunchKernelGGL(diag_last_layer_kernel, grid, dim3(256), 0, s, h->ws.probs.as<float>(), idx, M, C, slab_last, Phi,
                        diag_out + off, diag_out + off + C * Phi.width, wgt);
     LGNN_HIP_CHECK(hipGetLastError());
   }

@@ -144,14 +144,7 @@ int gcn2_forward_through_px(lgnn_ctx* h, hipStream_t s) {
                                          : nullptr;
   const int64_t nlr = h->n_long_fwd > 0 ? h->n_long_fwd : 0;
   LGNN_CALL(forward_input_view(h, s));
-  if (!(fc.x_valid && fc.px_valid)) {  // graph + features only: once per binding
-    LGNN_CALL(fc.rowsum.reserve(size_t(N) * 4));
-    LGNN_CALL(launch_csr_rowsum(h->P, N, fc.rowsum.as<float>(), s));
-    const int64_t d = fc.lin_in_ld[0];
-    fc.prop_ld[0] = d;
-    LGNN_CALL(fc.prop_in[0].reserve(size_t(N) * d * 4));
-    LGNN_CALL(launch_spmm(h->P, N, fc.lin_in_p[0], d, fc.prop_in[0].as<float>(), d, d, 0, s));
-  }
+  if (!(fc.x_valid && fc.px_valid)) LGNN_CALL(build_px(h, s));  // graph + features only: once per binding
   // enough (row tile, K slice) workgroups for the chip, slices a multiple of the 4 waves' chunk stride
   const int64_t row_tiles = cdiv(N, 32);
   const int64_t stride = int64_t(4) * kChunk;

@@ -374,6 +374,7 @@ int forward_ensure(lgnn_ctx* h, hipStream_t s);
 int forward_ensure_grams(lgnn_ctx* h, hipStream_t s);
 int forward_ensure_aux(lgnn_ctx* h, hipStream_t s);
 int forward_input_view(lgnn_ctx* h, hipStream_t s);  // GCN: lin_in_p[0] / lin_in_ld[0] (X or its padded copy)
+int build_px(lgnn_ctx* h, hipStream_t s);            // rowsum(P) and (GCN) [P X | rowsum(P) | 0]: graph and X only
 int ensure_wt(lgnn_ctx* h, hipStream_t s);           // transposed weights (forward GEMM, adjacency gradient)
 // gcn2_forward.hip: small plain 2-layer GCN, forward + auxiliary products through the cached P X
 bool gcn2_small_forward_supported(const lgnn_ctx* h);

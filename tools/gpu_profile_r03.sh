@@ -7,7 +7,7 @@ case $wl in
   arxiv) kern=paths_fused_kernel; units=40 ;;
   arxiv_powerlaw) kern=paths_fused_kernel; units=40 ;;
   arxiv_sage) kern=spmm_gram256_kernel; units=40 ;;
-  cora) kern=diag_first_layer_kernel; units=1299 ;;
+  cora) kern=diag_first_layer_mfma_kernel; units=1299 ;;
   products) kern=gram_mem_kernel; units=1128 ;;
 esac
 mkdir -p $O
