@@ -700,11 +700,21 @@ __global__ void diag_last_layer_kernel(const float* __restrict__ probs, const in
   if (i > Phi.width) return;
   const int64_t m_begin = int64_t(blockIdx.z) * slab, m_end = min(M, m_begin + slab);
   float acc = 0.f;
-  for (int64_t m = m_begin; m < m_end; ++m) {
-    const float p = wgt ? 0.f : probs[m * C + k];
-    const float wt = wgt ? wgt[m * C + k] : p * (1.f - p);
-    const float ph = feat(Phi, idx[m], i);
-    acc += wt * ph * ph;
+  // four samples per step: their ids first, then the (dependent) feature loads together -- one latency chain per four samples
+  for (int64_t m = m_begin; m < m_end; m += 4) {
+    int64_t n[4];
+    float wt[4], ph[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) n[u] = m + u < m_end ? idx[m + u] : -1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t mm = min(m + u, m_end - 1);
+      const float p = wgt ? wgt[mm * C + k] : probs[mm * C + k];
+      wt[u] = wgt ? p : p * (1.f - p);
+      ph[u] = feat(Phi, n[u], i);  // id -1 (past the slab) or out of range: 0
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += wt[u] * ph[u] * ph[u];
   }
   if (i < Phi.width) atomicAdd(&diag_w[k * Phi.width + i], acc);
   else atomicAdd(&diag_b[k], acc);
@@ -989,9 +999,7 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
   {
     FeatView Phi;
     feat_views(h, L - 1, Phi);
-    // a thread walks its slab's samples one dependent load chain after the other (id -> feature): short slabs while
-    // there are CUs to fill (Cora shape: 16.5 us with 39-sample slabs, the outputs are only C x (width + 1) atomics each)
-    const int64_t slab_last = std::max<int64_t>(1, std::min<int64_t>(slab, cdiv(M * cdiv(Phi.width + 1, 256) * C, 4096)));
+    const int64_t slab_last = slab;
     const dim3 grid{unsigned(cdiv(Phi.width + 1, 256)), unsigned(C), unsigned(cdiv(M, slab_last))};
     const float* wgt = nullptr;
     if (regression) {
