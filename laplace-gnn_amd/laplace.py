@@ -606,23 +606,34 @@ class KronLaplace(ParametricLaplace):
 
     # ---- 8(f)-4: what the GNN driver differentiates (gnn/marglik_training.py:197-216) ------------------------------
     def _logdet_factor_gradients(self):
-        """``d logdet(P) / d B_l`` and ``/ d A_l`` per layer, from the eigenpairs of the fitted factors
-        (laplace/utils/matrix.py:371-394: ``sum log(f lB_i lA_j + delta)`` per weight block, ``sum log(f lB_i + delta)``
-        per bias block, f = H_factor): ``Q diag(.) Q^T`` in the factor's own eigenbasis."""
-        f = self._H_factor
-        pp = torch.as_tensor(self.prior_precision, dtype=torch.float32, device=self._device).reshape(-1)
+        """``d logdet(P) / d B_l`` and ``/ d A_l`` per layer (laplace/utils/matrix.py:371-394: ``sum log(f lB_i lA_j + delta)``
+        per weight block, ``sum log(f lB_i + delta)`` per bias block, f = H_factor): ``Q diag(.) Q^T`` in the factor's own
+        eigenbasis.  Formed in fp64 from an fp64 eigendecomposition of the fitted (fp32) factors: with the fit's fp32
+        eigenpairs these matrices are off by up to 3e-3 -- the coefficients divide by f lB_i lA_j + delta, where the small
+        eigenvalues carry all of fp32's absolute error -- and that was the adjacency gradient's whole device error (3.3e-4
+        at a GraphSAGE with 256 hidden units, 4.4e-6 with this; tools/adjgrad_attribution.py,
+        profiles/r03_adjgrad_attribution.log).  Once per gradient, on factors of a few hundred rows: not a hot path."""
+        f = float(self._H_factor)
+        pp = torch.as_tensor(self.prior_precision, dtype=torch.float64, device=self._device).reshape(-1)
         deltas = pp.expand(self.n_layers) if pp.numel() == 1 else pp
+        kf = self.H_facs.kfacs
+        eig = {}  # the bias block's factor is its weight block's B: decompose it once
+
+        def eigh64(t):
+            key = (t.data_ptr(), tuple(t.shape))
+            if key not in eig:
+                eig[key] = torch.linalg.eigh(t.double())
+            return eig[key]
+
         gB, gA = [], []
-        ev, qs = self.H.eigenvalues, self.H.eigenvectors
-        for l in range(len(ev) // 2):
-            (lB, lA), (QB, QA) = ev[2 * l], qs[2 * l]
-            (lBb,), (QBb,) = ev[2 * l + 1], qs[2 * l + 1]
+        for l in range(len(kf) // 2):
+            (lB, QB), (lA, QA), (lBb, QBb) = eigh64(kf[2 * l][0]), eigh64(kf[2 * l][1]), eigh64(kf[2 * l + 1][0])
             den = f * torch.outer(lB, lA) + deltas[2 * l]
             cB = (f * lA.unsqueeze(0) / den).sum(dim=1)
             cA = (f * lB.unsqueeze(1) / den).sum(dim=0)
             cBb = f / (f * lBb + deltas[2 * l + 1])
-            gB.append((QB * cB) @ QB.T + (QBb * cBb) @ QBb.T)
-            gA.append((QA * cA) @ QA.T)
+            gB.append(((QB * cB) @ QB.T + (QBb * cBb) @ QBb.T).float())
+            gA.append(((QA * cA) @ QA.T).float())
         return gB, gA
 
     def neg_marglik_adj_grad(self, train_loader, prior_precision=None, process_group=None, candidates=None):

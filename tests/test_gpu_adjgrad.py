@@ -2,7 +2,10 @@
 (a) the reference's ``model.adj.grad`` after ``(-log_marginal_likelihood()).backward()`` on its STEGCN / STEGraphSAGE (goldens generated
 by oracle/make_golden.py from the reference's own autograd) and (b) the CPU oracle's hand-written reverse chain on
 seeded mid-size inputs (class chunks under a small workspace cap, repeated node ids, upstream vs fork-exact seeds).
-fp32 end to end (eigendecomposition, three chained sparse products per class plane): tolerance 1e-3 relative."""
+fp32 end to end (eigendecomposition, three chained sparse products per class plane).  Measured on the device
+(tools/adjgrad_attribution.py, profiles/r03_adjgrad_attribution.log): gradient <= 1.3e-6 on the fixtures and <= 1.1e-5 at
+the mid-size shapes (most of it the fp32 eigenpairs: 4e-7 .. 2e-6 with the factor gradients formed in fp64), value <= 3e-7,
+candidate pairs <= 7e-7 -- so the tolerances are 1e-5 (fixtures) and 1e-4 (mid size; BASELINE.json north_star's bar)."""
 import glob
 import os
 
@@ -31,8 +34,8 @@ def test_adjacency_gradient_matches_reference_autograd(path):
     la.fit(loader)
     val, ei, grad = la.neg_marglik_adj_grad(loader)
     assert np.array_equal(ei[0].cpu().numpy(), g["adj_nz_row"]) and np.array_equal(ei[1].cpu().numpy(), g["adj_nz_col"])
-    assert abs(float(val) - float(g["adjgrad_neg_marglik"])) <= 2e-4 * abs(float(g["adjgrad_neg_marglik"]))
-    assert rel(grad.cpu().numpy(), g["adjgrad_vals"]) < 1e-3
+    assert abs(float(val) - float(g["adjgrad_neg_marglik"])) <= 5e-6 * abs(float(g["adjgrad_neg_marglik"]))
+    assert rel(grad.cpu().numpy(), g["adjgrad_vals"]) < 1e-5
     diag = g["adj_nz_row"] == g["adj_nz_col"]
     if str(g["kind"]) == "gcn":
         assert float(grad.cpu().numpy()[diag].__abs__().max()) == 0.0  # overwritten by fill_diagonal_(1) in the reference
@@ -44,7 +47,7 @@ def test_adjacency_gradient_matches_reference_autograd(path):
     cand = torch.from_numpy(np.stack([g["adjgrad_ne_row"], g["adjgrad_ne_col"]])).cuda()
     _, _, grad2, gc = la.neg_marglik_adj_grad(loader, candidates=cand)
     assert rel(grad2.cpu().numpy(), grad.cpu().numpy()) < 1e-5
-    assert rel(gc.cpu().numpy(), g["adjgrad_ne_val"]) < 1e-3
+    assert rel(gc.cpu().numpy(), g["adjgrad_ne_val"]) < 1e-5
     model.engine.check_async_errors()
 
 
@@ -78,14 +81,14 @@ def test_adjacency_gradient_midsize_vs_oracle(fork_exact, sym, H, C, kind):
     om = oracle_from_arrays(kind, N, ei.numpy(), X.numpy(), Ws, bs, sym)
     oval, rows, cols, og = O.kron_marglik_adj_grad(om, idx.numpy(), y.numpy(), 200, 0.5, fork_exact, sym)
     assert np.array_equal(e2[0].cpu().numpy(), rows) and np.array_equal(e2[1].cpu().numpy(), cols)
-    assert abs(float(val) - oval) <= 2e-4 * abs(oval)
-    assert rel(grad.cpu().numpy(), og) < 1e-3 and rel(grad0.cpu().numpy(), og) < 1e-3
+    assert abs(float(val) - oval) <= 5e-6 * abs(oval)
+    assert rel(grad.cpu().numpy(), og) < 1e-4 and rel(grad0.cpu().numpy(), og) < 1e-4
     # candidate pairs against the oracle's dense N x N gradient; pairs that are stored edges are not candidates
     _, gd = O.kron_marglik_adj_grad(om, idx.numpy(), y.numpy(), 200, 0.5, fork_exact, sym, dense=True)
     stored = set(zip(rows.tolist(), cols.tolist()))
     keep = np.array([(int(i), int(j)) not in stored for i, j in cand.t().tolist()])
     assert keep.sum() > 250
-    assert rel(gc.cpu().numpy()[keep], gd[cand[0].numpy()[keep], cand[1].numpy()[keep]]) < 1e-3
+    assert rel(gc.cpu().numpy()[keep], gd[cand[0].numpy()[keep], cand[1].numpy()[keep]]) < 1e-4
     model.engine.check_async_errors()
 
 

@@ -73,12 +73,13 @@ def test_kron_laplace_fit(path):
     for i, ls in enumerate(la.H.eigenvalues):
         for j, lam in enumerate(ls):
             ref = g[f"kron_eig_{i}_{j}"]
-            assert np.abs(lam.cpu().numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30), (i, j)
+            # (measured over all fixtures, tools/tolerance_survey.py: <= 8.2e-7 of the largest eigenvalue; marglik <= 3.7e-7)
+            assert np.abs(lam.cpu().numpy() - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-30), (i, j)
     # "next" row 8(f)-1: marginal likelihood on the device from the decomposed factors (eigh + logdet)
     for pp, key in ((None, "kron_marglik_pp1"), (torch.tensor(0.7), "kron_marglik_pp07"),
                     (torch.from_numpy(g["kron_prior_layerwise"]), "kron_marglik_layerwise")):
         got = float(la.log_marginal_likelihood(prior_precision=pp))
-        assert abs(got - float(g[key])) <= 2e-4 * abs(float(g[key])), key
+        assert abs(got - float(g[key])) <= 5e-6 * abs(float(g[key])), key
     la.prior_precision = 1.0
     # torch.utils.data.DataLoader (the reference's loader) gives the same batches
     from torch.utils.data import DataLoader, TensorDataset
@@ -106,7 +107,7 @@ def test_diag_laplace_fit(path):
     assert la.mean.shape[0] == int(g["n_params"])
     for pp, key in ((None, "diag_marglik_pp1"), (torch.tensor(0.7), "diag_marglik_pp07")):
         got = float(la.log_marginal_likelihood(prior_precision=pp))
-        assert abs(got - float(g[key])) <= 2e-4 * abs(float(g[key])), key
+        assert abs(got - float(g[key])) <= 5e-6 * abs(float(g[key])), key
 
 
 @pytest.mark.parametrize("path", CASES, ids=IDS)
@@ -125,7 +126,7 @@ def test_posterior_samples_and_sampling_predictive(path):
     for structure in ("kron", "diag"):
         la = lg.Laplace(model, "classification", "all", structure)
         la.fit(loader)
-        assert rel(la.sample(eps=eps).cpu().numpy(), g[structure + "_samples"]) < 5e-4
+        assert rel(la.sample(eps=eps).cpu().numpy(), g[structure + "_samples"]) < 5e-5
         py = la(idx, pred_type="nn", link_approx="mc", n_samples=len(eps), eps=eps)
         assert np.abs(py.cpu().numpy() - g[structure + "_nn_py"]).max() < 5e-5
         # mean restored, engine follows it back
@@ -165,18 +166,18 @@ def test_jacobians_and_glm_predictive(path):
         la.fit(loader)
         f_mu, f_var = la._glm_predictive_distribution(idx)
         assert rel(f_mu.cpu().numpy(), g[structure + "_glm_fmu"]) < RTOL
-        assert rel(f_var.cpu().numpy(), g[structure + "_glm_fvar"]) < 5e-4
+        assert rel(f_var.cpu().numpy(), g[structure + "_glm_fvar"]) < 5e-5
         assert np.abs(la(idx).cpu().numpy() - g[structure + "_glm_probit"]).max() < 5e-5
         for link in ("bridge", "bridge_norm"):
             got = la(idx, pred_type="glm", link_approx=link).cpu().numpy()
-            assert np.abs(got - g[f"{structure}_glm_{link}"]).max() < 2e-4, link
+            assert np.abs(got - g[f"{structure}_glm_{link}"]).max() < 2e-5, link
         mc = la(idx, pred_type="glm", link_approx="mc", n_samples=6, eps=torch.from_numpy(g["glm_eps"]).cuda())
-        assert np.abs(mc.cpu().numpy() - g[structure + "_glm_mc"]).max() < 2e-4
+        assert np.abs(mc.cpu().numpy() - g[structure + "_glm_mc"]).max() < 2e-5
         if structure == "kron":  # post-hoc prior tuning on the marginal likelihood (reference's Adam loop, 25 steps)
             la.optimize_prior_precision(method="marglik", n_steps=25, lr=0.1, prior_structure="scalar")
-            assert rel(la.prior_precision.cpu().numpy(), g["kron_opt_pp_scalar"]) < 2e-3
+            assert rel(la.prior_precision.cpu().numpy(), g["kron_opt_pp_scalar"]) < 2e-4
             la.optimize_prior_precision(method="marglik", n_steps=25, lr=0.1, prior_structure="layerwise")
-            assert rel(la.prior_precision.cpu().numpy(), g["kron_opt_pp_layerwise"]) < 2e-3
+            assert rel(la.prior_precision.cpu().numpy(), g["kron_opt_pp_layerwise"]) < 2e-4
     model.engine.check_async_errors()
 
 
@@ -199,9 +200,9 @@ def test_full_laplace_all_weights(name):
         assert abs(got - float(g[key])) <= 3e-4 * abs(float(g[key])), key
     la.prior_precision = 1.0
     eps, idx = torch.from_numpy(g["pred_eps"]).cuda(), torch.from_numpy(g["pred_idx"]).cuda()
-    assert rel(la.sample(eps=eps).cpu().numpy(), g["fullla_samples"]) < 1e-3
+    assert rel(la.sample(eps=eps).cpu().numpy(), g["fullla_samples"]) < 1e-4
     _, f_var = la._glm_predictive_distribution(idx)
-    assert rel(f_var.cpu().numpy(), g["fullla_glm_fvar"]) < 1e-3
+    assert rel(f_var.cpu().numpy(), g["fullla_glm_fvar"]) < 1e-4
     assert np.abs(la(idx).cpu().numpy() - g["fullla_glm_probit"]).max() < 1e-4
     la3 = lg.FullLaplace(model, "classification")
     la3.fit(lg.TensorBatchLoader(idx_all, y_all, batch_size=max(1, len(idx_all) // 3 + 1)))
@@ -227,7 +228,7 @@ def test_regression_likelihood(name):
     assert abs(float(la.loss) - float(g["reg_kron_loss"])) < RTOL * float(g["reg_kron_loss"])
     assert abs(float(la.log_marginal_likelihood()) - float(g["reg_kron_marglik"])) < 3e-4 * abs(float(g["reg_kron_marglik"]))
     f_mu, f_var = la(torch.from_numpy(g["pred_idx"]).cuda(), pred_type="glm")
-    assert rel(f_mu.cpu().numpy(), g["reg_kron_glm_fmu"]) < RTOL and rel(f_var.cpu().numpy(), g["reg_kron_glm_fvar"]) < 5e-4
+    assert rel(f_mu.cpu().numpy(), g["reg_kron_glm_fmu"]) < RTOL and rel(f_var.cpu().numpy(), g["reg_kron_glm_fvar"]) < 5e-5
     # unfused kernels and a three-batch fit give the same factors
     be = lg.HipGGN(model, "regression")
     _, views, loss = be.engine.new_kfac_buffers()
@@ -478,8 +479,8 @@ def test_matrix_free_glm_variance_matches_the_jacobian_route_and_the_reference(n
         la.prior_precision = 1.0
         f_mu, f_vd = la._glm_variance_matrix_free(x)
         gold = np.diagonal(g[key + "_glm_fvar"], axis1=1, axis2=2)
-        assert rel(f_vd.cpu().numpy(), gold) < 1e-3, key
-        assert rel(la(x, link_approx="probit").cpu().numpy(), g[key + "_glm_probit"]) < 1e-3
+        assert rel(f_vd.cpu().numpy(), gold) < 1e-4, key
+        assert rel(la(x, link_approx="probit").cpu().numpy(), g[key + "_glm_probit"]) < 1e-4
     model.engine.check_async_errors()
 
 
