@@ -673,7 +673,8 @@ KfacPlan plan_kfac(int kind, int L, int64_t N, int64_t nnz, const int64_t* dims,
                    fused_supported(d_top, 2 * d_top, (N + 1) * 2 * d_top, nullptr, N + 1) && hact_ld(L - 2) % 4 == 0;
   const bool row_active = gcn && !no_fuse && nnz > 0;  // flags of the non-zero top-layer gradient rows exist
   p.need_pong = L > 2 || no_fuse;
-  p.paths = !no_fuse && !no_paths && p.seeds_on_the_fly && paths_supported(kind, L, dims, act, nnz);
+  p.paths = !no_fuse && !no_paths && (gcn ? p.seeds_on_the_fly : true) && paths_supported(kind, L, dims, act, nnz);
+  if (p.paths) p.sage_compact = false;  // (GraphSAGE: one-hop paths instead of the compact top level + fused LIST kernel)
   for (int l = L - 1; l >= 1; --l) {
     const int64_t d = dims[l], dout = dims[l + 1];
     const bool top = l == L - 1;
@@ -796,7 +797,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   // the two-hop path route (paths.hip) where the shape allows it and the batch's expected number of paths makes it pay
   bool no_paths = (flags & LGNN_FLAG_NO_PATHS) != 0 || fisher != nullptr || no_fuse ||
                   !paths_supported(h->kind, L, h->dims, h->act, h->nnz);
-  if (!no_paths) {
+  if (!no_paths && h->kind == LGNN_KIND_GCN) {  // (GraphSAGE's paths are one hop: at most nnz + (C + 1) M of them, always cheaper)
     LGNN_CALL(two_hop_ensure(h, s));
     no_paths = !paths_pay(h, M) && (flags & LGNN_FLAG_FORCE_PATHS) == 0;
   }
@@ -827,7 +828,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
 
   // ---- top layer ---------------------------------------------------------------------------------
   float* gtop = nullptr;  // planes [C][N][C]
-  if (h->kind == LGNN_KIND_GCN || L > 1) {
+  if ((h->kind == LGNN_KIND_GCN || L > 1) && !(h->kind == LGNN_KIND_SAGE && plan.paths && !fisher)) {
     LGNN_CALL(h->ws.top.reserve(size_t(N) * CC * 4 + 16));  // + 16: the backward GEMM reads rows shifted by one float
     gtop = h->ws.top.as<float>();
   }
@@ -874,7 +875,7 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   } else {
     // rows (m, c) of the accumulated seeds; rows of non-first duplicates are zero
     if (first) LGNN_CALL(launch_gram(h->ws.seeds.as<float>(), C, M * C, C, h->ws.gram_scratch[L - 1].as<float>(), s));
-    if (L > 1) {
+    if (L > 1 && !(plan.paths && !fisher)) {  // (the path route reads the samples' probabilities, not seed planes)
       // the compact top level reads the planes at the batch nodes only; every other path reads all rows
       if (!sage_compact) LGNN_HIP_CHECK(hipMemsetAsync(gtop + cb * N * C, 0, size_t(N) * (ce - cb) * C * 4, s));
       hipLaunchKernelGGL(scatter_seed_planes_kernel, dim3(unsigned(M)), dim3(256), 0, s, idx, M, N, C,
@@ -884,11 +885,13 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   }
 
   // ---- 2-layer GCN: B_0 from the batch's 2-hop paths -- no class planes (paths.hip) -------------------------
-  const bool paths_route = plan.paths && !fisher && seeds_on_the_fly;
+  const bool paths_route = plan.paths && !fisher && (h->kind == LGNN_KIND_GCN ? seeds_on_the_fly : true);
   h->last_route_paths = paths_route;
-  if (paths_route)
-    LGNN_CALL(kfac_paths_first_layer(h, idx, M, h->lik == LGNN_LIK_REGRESSION ? 2 : (fork_exact ? 1 : 0), cb, ce,
-                                     h->ws.gram_scratch[0].as<float>(), s));
+  if (paths_route) {
+    const int mode = h->lik == LGNN_LIK_REGRESSION ? 2 : (fork_exact ? 1 : 0);
+    if (h->kind == LGNN_KIND_GCN) LGNN_CALL(kfac_paths_first_layer(h, idx, M, mode, cb, ce, h->ws.gram_scratch[0].as<float>(), s));
+    else LGNN_CALL(kfac_paths_first_layer_sage(h, idx, M, mode, cb, ce, h->ws.gram_scratch[0].as<float>(), s));
+  }
 
   // ---- lower layers, chunked over classes ----------------------------------------------------------
   if (L > 1 && !paths_route) {

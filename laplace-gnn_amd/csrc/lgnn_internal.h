@@ -365,6 +365,8 @@ bool paths_pay(const lgnn_ctx* h, int64_t M);     // expected paths per destinat
 // scratch [H, H] += B_0 of this batch's class columns [cb, ce) (seed_mode: 0 upstream, 1 fork exact, 2 regression)
 int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce, float* scratch,
                            hipStream_t s);
+int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce,
+                                float* scratch, hipStream_t s);  // GraphSAGE: one-hop paths through the same fused kernel
 // scratch [width, width] (upper 32 x 32 sub-tiles) += Y^T Y for rows of `width` floats (row stride ld), 128 < width <= 256:
 // all eight waves of a persistent workgroup per CU on the matrix pipes, row blocks by LDS-DMA (paths.hip)
 int launch_gram256_stream(const float* Y, int64_t ld, int64_t rows, int64_t width, float* scratch, hipStream_t s,

@@ -170,7 +170,8 @@ struct YArgs {
   const float* bg;          // [2 M][H]: rows b_m, then rows g_m
   const uint32_t* mask;     // [N][mask_words] ReLU bits of h_1
   int mask_words;
-  const float* W1;          // [C][H]
+  const float* W1;          // [C][w1_ld]: the H columns Y is multiplied with (GraphSAGE: the neighbour half of W_1)
+  int w1_ld;
   float* Y;                 // [N][R][H]
   int64_t N, M;
   int H, c0, R;
@@ -366,7 +367,7 @@ __device__ __forceinline__ void y_load_w1(const YArgs& a, const YRole& ro, bool 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = 4 * ro.half + (r & 3) + 8 * (r >> 2);
-        g.w1r[ct][r] = (path_wave && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * H + colc] : 0.f;
+        g.w1r[ct][r] = (path_wave && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * a.w1_ld + colc] : 0.f;
       }
     }
   } else {
@@ -376,7 +377,7 @@ __device__ __forceinline__ void y_load_w1(const YArgs& a, const YRole& ro, bool 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 32 + 4 * (ro.lane >> 4) + r;
-        g.w1r[ct][r] = (path_wave && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * H + colc] : 0.f;
+        g.w1r[ct][r] = (path_wave && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * a.w1_ld + colc] : 0.f;
       }
     }
   }
@@ -640,12 +641,14 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
     const int kwnn = min(kWin, p1nn - p0nn);
     pp.trm = 0; pp.trv = 0; pp.trw = 0.f;
     if (tid < kwnn) { pp.trm = a.pm[p0nn + tid]; pp.trv = a.pv[p0nn + tid]; pp.trw = a.pw[p0nn + tid]; }
-    // ---- (1) + (2): the path products of node i, Y[n] into the LDS tile
-    y_node_products<RT1>(a, sh.win, sh.meta, sh.y, ro, path_wave, g, b, ms, pp.kwc, pp.p0c, pp.p1c);
+    // ---- (1) + (2): the path products of node i, Y[n] into the LDS tile.  A node without paths (GraphSAGE: neither in the
+    // batch nor next to it; a short last batch) has Y[n] = 0: no products, no Gram, only its share of the pipeline
+    const bool has_paths = pp.p1c > pp.p0c;  // (workgroup uniform)
+    if (has_paths) y_node_products<RT1>(a, sh.win, sh.meta, sh.y, ro, path_wave, g, b, ms, pp.kwc, pp.p0c, pp.p1c);
     if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = pp.mwn;  // (readers of that buffer passed this node's barrier)
     lds_barrier();  // raw: a __syncthreads() here would drain the copies in flight for node i + 1
     // ---- (3) S += Y[n]^T Y[n], rows two at a time (operands of step k + 1 read before the MFMAs of step k)
-    {
+    if (has_paths) {
       const float* __restrict__ base = &sh.y[0][0] + (lane >> 5) * 256 + (lane & 31);
       const int nk = r2 >> 1;
       float xa[8], xb[8];
@@ -797,6 +800,91 @@ __global__ __launch_bounds__(512, 2) void gram256_stream_kernel(GramStreamArgs a
 }  // namespace
 
 namespace {
+
+// ---- GraphSAGE: the same fused kernel over ONE-hop paths ----------------------------------------------------------------
+// cat_1 = [h_1 | P h_1], out = cat_1 W_1^T + b_1 (gnn/models/layers.py:26-29), so the first-layer gradient rows of node n are
+//     G_c[n] = mask_n (.) ( S_c[n] W_1s + sum_m P[m, n] S_c[m] W_1n ),   S_c[m] = V_m[:, c]^T (the sample's seed column),
+// W_1 = [W_1s | W_1n].  With V = diag(alpha) - u beta^T - p gamma^T this is the path sum of the GCN route with the mask at
+// the DESTINATION (every path of n names n as its mask row), the neighbour half W_1n as the kernel's W_1 operand, and the
+// self terms as pseudo paths:
+//   sample index 2 m + 1 : neighbour path m -> n, weight P[m, n] mult_m, coefficients (alpha, -beta, -gamma)_m, rows u_m^T W_1n, p_m^T W_1n
+//   sample index 2 m     : n's own beta / gamma terms: coefficients (0, -beta, -gamma)_m, rows u_m^T W_1s, p_m^T W_1s
+//   sample index 2 M + c': n's own alpha term alpha_{m,c'} W_1s[c', :] as a "beta" product with a one-hot coefficient row
+//                          (+1 at class c'), table row W_1s[c', :] and path weight mult_m alpha_{m,c'}
+// (u^T [W_1s | W_1n] is one GEMM whose [M][2H] output IS the [2M][H] table in that order).  paths_fused_kernel runs unchanged.
+__global__ __launch_bounds__(256) void sage_path_tables_kernel(const float* __restrict__ probs, const float* __restrict__ logits,
+                                                               const int64_t* __restrict__ idx, const int32_t* __restrict__ pos,
+                                                               int64_t M, int64_t N, int C, int mode, float* __restrict__ coef,
+                                                               float* __restrict__ up) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (m >= M + C) return;
+  if (m >= M) {  // the one-hot rows
+    float* __restrict__ cm = coef + (2 * M + (m - M)) * kCoefRow;
+    cm[lane] = 0.f; cm[kCoefStride + lane] = lane == int(m - M) ? 1.f : 0.f; cm[2 * kCoefStride + lane] = 0.f; cm[3 * kCoefStride + lane] = 0.f;
+    return;
+  }
+  const int64_t n = idx[m];
+  const bool own = n >= 0 && n < N && pos[n] == int32_t(m);
+  float pk = 0.f, fk = 0.f;
+  if (own && lane < C && mode != 2) { pk = probs[m * C + lane]; fk = logits[n * C + lane]; }
+  const float mb = wsum(pk * fk);  // same summation order as seed_kernel
+  const float sp = sqrtf(pk), t = fk - mb;
+  float al = 0.f, be = 0.f, ga = 0.f, u = 0.f;
+  if (own && lane < C) {
+    if (mode == 2) al = 1.41421356237309515f;
+    else if (mode == 1) { al = sp * (1.f + 0.5f * t); be = sp; ga = 0.5f * sp * t; u = pk * (1.f + t); }
+    else { al = sp; be = sp; u = pk; }
+  }
+  float* __restrict__ cs = coef + (2 * m) * kCoefRow;      // the node's own beta / gamma terms
+  float* __restrict__ cn = coef + (2 * m + 1) * kCoefRow;  // a neighbour path from sample m
+  cs[lane] = 0.f; cs[kCoefStride + lane] = -be; cs[2 * kCoefStride + lane] = -ga; cs[3 * kCoefStride + lane] = 0.f;
+  cn[lane] = al;  cn[kCoefStride + lane] = -be; cn[2 * kCoefStride + lane] = -ga; cn[3 * kCoefStride + lane] = 0.f;
+  if (lane < C) { up[m * C + lane] = u; up[(M + m) * C + lane] = own ? pk : 0.f; }
+}
+
+// One wave per node n: its paths (see above).  Row n of P^T lists the samples' nodes v with P[v, n] != 0.
+template <bool FILL>
+__global__ __launch_bounds__(256) void sage_path_list_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                             const float* __restrict__ val, int64_t N, int64_t M, int C,
+                                                             const int32_t* __restrict__ pos, const int32_t* __restrict__ mult,
+                                                             const float* __restrict__ coef, int32_t* __restrict__ pcnt,
+                                                             const int32_t* __restrict__ pptr, int32_t* __restrict__ pm,
+                                                             int32_t* __restrict__ pv, float* __restrict__ pw) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int32_t s = rowptr[n], e = rowptr[n + 1];
+  int32_t run = FILL ? pptr[n] : 0;
+  for (int32_t base = s; base < e; base += 64) {
+    int32_t mv = INT32_MAX;
+    float w = 0.f;
+    if (base + lane < e) { mv = pos[col[base + lane]]; w = val[base + lane]; }
+    const bool in = mv != INT32_MAX;
+    const uint64_t bal = __ballot(in);
+    if constexpr (FILL) {
+      if (in) {
+        const int32_t o = run + __popcll(bal & ((uint64_t(1) << lane) - 1));
+        pm[o] = 2 * mv + 1; pv[o] = int32_t(n); pw[o] = w * float(mult[mv]);
+      }
+    }
+    run += __popcll(bal);
+  }
+  const int32_t ms = pos[n];
+  if (ms != INT32_MAX) {  // n is a batch node: its own beta / gamma path and the C one-hot alpha paths
+    if constexpr (FILL) {
+      const float tm = float(mult[ms]);
+      if (lane == 0) { pm[run] = 2 * ms; pv[run] = int32_t(n); pw[run] = tm; }
+      if (lane < C) {
+        pm[run + 1 + lane] = int32_t(2 * M) + lane; pv[run + 1 + lane] = int32_t(n);
+        pw[run + 1 + lane] = tm * coef[(2 * int64_t(ms) + 1) * kCoefRow + lane];
+      }
+    }
+    run += 1 + C;
+  }
+  if (!FILL && lane == 0) pcnt[n] = run;
+}
+
 // S2 = sum_v (entries of row v of P) * (entries of row v of P^T): the number of 2-hop paths n <- v <- m of the whole graph
 __global__ void two_hop_count_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ rpt, int64_t N,
                                      unsigned long long* __restrict__ out) {
@@ -841,8 +929,8 @@ bool paths_pay(const lgnn_ctx* h, int64_t M) {
 
 bool paths_supported(int kind, int L, const int64_t* dims, int act, int64_t nnz) {
   const int64_t C = dims[L], H = L >= 2 ? dims[L - 1] : 0;
-  return kind == LGNN_KIND_GCN && L == 2 && act == LGNN_ACT_RELU && nnz > 0 && C <= kCoefStride && H > 128 && H <= 256 &&
-         H % 4 == 0;
+  return (kind == LGNN_KIND_GCN || kind == LGNN_KIND_SAGE) && L == 2 && act == LGNN_ACT_RELU && nnz > 0 && C <= kCoefStride &&
+         H > 128 && H <= 256 && H % 4 == 0;
 }
 
 int launch_gram256_stream(const float* Y, int64_t ld, int64_t rows, int64_t width, float* scratch, hipStream_t s,
@@ -935,7 +1023,7 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.pw = ws.path_pw.as<float>(); y.cap = cap;
     y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>(); y.zeros = ws.path_zeros.as<float>();
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
-    y.W1 = h->W[1]; y.Y = nullptr; y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
+    y.W1 = h->W[1]; y.w1_ld = int(H); y.Y = nullptr; y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel(s) of the KFAC path (bench.py roofline)
     hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y, scratch);
@@ -957,12 +1045,80 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.pptr = ws.path_pptr.as<int32_t>(); y.cap = cap;
     y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>(); y.zeros = ws.path_zeros.as<float>();
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
-    y.W1 = h->W[1]; y.Y = ws.planes_a.as<float>(); y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
+    y.W1 = h->W[1]; y.w1_ld = int(H); y.Y = ws.planes_a.as<float>(); y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
     const unsigned threads = unsigned(64 * cdiv(H, 64) * cdiv(R, 32));  // (column groups) x (32-class row tiles) waves
     hipLaunchKernelGGL(ybuild_kernel, dim3(unsigned(std::min<int64_t>(N, 1024))), dim3(threads), 0, s, y);
     LGNN_HIP_CHECK(hipGetLastError());
     LGNN_CALL(launch_gram256_stream(y.Y, H, N * R, H, scratch, s, ws.path_pptr.as<int32_t>() + N, cap));
+  }
+  return 0;
+}
+
+// GraphSAGE: B_0 scratch += the class columns [cb, ce) of this batch from the one-hop paths (see sage_path_tables_kernel).
+// Needs batch_prologue's probabilities / multiplicities / positions and the cached forward (logits, mask bits).
+int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce, float* scratch,
+                                hipStream_t s) {
+  const int64_t N = h->N, C = h->dims[2], H = h->dims[1];
+  Workspace& ws = h->ws;
+  LGNN_REQUIRE(h->kind == LGNN_KIND_SAGE && paths_supported(h->kind, h->L, h->dims, h->act, h->nnz),
+               "internal: path route on an unsupported model");
+  const int64_t T = 2 * M + C;  // sample indices: 2 m (own beta / gamma), 2 m + 1 (neighbour path), 2 M + c' (one-hot alpha)
+  LGNN_CALL(ws.path_coef.reserve(size_t(T) * kCoefRow * 4));
+  LGNN_CALL(ws.path_up.reserve(size_t(2 * M) * C * 4));
+  LGNN_CALL(ws.path_bg.reserve(size_t(2 * T) * H * 4));
+  hipLaunchKernelGGL(sage_path_tables_kernel, dim3(unsigned(cdiv(M + C, 4))), dim3(256), 0, s, ws.probs.as<float>(),
+                     h->fc.out.as<float>(), idx, ws.pos.as<int32_t>(), M, N, int(C), seed_mode, ws.path_coef.as<float>(),
+                     ws.path_up.as<float>());
+  LGNN_HIP_CHECK(hipGetLastError());
+  // b rows [0, T): u^T [W_1s | W_1n] as rows (2 m, 2 m + 1), then W_1s[c', :]; g rows [T, 2 T): p^T [W_1s | W_1n], then zeros
+  float* bg = ws.path_bg.as<float>();
+  GemmEpilogue none;
+  LGNN_CALL(launch_gemm(ws.path_up.as<float>(), C, h->W[1], 2 * H, bg, 2 * H, M, C, 2 * H, none, s));
+  LGNN_CALL(launch_gemm(ws.path_up.as<float>() + M * C, C, h->W[1], 2 * H, bg + T * H, 2 * H, M, C, 2 * H, none, s));
+  LGNN_HIP_CHECK(hipMemcpy2DAsync(bg + 2 * M * H, size_t(H) * 4, h->W[1], size_t(2 * H) * 4, size_t(H) * 4, size_t(C),
+                                  hipMemcpyDeviceToDevice, s));
+  LGNN_HIP_CHECK(hipMemsetAsync(bg + (T + 2 * M) * H, 0, size_t(C) * H * 4, s));
+  LGNN_CALL(ws.path_zeros.reserve(1024));
+  if (!ws.path_zeros_set) {
+    LGNN_HIP_CHECK(hipMemsetAsync(ws.path_zeros.p, 0, 1024, s));
+    ws.path_zeros_set = true;
+  }
+  // ---- the paths of every node: count (one wave per node), scan, fill.  At most nnz + (C + 1) M of them: the list always fits
+  const int64_t cap = std::max<int64_t>(h->nnz, 1) + (C + 1) * M + 64;
+  LGNN_REQUIRE(cap < (int64_t(1) << 31), "too many paths for one launch");
+  LGNN_CALL(ws.path_pcnt.reserve(size_t(N + 1) * 4));
+  LGNN_CALL(ws.path_pptr.reserve(size_t(N + 1) * 4));
+  LGNN_CALL(ws.path_pm.reserve(size_t(cap) * 4));
+  LGNN_CALL(ws.path_pv.reserve(size_t(cap) * 4));
+  LGNN_CALL(ws.path_pw.reserve(size_t(cap) * 4));
+  LGNN_HIP_CHECK(hipMemsetAsync(ws.path_pcnt.as<int32_t>() + N, 0, 4, s));
+  const dim3 pgrid{unsigned(cdiv(N, 4))};
+  hipLaunchKernelGGL(sage_path_list_kernel<false>, pgrid, dim3(256), 0, s, h->PT.rowptr, h->PT.col, h->PT.val, N, M, int(C),
+                     ws.pos.as<int32_t>(), ws.mult.as<int32_t>(), ws.path_coef.as<float>(), ws.path_pcnt.as<int32_t>(),
+                     static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
+                     static_cast<float*>(nullptr));
+  LGNN_CALL(exclusive_scan_i32(ws.path_pcnt.as<int32_t>(), ws.path_pptr.as<int32_t>(), N + 1, ws.select_tmp, s));
+  hipLaunchKernelGGL(sage_path_list_kernel<true>, pgrid, dim3(256), 0, s, h->PT.rowptr, h->PT.col, h->PT.val, N, M, int(C),
+                     ws.pos.as<int32_t>(), ws.mult.as<int32_t>(), ws.path_coef.as<float>(), ws.path_pcnt.as<int32_t>(),
+                     ws.path_pptr.as<int32_t>(), ws.path_pm.as<int32_t>(), ws.path_pv.as<int32_t>(), ws.path_pw.as<float>());
+  LGNN_HIP_CHECK(hipGetLastError());
+  LGNN_REQUIRE(N < (int64_t(1) << 31), "too many nodes for one launch");
+  for (int64_t c0 = cb; c0 < ce; c0 += kYRows) {
+    const int64_t R = std::min<int64_t>(kYRows, ce - c0);
+    YArgs y{};
+    y.rowptr = h->PT.rowptr; y.col = h->PT.col; y.val = h->PT.val;
+    y.pptr = ws.path_pptr.as<int32_t>(); y.pm = ws.path_pm.as<int32_t>(); y.pv = ws.path_pv.as<int32_t>();
+    y.pw = ws.path_pw.as<float>(); y.cap = cap;
+    y.coef = ws.path_coef.as<float>(); y.bg = bg; y.zeros = ws.path_zeros.as<float>();
+    y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
+    y.W1 = h->W[1] + H; y.w1_ld = int(2 * H);  // the neighbour half: the alpha term of the neighbour paths
+    y.Y = nullptr; y.N = N; y.M = T; y.H = int(H); y.c0 = int(c0); y.R = int(R);
+    y.no_bg = 0;  // (the one-hot alpha paths go through the beta product: never skipped)
+    if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the KFAC path (bench.py roofline)
+    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y, scratch);
+    LGNN_HIP_CHECK(hipGetLastError());
+    if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }
   return 0;
 }

@@ -390,14 +390,15 @@ def test_rebinding_a_graphsage_context_to_other_widths():
         Ws = [torch.randn(dims[l + 1], 2 * dims[l], generator=g) / (2 * dims[l]) ** 0.5 for l in range(2)]
         bs = [torch.randn(dims[l + 1], generator=g) * 0.1 for l in range(2)]
         eng.bind(X.cuda(), [w.cuda() for w in Ws], [b.cuda() for b in bs])
-        assert eng.kfac_plan()["sage_compact"]
-        _, views, loss = eng.new_kfac_buffers()
-        for s in (0, 120):
-            eng.kfac_accumulate(idx[s:s + 120].cuda(), y[s:s + 120].cuda(), 200, views, loss)
-        torch.cuda.synchronize()
+        assert eng.kfac_plan(paths=False)["sage_compact"]
         om = oracle_from_arrays("sage", N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], True)
         _, oH = O.fit_kron(om, idx.numpy(), y.numpy(), 120)
-        for l, (A, B) in enumerate(views):
-            assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL, (H, "B", l)
-            assert rel(A.cpu().numpy(), oH[2 * l][1]) < RTOL, (H, "A", l)
+        for paths in (False, None):  # the compact class-plane route this test is about, then the default (H > 128: one-hop paths)
+            _, views, loss = eng.new_kfac_buffers()
+            for s in (0, 120):
+                eng.kfac_accumulate(idx[s:s + 120].cuda(), y[s:s + 120].cuda(), 200, views, loss, paths=paths)
+            torch.cuda.synchronize()
+            for l, (A, B) in enumerate(views):
+                assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL, (H, "B", l, paths)
+                assert rel(A.cpu().numpy(), oH[2 * l][1]) < RTOL, (H, "A", l, paths)
     eng.close()

@@ -158,3 +158,75 @@ def test_path_list_overflow_takes_the_enumerating_route(H, C, monkeypatch):
     eng.check_async_errors()
     eng.close()
 
+
+
+@pytest.mark.parametrize("H,C,skew,fork_exact,sym", [
+    (256, 40, False, True, True), (256, 40, True, True, False), (192, 7, False, True, True), (132, 33, True, False, True),
+    (256, 64, False, True, False), (160, 10, True, False, False)])
+def test_graphsage_one_hop_path_route_vs_oracle_and_plane_route(H, C, skew, fork_exact, sym):
+    """GraphSAGE: the same fused kernel over one-hop paths -- mask at the destination, the neighbour half
+    of W_1 as the kernel's operand, the node's own terms as pseudo paths (one-hot coefficient rows for its alpha term)."""
+    import laplace_gnn_amd as lg
+
+    N, F, E = 3000, 48, 12000
+    ei, X, Ws, bs = _make("sage", N, F, H, C, E, L=2, seed=H + C, skew=skew)
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randperm(N, generator=g)[:700]
+    idx[7] = idx[11]
+    idx[650:] = idx[100:150]  # node ids listed twice accumulate (x[x_indices] backward)
+    y = torch.randint(0, C, (700,), generator=g)
+    eng = lg.GraphEngine(ei.cuda(), N, kind="sage", symmetric=sym)
+    eng.bind(X.cuda(), [w.cuda() for w in Ws], [b.cuda() for b in bs])
+    assert eng.kfac_plan()["paths"] and not eng.kfac_plan(paths=False)["paths"]
+    flat, views, loss = eng.new_kfac_buffers()
+    flat2, views2, loss2 = eng.new_kfac_buffers()
+    for s in range(0, 700, 300):  # 300 / 300 / 100
+        eng.kfac_accumulate(idx[s:s + 300].cuda(), y[s:s + 300].cuda(), 700, views, loss, fork_exact=fork_exact)
+        assert eng.last_kfac_used_paths
+        eng.kfac_accumulate(idx[s:s + 300].cuda(), y[s:s + 300].cuda(), 700, views2, loss2, fork_exact=fork_exact, paths=False)
+        assert not eng.last_kfac_used_paths
+    torch.cuda.synchronize()
+    om = oracle_from_arrays("sage", N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], sym)
+    oloss, oH = O.fit_kron(om, idx.numpy(), y.numpy(), 300, fork_exact)
+    for l, (A, B) in enumerate(views):
+        assert rel(B.cpu().numpy(), oH[2 * l][0]) < RTOL, f"B_{l} vs oracle"
+        assert rel(B.cpu().numpy(), views2[l][1].cpu().numpy()) < 2e-5, f"B_{l} vs the plane route"
+        assert rel(A.cpu().numpy(), oH[2 * l][1]) < RTOL, f"A_{l} vs oracle"
+        assert torch.equal(B, B.T)
+    assert abs(float(loss) - float(oloss)) <= RTOL * abs(float(oloss))
+    # class ranges (the multi-GPU units) are exact shares on this route too
+    flat3, v3, l3 = eng.new_kfac_buffers()
+    cuts = [0, 1, min(20, C - 1), C] if C > 2 else [0, C]
+    for s in range(0, 700, 300):
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b > a:
+                eng.kfac_accumulate(idx[s:s + 300].cuda(), y[s:s + 300].cuda(), 700, v3, l3, classes=(a, b), fork_exact=fork_exact)
+    torch.cuda.synchronize()
+    assert rel(flat3.cpu().numpy(), flat.cpu().numpy()) < 1e-5
+    eng.check_async_errors()
+    eng.close()
+
+
+def test_graphsage_path_route_regression_and_isolated_nodes():
+    """Regression likelihood (V = sqrt(2) I: the one-hot alpha paths carry everything) and nodes without neighbours (their
+    own terms only; rows without neighbours keep mean_agg's divisor 1)."""
+    import laplace_gnn_amd as lg
+
+    N, F, H, C, E = 1500, 16, 256, 3, 900  # sparse: many isolated nodes, most nodes far from the 60 batch nodes
+    ei, X, Ws, bs = _make("sage", N, F, H, C, E, L=2, seed=9)
+    g = torch.Generator().manual_seed(2)
+    idx = torch.randperm(N, generator=g)[:60]
+    yr = torch.randn(60, C, generator=g)
+    eng = lg.GraphEngine(ei.cuda(), N, kind="sage", symmetric=True)
+    eng.bind(X.cuda(), [w.cuda() for w in Ws], [b.cuda() for b in bs], likelihood="regression")
+    om = oracle_from_arrays("sage", N, ei.numpy(), X.numpy(), [w.numpy() for w in Ws], [b.numpy() for b in bs], True)
+    for paths in (None, False):
+        _, views, loss = eng.new_kfac_buffers()
+        eng.kfac_accumulate(idx.cuda(), yr.cuda(), 60, views, loss, paths=paths)
+        assert eng.last_kfac_used_paths == (paths is None)
+        torch.cuda.synchronize()
+        ol, okf = O.kfac_batch(om, idx.numpy(), yr.numpy(), 60, likelihood="regression")
+        for l, (A, B) in enumerate(views):
+            assert rel(B.cpu().numpy() * np.sqrt(0.5), okf[2 * l][0]) < RTOL, (paths, l)
+    eng.check_async_errors()
+    eng.close()

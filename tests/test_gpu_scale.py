@@ -191,7 +191,7 @@ def test_arxiv_shape_graphsage_properties():
         assert torch.equal(Af, Au) and torch.equal(Bf, Bf.T)
         ev = torch.linalg.eigvalsh(Bf.double())
         assert float(ev.min()) > -1e-5 * float(ev.max())
-    assert abs(float(l_f) - float(l_u)) < 1e-6 * abs(float(l_u))
+    assert abs(float(l_f) - float(l_u)) < 1e-5 * abs(float(l_u))  # (one float atomic per workgroup: the order varies run to run)
     eng.check_async_errors()
 
 

@@ -68,10 +68,13 @@ def test_kfac_plan_decisions_without_a_gpu():
         "fused": [False, False], "backgemm": [False, False], "paths": True}
     for dims in ([128, 128, 40], [128, 256, 70], [128, 256, 256, 40], [128, 254, 40]):  # width, classes, depth, alignment
         assert not kfac_plan("gcn", dims, 169_343, 2_500_000, paths=True)["paths"], dims
-    assert not kfac_plan("sage", [128, 256, 40], 169_343, 2_500_000, paths=True)["paths"]
+    # GraphSAGE, same widths: the same fused kernel over ONE-hop paths (no compact top level, no fused LIST kernel)
+    assert kfac_plan("sage", [128, 256, 40], 169_343, 2_500_000) == {
+        "seeds_on_the_fly": False, "sage_compact": False, "need_pong": False, "classes_per_chunk": 40,
+        "fused": [False, False], "backgemm": [False, False], "paths": True}
     assert not kfac_plan("gcn", [128, 256, 40], 169_343, 2_500_000, act="tanh", paths=True)["paths"]
     assert kfac_plan("gcn", [128, 256, 40], 169_343, 2_500_000, fuse=False)["need_pong"]
-    sage = kfac_plan("sage", [128, 256, 40], 169_343, 2_500_000)
+    sage = kfac_plan("sage", [128, 256, 40], 169_343, 2_500_000, paths=False)
     assert sage["sage_compact"] and sage["fused"] == [False, True] and not sage["need_pong"]
     prod = kfac_plan("sage", [100, 256, 256, 47], 2_449_029, 123_000_000)
     assert prod["fused"] == [False, False, False] and prod["need_pong"] and not prod["sage_compact"]
