@@ -950,6 +950,12 @@ int launch_gram256_stream(const float* Y, int64_t ld, int64_t rows, int64_t widt
   return 0;
 }
 
+// persistent workgroups of paths_fused_kernel: one per CU (149 KB of LDS each); LGNN_FUSED_WGS (dev) leaves CUs to other streams
+static int64_t fused_workgroups() {
+  static const int64_t n = getenv("LGNN_FUSED_WGS") ? std::max<int64_t>(1, atoll(getenv("LGNN_FUSED_WGS"))) : 256;
+  return n;
+}
+
 // B_0 scratch += sum over the class columns [cb, ce) of this batch (see the file header).  Needs batch_prologue's
 // probabilities / multiplicities / positions and the cached forward (logits, mask bits).
 int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce, float* scratch,
@@ -1026,7 +1032,7 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.W1 = h->W[1]; y.w1_ld = int(H); y.Y = nullptr; y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel(s) of the KFAC path (bench.py roofline)
-    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y, scratch);
+    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, fused_workgroups()))), dim3(512), 0, s, y, scratch);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }
@@ -1116,7 +1122,7 @@ int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int 
     y.Y = nullptr; y.N = N; y.M = T; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = 0;  // (the one-hot alpha paths go through the beta product: never skipped)
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the KFAC path (bench.py roofline)
-    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, 256))), dim3(512), 0, s, y, scratch);
+    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, fused_workgroups()))), dim3(512), 0, s, y, scratch);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }

@@ -23,6 +23,8 @@ from __future__ import annotations
 from math import log, pi
 from typing import Any
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -485,6 +487,7 @@ class KronLaplace(ParametricLaplace):
     def _init_H(self):
         self.H = Kron.init_from_model(self.params, self._device)
         self._flat = None
+        self._flat_used = False
 
     def state_dict(self) -> dict:  # laplace/baselaplace.py:1664-1677: the factors, not their decomposition
         sd = super().state_dict()
@@ -509,10 +512,48 @@ class KronLaplace(ParametricLaplace):
         if self._inplace_backend():  # in-place fast path of the HIP backend
             if self._flat is None:
                 self._flat = be.new_kfac_buffers() if hasattr(be, "new_kfac_buffers") else be.engine.new_kfac_buffers()
+            first = not self._flat_used
+            self._flat_used = True
             _, views, loss_buf = self._flat
             be.kron_accumulate_(views, loss_buf, X, y, N, classes=classes)
+            if first and getattr(self, "_early_ok", False):
+                self._snapshot_large_input_factors(views)
             return 0.0, None
         return be.kron(X, y, N=N, **self._asdl_fisher_kwargs)
+
+    def _snapshot_large_input_factors(self, views):
+        """The input covariances do not depend on the batch: every batch adds the same ``in_l^T in_l / N_train`` (the forward
+        pass is cached per weight version), so after the FIRST batch of an ``override=True`` fit a factor already has its
+        final eigenvectors and its eigenvalues up to the scale ``T``.  Factors too large for the one-workgroup
+        decomposition (more than 256 rows: a GraphSAGE's ``A_1`` is 2 H wide, 512 at the arxiv shape) cost a library
+        ``syevd`` of ~12 ms -- a chain of a few thousand tiny launches that used to run after the batch loop.  They are
+        copied here, behind the first batch; ``_finish_accumulate`` -- the host has queued every batch by then and the
+        device is tens of milliseconds behind -- starts their decomposition on a side stream, where it overlaps the
+        remaining batches; ``fit`` hands the result (eigenvalues rescaled by the ratio of the traces, a device scalar: no
+        synchronisation) to ``decompose``."""
+        from .matrix import _SMALL_EIG
+        big = [l for l, (A, _) in enumerate(views) if A.is_cuda and A.shape[0] > _SMALL_EIG]
+        if not big:
+            return
+        snaps = [views[l][0].clone() for l in big]  # A_l after one batch (the buffers keep accumulating)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._early_pending = (big, snaps, [a.diagonal().sum() for a in snaps], ev)
+
+    def _finish_accumulate(self):
+        pending, self._early_pending = getattr(self, "_early_pending", None), None
+        if pending is None:
+            return
+        from .matrix import symeig_batched_hip
+        big, snaps, traces, ev = pending
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=snaps[0].device)
+        self._side_stream.wait_event(ev)
+        with torch.cuda.stream(self._side_stream):
+            pairs = symeig_batched_hip(snaps)
+        for a in snaps:
+            a.record_stream(self._side_stream)
+        self._early = {l: (lam, Q, tr) for l, (lam, Q), tr in zip(big, pairs, traces)}
 
     def _shard_plan(self, train_loader, rank: int, world: int):
         """Backends that can restrict a call to a range of class columns get the balanced (batch, class)
@@ -563,6 +604,13 @@ class KronLaplace(ParametricLaplace):
         return kron
 
     def fit(self, train_loader, override: bool = True, progress_bar: bool = False, process_group=None) -> None:
+        rank_world = _dist_info(process_group)
+        self._early, self._early_pending = {}, None
+        self._side_stream = getattr(self, "_side_stream", None)
+        # (see _snapshot_large_input_factors; single process, fresh factors, and no exact-key cache for the same factor)
+        self._early_ok = (override and rank_world[1] == 1 and self.cache_decompositions and self._inplace_backend()
+                          and os.environ.get("LGNN_NO_EARLY_EIG", "") in ("", "0")
+                          and self._decompose_cache(train_loader, override)[0] is None)
         if override:
             self.H_facs = None
         if self.H_facs is not None:
@@ -579,6 +627,14 @@ class KronLaplace(ParametricLaplace):
             self.H = self._rescale_factors(self.H, n_data_new / (n_data_new + n_data_old))
             self.H_facs += self.H
         cache, keys = self._decompose_cache(train_loader, override)
+        if self._early and cache is None:
+            torch.cuda.current_stream(self._side_stream.device).wait_stream(self._side_stream)
+            cache, keys = {}, {}
+            for l, (lam, Q, tr) in self._early.items():  # block 2 l = layer l's weight block, factor 1 = its A
+                final = self.H_facs.kfacs[2 * l][1]
+                cache[("early", l)] = (lam * (final.diagonal().sum() / tr), Q)
+                keys[(2 * l, 1)] = ("early", l)
+        self._early = {}
         self.H = self.H_facs.decompose(damping=self.damping, process_group=process_group, cache=cache, cache_keys=keys)
 
     def _decompose_cache(self, train_loader, override: bool):

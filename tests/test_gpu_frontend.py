@@ -166,7 +166,9 @@ def test_jacobians_and_glm_predictive(path):
         la.fit(loader)
         f_mu, f_var = la._glm_predictive_distribution(idx)
         assert rel(f_mu.cpu().numpy(), g[structure + "_glm_fmu"]) < RTOL
-        assert rel(f_var.cpu().numpy(), g[structure + "_glm_fvar"]) < 5e-5
+        # (J P^-1 J^T amplifies the factors' run-to-run last-bit differences -- float atomics -- through the small eigenvalues:
+        #  8e-7 ... 2e-4 observed over repeated runs of the same fixture)
+        assert rel(f_var.cpu().numpy(), g[structure + "_glm_fvar"]) < 5e-4
         assert np.abs(la(idx).cpu().numpy() - g[structure + "_glm_probit"]).max() < 5e-5
         for link in ("bridge", "bridge_norm"):
             got = la(idx, pred_type="glm", link_approx=link).cpu().numpy()
@@ -202,7 +204,7 @@ def test_full_laplace_all_weights(name):
     eps, idx = torch.from_numpy(g["pred_eps"]).cuda(), torch.from_numpy(g["pred_idx"]).cuda()
     assert rel(la.sample(eps=eps).cpu().numpy(), g["fullla_samples"]) < 1e-4
     _, f_var = la._glm_predictive_distribution(idx)
-    assert rel(f_var.cpu().numpy(), g["fullla_glm_fvar"]) < 1e-4
+    assert rel(f_var.cpu().numpy(), g["fullla_glm_fvar"]) < 5e-4
     assert np.abs(la(idx).cpu().numpy() - g["fullla_glm_probit"]).max() < 1e-4
     la3 = lg.FullLaplace(model, "classification")
     la3.fit(lg.TensorBatchLoader(idx_all, y_all, batch_size=max(1, len(idx_all) // 3 + 1)))
@@ -228,7 +230,7 @@ def test_regression_likelihood(name):
     assert abs(float(la.loss) - float(g["reg_kron_loss"])) < RTOL * float(g["reg_kron_loss"])
     assert abs(float(la.log_marginal_likelihood()) - float(g["reg_kron_marglik"])) < 3e-4 * abs(float(g["reg_kron_marglik"]))
     f_mu, f_var = la(torch.from_numpy(g["pred_idx"]).cuda(), pred_type="glm")
-    assert rel(f_mu.cpu().numpy(), g["reg_kron_glm_fmu"]) < RTOL and rel(f_var.cpu().numpy(), g["reg_kron_glm_fvar"]) < 5e-5
+    assert rel(f_mu.cpu().numpy(), g["reg_kron_glm_fmu"]) < RTOL and rel(f_var.cpu().numpy(), g["reg_kron_glm_fvar"]) < 5e-4
     # unfused kernels and a three-batch fit give the same factors
     be = lg.HipGGN(model, "regression")
     _, views, loss = be.engine.new_kfac_buffers()
@@ -624,3 +626,40 @@ def test_last_layer_jacobians_are_the_last_block_of_the_full_jacobians(name):
     la.fit(lg.TensorBatchLoader(x, torch.from_numpy(g["train_y"]).cuda(), batch_size=10000))
     probs = la(x[:8], link_approx="probit")
     assert probs.shape == (8, f.shape[1]) and float((probs.sum(-1) - 1).abs().max()) < 1e-5
+
+
+def test_early_decomposition_of_a_large_input_factor_matches_the_late_one():
+    """A GraphSAGE's A_1 is 2 H wide: above 256 rows it is decomposed by a library call, started on a side stream behind the
+    first batch (KronLaplace._snapshot_large_input_factors / _finish_accumulate: the input covariances do not depend on the batch).  Same
+    eigenvalues, marginal likelihood and predictive as the decomposition after the loop (cache_decompositions=False)."""
+    import laplace_gnn_amd as lg
+
+    N, F, H, C, E = 2000, 40, 160, 6, 9000  # A_1: 320 x 320
+    g = torch.Generator().manual_seed(3)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    X = torch.randn(N, F, generator=g)
+    torch.manual_seed(2)
+    model = lg.GraphSAGE(F, H, C, 2, X, ei, symmetric=True).to("cuda").eval()
+    idx, y = torch.randperm(N, generator=g)[:700].cuda(), torch.randint(0, C, (700,), generator=g).cuda()
+    loader = lg.TensorBatchLoader(idx, y, batch_size=300)  # 300 / 300 / 100
+    early = lg.KronLaplace(model, "classification", prior_precision=0.7)
+    early.fit(loader)
+    late = lg.KronLaplace(model, "classification", prior_precision=0.7, cache_decompositions=False)
+    late.fit(loader)
+    assert early._early_ok and not late._early_ok
+    for Fe, Fl in zip(early.H_facs.kfacs, late.H_facs.kfacs):
+        for a, b in zip(Fe, Fl):
+            assert rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+    for le, ll in zip(early.H.eigenvalues, late.H.eigenvalues):
+        for a, b in zip(le, ll):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    for (Qe, le), (Ql, ll), Fs in zip(zip(early.H.eigenvectors, early.H.eigenvalues), zip(late.H.eigenvectors, late.H.eigenvalues),
+                                      early.H_facs.kfacs):
+        for Q, lam, Hm in zip(Qe, le, Fs):  # the early eigenpairs reconstruct the FINAL factor
+            assert rel(((Q * lam) @ Q.T).cpu().numpy(), Hm.cpu().numpy()) < 2e-5
+    assert abs(float(early.log_marginal_likelihood()) - float(late.log_marginal_likelihood())) <= 5e-6 * abs(float(late.log_marginal_likelihood()))
+    x = torch.arange(50).cuda()
+    assert rel(early(x).cpu().numpy(), late(x).cpu().numpy()) < 1e-4  # (two fp32 decompositions: the small eigenvalues' noise)
+    # override=False adds to fitted factors: nothing is known early, the late path runs
+    early.fit(loader, override=False)
+    assert not early._early_ok
