@@ -25,6 +25,11 @@
 namespace lgnn {
 namespace {
 rocblas_handle g_handle = nullptr;
+// The library path (factors above 256 rows) has a handle and a workspace of its own: KronLaplace runs it on a side stream
+// while the caller's stream still executes queued batches that use g_handle (rocBLAS handles are not meant to serve two
+// streams at once: they carry the solver's device workspace).
+rocblas_handle g_eig_handle = nullptr;
+DevBuf g_e_large;  // off-diagonal workspace of the library path [batch, n]
 DevBuf g_e;    // off-diagonal workspace [batch, n]
 DevBuf g_v;    // Householder vectors [batch][n][256]
 DevBuf g_tau;  // [batch][n]
@@ -245,8 +250,8 @@ extern "C" int lgnn_symeig_batched(float* A, int64_t n, int64_t batch, float* W,
   LGNN_REQUIRE(n > 0 && n <= 32768 && batch > 0 && batch <= 65535, "symeig: bad shape");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!blas_handle(s)) { set_error("rocBLAS handle / stream setup failed"); return 3; }
-  LGNN_CALL(g_e.reserve(size_t(batch) * n * 4));
   if (n <= TN && n >= 2 && getenv("LGNN_EIGH_LIBRARY") == nullptr) {
+    LGNN_CALL(g_e.reserve(size_t(batch) * n * 4));
     LGNN_CALL(g_v.reserve(size_t(batch) * n * TN * 4));
     LGNN_CALL(g_tau.reserve(size_t(batch) * n * 4));
     LGNN_CALL(g_d.reserve(size_t(batch) * n * 4));
@@ -261,9 +266,12 @@ extern "C" int lgnn_symeig_batched(float* A, int64_t n, int64_t batch, float* W,
     LGNN_HIP_CHECK(hipGetLastError());
     return 0;
   }
+  if (!g_eig_handle && rocblas_create_handle(&g_eig_handle) != rocblas_status_success) { set_error("rocBLAS handle"); return 3; }
+  if (rocblas_set_stream(g_eig_handle, s) != rocblas_status_success) { set_error("rocBLAS stream setup failed"); return 3; }
+  LGNN_CALL(g_e_large.reserve(size_t(batch) * n * 4));
   const rocblas_status st = rocsolver_ssyevd_strided_batched(
-      g_handle, rocblas_evect_original, rocblas_fill_upper, rocblas_int(n), A, rocblas_int(n), rocblas_stride(n * n), W,
-      rocblas_stride(n), g_e.as<float>(), rocblas_stride(n), info, rocblas_int(batch));
+      g_eig_handle, rocblas_evect_original, rocblas_fill_upper, rocblas_int(n), A, rocblas_int(n), rocblas_stride(n * n), W,
+      rocblas_stride(n), g_e_large.as<float>(), rocblas_stride(n), info, rocblas_int(batch));
   if (st != rocblas_status_success) { set_error("rocsolver_ssyevd_strided_batched failed"); return 3; }
   return 0;
 }

@@ -630,7 +630,10 @@ class KronLaplace(ParametricLaplace):
         if self._early and cache is None:
             torch.cuda.current_stream(self._side_stream.device).wait_stream(self._side_stream)
             cache, keys = {}, {}
+            main = torch.cuda.current_stream(self._side_stream.device)
             for l, (lam, Q, tr) in self._early.items():  # block 2 l = layer l's weight block, factor 1 = its A
+                lam.record_stream(main)  # (allocated on the side stream, read on this one from here on)
+                Q.record_stream(main)
                 final = self.H_facs.kfacs[2 * l][1]
                 cache[("early", l)] = (lam * (final.diagonal().sum() / tr), Q)
                 keys[(2 * l, 1)] = ("early", l)
