@@ -136,6 +136,11 @@ bool gcn2_small_forward_supported(const lgnn_ctx* h) {
   return H <= 64 && C <= 64 && h->N * std::max(F, H) <= (int64_t(1) << 24) && h->N >= 32 && getenv("LGNN_NO_SMALL_FORWARD") == nullptr;
 }
 
+static int64_t gcn2_target_wgs() {  // (dev: LGNN_GCN2_WGS) workgroups of the long-K product: more K slices, shorter load chains
+  static const int64_t n = getenv("LGNN_GCN2_WGS") ? std::max<int64_t>(64, atoll(getenv("LGNN_GCN2_WGS"))) : 512;
+  return n;
+}
+
 int gcn2_forward_through_px(lgnn_ctx* h, hipStream_t s) {
   ForwardCache& fc = h->fc;
   const int64_t N = h->N, F = h->dims[0], H = h->dims[1], C = h->dims[2];
@@ -148,7 +153,7 @@ int gcn2_forward_through_px(lgnn_ctx* h, hipStream_t s) {
   // enough (row tile, K slice) workgroups for the chip, slices a multiple of the 4 waves' chunk stride
   const int64_t row_tiles = cdiv(N, 32);
   const int64_t stride = int64_t(4) * kChunk;
-  int64_t ks = std::max<int64_t>(1, std::min<int64_t>(cdiv(512, row_tiles), cdiv(F, stride * 2)));
+  int64_t ks = std::max<int64_t>(1, std::min<int64_t>(cdiv(gcn2_target_wgs(), row_tiles), cdiv(F, stride * 2)));
   const int64_t k_slice = cdiv(cdiv(F, ks), stride) * stride;
   ks = cdiv(F, k_slice);
   LGNN_CALL(fc.tmp.reserve(size_t(ks) * N * H * 4));

@@ -6,7 +6,7 @@ tag=$1; wl=$2; steps=${3:-10}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; P=${tag}_${w
 case $wl in
   arxiv) kern=paths_fused_kernel; units=40 ;;
   arxiv_powerlaw) kern=spmm_gram256_kernel; units=40 ;;   # hub-heavy graph: full batches keep the class planes (paths_pay)
-  arxiv_sage) kern=spmm_gram256_kernel; units=40 ;;
+  arxiv_sage) kern=paths_fused_kernel; units=40 ;;   # round 3: one-hop path route
   cora) kern=diag_first_layer_mfma_kernel; units=1299 ;;
   products) kern=gram_mem_kernel; units=1128 ;;
 esac
