@@ -178,11 +178,15 @@ struct YArgs {
   int no_bg;                // regression / nothing but the diagonal term: the beta / gamma products vanish
 };
 
-constexpr int kWin = 16;  // paths staged per window: 16 x (2 x 1 KiB table rows + 1 KiB coefficients + 32 B mask) = 48.5 KiB
+// Paths staged per window.  26.6 % of the arxiv-shaped nodes have more than 16 paths, 12 % more than 20 (mean 13.7): every
+// further window of a node is restaged in place, two barriers and an exposed copy.  20 x (2 x 1 KiB table rows + 768 B
+// coefficients + 32 B mask) = 55.6 KiB per window; two of them and a 40-row Y tile fill the 160 KiB of a CU.
+constexpr int kWin = 20;
+constexpr int kCoefLds = 3 * kCoefStride;  // floats of a coefficient row that are staged (the table's rows are 1 KiB apart)
 
 struct YWin {
   float bg[kWin][2][256];       // rows b_m, g_m as they sit in the table (the mask is applied when they are read)
-  float coef[kWin][kCoefRow];   // (alpha | -beta | -gamma | 0) of the path's sample (the path weight is applied when read)
+  float coef[kWin][kCoefLds];   // (alpha | -beta | -gamma) of the path's sample (the path weight is applied when read)
   uint32_t mask[kWin][8];       // ReLU bits of the path's middle node v
 };
 struct YMeta {                  // the window's triples
@@ -212,7 +216,8 @@ __device__ __forceinline__ void stage_dma(const YArgs& a, YWin& win, const YMeta
       if (kind == 2) src = a.coef + mj * kCoefRow + 4 * lane;
       else if (lane_ok && !a.no_bg) src = a.bg + ((kind ? a.M : 0) + mj) * a.H + 4 * lane;
     }
-    lds_dma16(src, dst);
+    // (a coefficient row is 768 bytes in LDS: 48 lanes copy, the others would land in the next path's row)
+    if (kind < 2 || lane < kCoefLds / 4) lds_dma16(src, dst);
   }
 }
 // the mask word (j = tid >> 3, word = tid & 7) of the window's paths, for threads tid < 8 * kw2
@@ -596,7 +601,7 @@ __device__ __forceinline__ void part_mfma(const float (&x)[8], f32x16 (&acc)[HI 
 //   (3) all eight waves contract it into the register-resident upper-triangular 256 x 256 accumulators (36 sub-tiles, 5 + 4 per
 //       SIMD pair), S += Y[n]^T Y[n].
 // Two barriers per node, no exposed memory latency; nodes with more than 16 paths (hubs) restage further windows in place.
-constexpr int kYRows = 48;  // classes per launch (LDS: 2 x 48.5 KiB windows + 48 KiB tile = 146 KiB)
+constexpr int kYRows = 40;  // classes per launch (LDS: 2 x 55.6 KiB windows + 40 KiB tile = 152 KiB)
 
 struct FusedShared {
   YWin win[2];
