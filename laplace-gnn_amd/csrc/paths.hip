@@ -358,6 +358,18 @@ __device__ __forceinline__ YRole y_role(const YArgs& a, bool fixed8 = false) {
 // (hubs) are restaged in place -- every wave of the workgroup takes part in the barriers of that loop, whatever its role.
 // RT1 = false: the wave owns classes [0, 32) x 64 columns (32 x 32 x 2 MFMA); RT1 = true: classes [32, 48) x 64 columns
 // (16 x 16 x 4 MFMA).  W_1's slice of the wave stays in registers for the whole launch.
+#ifdef LGNN_DEV  // make DEV=1: per-wave cycle counts of the fused kernel's phases (s_memtime), printed by paths_phase_report()
+__device__ unsigned long long g_phase[8][8];
+struct Ph { unsigned long long t, acc[8]; };
+#define PH_ARG , Ph& ph
+#define PH_PASS , ph
+#define PH_MARK(k) do { const unsigned long long ph_n = __builtin_amdgcn_s_memtime(); ph.acc[k] += ph_n - ph.t; ph.t = ph_n; } while (0)
+#else
+#define PH_ARG
+#define PH_PASS
+#define PH_MARK(k)
+#endif
+
 template <bool RT1>
 struct YRegs {
   float w1r[RT1 ? 4 : 2][RT1 ? 4 : 16];
@@ -390,7 +402,7 @@ __device__ __forceinline__ void y_load_w1(const YArgs& a, const YRole& ro, bool 
 template <bool RT1>
 __device__ __forceinline__ void y_node_products(const YArgs& a, YWin (&win)[2], YMeta (&meta)[4], float (*ytile)[256],
                                                 const YRole& ro, bool path_wave, const YRegs<RT1>& g, int b, int ms, int kwc,
-                                                int32_t p0c, int32_t p1c) {
+                                                int32_t p0c, int32_t p1c PH_ARG) {
   const int tid = threadIdx.x, H = a.H, lane = ro.lane;
   const bool no_bg = a.no_bg != 0;
   const int cls16 = min(a.c0 + 32 + (lane & 15), kCoefStride - 1);
@@ -407,6 +419,7 @@ __device__ __forceinline__ void y_node_products(const YArgs& a, YWin (&win)[2], 
     for (int ct = 0; ct < 4; ++ct) { u1[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; u2[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
     if (path_wave) mfma_window16(win[b], meta[ms], kwc, lane, cls16, ro.cg, H, no_bg, u1, u2);
   }
+  PH_MARK(2);  // first window's products
   for (int32_t wb = p0c + kWin; wb < p1c; wb += kWin) {  // hubs: further windows, restaged in place (not overlapped)
     const int kw = min(kWin, p1c - wb);
     lds_barrier();
@@ -421,6 +434,7 @@ __device__ __forceinline__ void y_node_products(const YArgs& a, YWin (&win)[2], 
       else mfma_window16(win[b], meta[3], kw, lane, cls16, ro.cg, H, no_bg, u1, u2);
     }
   }
+  PH_MARK(3);  // further windows (restaged)
   // Y[n] into the LDS tile (readers of the previous node's tile passed this node's first barrier)
   if (path_wave) {
     if constexpr (!RT1) {
@@ -450,7 +464,7 @@ __device__ __forceinline__ void y_node_products(const YArgs& a, YWin (&win)[2], 
 // The part of the node loop both persistent kernels share: prologue (node 0's window in flight, node 1's triples in
 // registers) and, per node, the top of the iteration (wait, publish the next triples, barrier, start the next window).
 struct YPipe {
-  int32_t p0c, p1c, p0n, p1n, trm, trv;
+  int32_t p0c, p1c, p0n, p1n, p0f, p1f, trm, trv;  // path ranges of the current node, the next one, and the one after (fetched early)
   float trw;
   int kwc, kwn;
   uint32_t mwn;
@@ -472,6 +486,7 @@ __device__ __forceinline__ void y_pipe_prologue(const YArgs& a, YWin (&win)[2], 
   pp.kwn = min(kWin, pp.p1n - pp.p0n);
   pp.trm = 0; pp.trv = 0; pp.trw = 0.f;
   if (tid < pp.kwn) { pp.trm = a.pm[pp.p0n + tid]; pp.trv = a.pv[pp.p0n + tid]; pp.trw = a.pw[pp.p0n + tid]; }
+  y_range(a, cnt, 2, pp.p0f, pp.p1f);
 }
 
 // The fallback when the batch's path list does not fit its buffer (very large batches on hub-heavy graphs): a grid-stride loop
@@ -631,27 +646,39 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
   const int64_t cnt = a.N > int64_t(blockIdx.x) ? (a.N - blockIdx.x + stride - 1) / stride : 0;
   YPipe pp;
   y_pipe_prologue(a, sh.win, sh.meta, ro, cnt, pp);
+#ifdef LGNN_DEV
+  Ph ph;
+  ph.t = __builtin_amdgcn_s_memtime();
+  for (int k = 0; k < 8; ++k) ph.acc[k] = 0;
+#endif
   for (int64_t i = 0; i < cnt; ++i) {
     const int b = int(i & 1), ms = int(i % 3), msn = int((i + 1) % 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // node i's window has landed; node i + 1's triples are in registers
+    PH_MARK(7);  // waiting for the window's copies
     if (tid < pp.kwn) { sh.meta[msn].m[tid] = pp.trm; sh.meta[msn].v[tid] = pp.trv; sh.meta[msn].w[tid] = pp.trw; }
     lds_barrier();  // window i visible to all waves; everybody is done with node i - 1 (its Gram, the other window buffer;
                     // meta slot msn's previous tenant is three nodes back)
+    PH_MARK(0);  // first barrier
     // ---- asynchronous, behind this node's work: node i + 1's window, its mask words, node i + 2's triples
     stage_dma(a, sh.win[b ^ 1], sh.meta[msn], pp.kwn, ro.wave, 8, lane);
     pp.mwn = 0;
     if (tid < 8 * kWin) pp.mwn = load_mask_word(a, sh.meta[msn], pp.kwn, tid);
-    int32_t p0nn, p1nn;
-    y_range(a, cnt, i + 2, p0nn, p1nn);
+    // (node i + 2's range was fetched one node ago: its triples' addresses do not wait for a pointer load -- measured with
+    //  the DEV build's phase counters: 10.6 % of the kernel sat in that dependent load; node i + 3's range starts now)
+    const int32_t p0nn = pp.p0f, p1nn = pp.p1f;
+    y_range(a, cnt, i + 3, pp.p0f, pp.p1f);
     const int kwnn = min(kWin, p1nn - p0nn);
     pp.trm = 0; pp.trv = 0; pp.trw = 0.f;
     if (tid < kwnn) { pp.trm = a.pm[p0nn + tid]; pp.trv = a.pv[p0nn + tid]; pp.trw = a.pw[p0nn + tid]; }
     // ---- (1) + (2): the path products of node i, Y[n] into the LDS tile.  A node without paths (GraphSAGE: neither in the
     // batch nor next to it; a short last batch) has Y[n] = 0: no products, no Gram, only its share of the pipeline
     const bool has_paths = pp.p1c > pp.p0c;  // (workgroup uniform)
-    if (has_paths) y_node_products<RT1>(a, sh.win, sh.meta, sh.y, ro, path_wave, g, b, ms, pp.kwc, pp.p0c, pp.p1c);
+    PH_MARK(1);  // staging issue, prefetches
+    if (has_paths) y_node_products<RT1>(a, sh.win, sh.meta, sh.y, ro, path_wave, g, b, ms, pp.kwc, pp.p0c, pp.p1c PH_PASS);
+    PH_MARK(4);  // Y tile write
     if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = pp.mwn;  // (readers of that buffer passed this node's barrier)
     lds_barrier();  // raw: a __syncthreads() here would drain the copies in flight for node i + 1
+    PH_MARK(5);  // second barrier
     // ---- (3) S += Y[n]^T Y[n], rows two at a time (operands of step k + 1 read before the MFMAs of step k)
     if (has_paths) {
       const float* __restrict__ base = &sh.y[0][0] + (lane >> 5) * 256 + (lane & 31);
@@ -671,10 +698,14 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
         }
       }
     }
+    PH_MARK(6);  // Gram
     pp.p0c = pp.p0n; pp.p1c = pp.p1n; pp.kwc = pp.kwn;
     pp.p0n = p0nn; pp.p1n = p1nn; pp.kwn = kwnn;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LGNN_DEV
+  if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_phase[ro.wave][k], ph.acc[k]);
+#endif
   const int l31 = lane & 31, lhi = lane >> 5;
   const int64_t D = H;
 #pragma unroll
@@ -954,6 +985,23 @@ int launch_gram256_stream(const float* Y, int64_t ld, int64_t rows, int64_t widt
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }
+
+#ifdef LGNN_DEV
+// make DEV=1: print and clear the phase counters (called from lgnn_destroy when LGNN_PHASE_REPORT is set)
+void paths_phase_report() {
+  unsigned long long host[8][8];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase), sizeof(host)) != hipSuccess) return;
+  static const char* names[8] = {"barrier 1", "stage issue", "products w1", "products w2+", "Y write", "barrier 2", "Gram", "window wait"};
+  fprintf(stderr, "paths_fused_kernel phase cycles (s_memtime ticks, summed over workgroups and launches)\n");
+  for (int k = 0; k < 8; ++k) {
+    fprintf(stderr, "  %-14s", names[k]);
+    for (int w = 0; w < 8; ++w) fprintf(stderr, " %12llu", host[w][k]);
+    fprintf(stderr, "\n");
+  }
+  unsigned long long zero[8][8] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof(zero));
+}
+#endif
 
 // persistent workgroups of paths_fused_kernel: one per CU (149 KB of LDS each); LGNN_FUSED_WGS (dev) leaves CUs to other streams
 static int64_t fused_workgroups() {
