@@ -177,6 +177,21 @@ LGNN_API int lgnn_kfac_accumulate_classes(lgnn_ctx* h, const int64_t* idx, const
                                  uint32_t flags, int64_t class_begin, int64_t class_end,
                                  float* const* A_out, float* const* B_out, float* loss_out, void* stream);
 
+/* Parts [part_begin, part_end) of `part_count` equal parts of the batch's work -- the unit a data-parallel caller deals
+ * to its ranks (laplace_gnn_amd.KronLaplace: part_count = C, contiguous balanced runs of (batch, part) units).  HOW a
+ * batch is cut is the library's choice, the same on every rank for the same (graph, model, batch size, flags):
+ *   - path routes (2-layer GCN / GraphSAGE, lgnn_kfac_last_route == 1): B_0 = sum over destination nodes n of Y_n^T Y_n,
+ *     so a part is the node range [N part_begin / part_count, N part_end / part_count) with ALL classes -- nothing is
+ *     computed twice (a class range would repeat the path products, which do not depend on the class count);
+ *     the small top-layer factor goes with part 0;
+ *   - everywhere else: the class range [C part_begin / part_count, C part_end / part_count) of
+ *     lgnn_kfac_accumulate_classes (possibly empty).
+ * The parts of a batch add up to lgnn_kfac_accumulate exactly (sums of disjoint terms); part 0 also adds the loss and
+ * the A increment.  Replaces the same reference loop as lgnn_kfac_accumulate (curvlinops/kfac.py:653-661, 777-817).      */
+LGNN_API int lgnn_kfac_accumulate_share(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train,
+                               uint32_t flags, int64_t part_begin, int64_t part_end, int64_t part_count,
+                               float* const* A_out, float* const* B_out, float* loss_out, void* stream);
+
 /* ---- empirical / Monte-Carlo Fisher -----------------------------------------------------------------------------
  * KFAC with FisherType.EMPIRICAL / FisherType.MC (curvlinops/kfac.py:663-674; reached through CurvlinopsEF and
  * CurvlinopsGGN(stochastic=True), laplace/curvature/curvlinops.py:143-179): ONE backward pass per call, seeded with

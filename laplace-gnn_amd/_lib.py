@@ -42,6 +42,7 @@ SIGNATURES = {
     "lgnn_forward_all": (_i32, [_vp, _vp, _vp]),
     "lgnn_kfac_accumulate": (_i32, [_vp, _vp, _vp, _i64, _i64, _u32, _pp, _pp, _vp, _vp]),
     "lgnn_kfac_accumulate_classes": (_i32, [_vp, _vp, _vp, _i64, _i64, _u32, _i64, _i64, _pp, _pp, _vp, _vp]),
+    "lgnn_kfac_accumulate_share": (_i32, [_vp, _vp, _vp, _i64, _i64, _u32, _i64, _i64, _i64, _pp, _pp, _vp, _vp]),
     "lgnn_kfac_accumulate_fisher": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _u32, C.c_float, C.c_float, _pp, _pp, _vp, _vp]),
     "lgnn_ef_accumulate": (_i32, [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "lgnn_kfac_plan": (_i32, [_i32, _i32, C.POINTER(_i64), _i64, _i64, _i32, _u32, _i64, C.POINTER(_i64)]),

@@ -497,6 +497,15 @@ extern "C" int lgnn_kfac_accumulate_classes(lgnn_ctx* h, const int64_t* idx, con
                          static_cast<hipStream_t>(stream));
 }
 
+extern "C" int lgnn_kfac_accumulate_share(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train,
+                                          uint32_t flags, int64_t part_begin, int64_t part_end, int64_t part_count,
+                                          float* const* A_out, float* const* B_out, float* loss_out, void* stream) {
+  if (!h) { set_error("null context"); return 2; }
+  const KfacShare share{part_begin, part_end, part_count};
+  return kfac_accumulate(h, idx, y, M, n_train, flags, 0, h->L > 0 ? h->dims[h->L] : 1, A_out, B_out, loss_out,
+                         static_cast<hipStream_t>(stream), nullptr, &share);
+}
+
 extern "C" int lgnn_diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags,
                                     float* diag_out, float* loss_out, void* stream) {
   if (!h) { set_error("null context"); return 2; }

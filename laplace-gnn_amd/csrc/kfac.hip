@@ -765,14 +765,20 @@ int kfac_top_planes(lgnn_ctx* h, const int64_t* idx, int64_t M, bool fork_exact,
 
 int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train, uint32_t flags,
                     int64_t cb, int64_t ce, float* const* A_out, float* const* B_out, float* loss_out, hipStream_t s,
-                    const KfacFisherOpts* fisher) {
+                    const KfacFisherOpts* fisher, const KfacShare* share) {
   LGNN_REQUIRE(M > 0 && idx && (y || (fisher && !fisher->add_loss_and_A)), "empty batch or null batch pointers");
   LGNN_REQUIRE(h->L > 0, "no model bound");
+  // Share mode (lgnn_kfac_accumulate_share): parts [begin, end) of `count` equal parts of the batch's work; HOW a batch is
+  // cut is decided below, once the route is known -- destination-node ranges on the path routes (B_0 = sum_n Y_n^T Y_n:
+  // nothing is computed twice), class ranges everywhere else.  Until then the range is "everything".
+  LGNN_REQUIRE(!share || (share->count > 0 && share->begin >= 0 && share->begin < share->end && share->end <= share->count && !fisher),
+               "share must satisfy 0 <= begin < end <= count");
+  if (share) { cb = 0; ce = h->dims[h->L]; }
   LGNN_REQUIRE(cb >= 0 && cb < ce && ce <= h->dims[h->L], "class range must satisfy 0 <= begin < end <= C");
   // B_l = sum over class columns c of g_c^T g_c: a class range is an exact additive share of the batch.
   // The share that contains class 0 also carries what exists once per batch: the loss and the A increment
   // (and, for GraphSAGE, the whole top-layer Gram, which is only M*C rows).
-  const bool first = cb == 0;
+  const bool first = share ? share->begin == 0 : cb == 0;
   // empirical / MC Fisher: one plane (the gradient seed sits in column 0 of the block), B scaled by 1 / mc_samples, the
   // loss of the TRUE labels and the A increment only with the call that is told to add them
   const bool once = fisher ? fisher->add_loss_and_A : first;
@@ -802,6 +808,18 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
     no_paths = !paths_pay(h, M) && (flags & LGNN_FLAG_FORCE_PATHS) == 0;
   }
   const KfacPlan plan = plan_kfac(h->kind, L, N, h->nnz, h->dims, h->act, no_fuse, h->ws_limit, no_paths);
+  // share mode: the cut.  Path routes: nodes [nb, ne), all classes (the top layer's small Gram goes with part 0); otherwise
+  // classes [C begin / count, C end / count) -- possibly none, then only what exists once per batch is left to do.
+  int64_t nb = 0, ne = N;
+  const bool share_nodes = share && plan.paths;
+  if (share_nodes) {
+    nb = N * share->begin / share->count;
+    ne = N * share->end / share->count;
+  } else if (share) {
+    cb = C * share->begin / share->count;
+    ce = C * share->end / share->count;
+  }
+  const bool no_classes = cb >= ce;  // (share mode with more parts than classes)
   // GCN, fused path: the top-layer kernel rebuilds each sample's C x C seed block from its probabilities and logits,
   // so the blocks are never written (64 MB per arxiv-shaped batch); every other path reads them from ws.seeds
   const bool seeds_on_the_fly = plan.seeds_on_the_fly && !fisher;  // the on-the-fly rebuild knows the GGN blocks only
@@ -824,6 +842,13 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
       LGNN_CALL(h->ws.gram_scratch_res[l].reserve(size_t(D) * D * 4));
       LGNN_HIP_CHECK(hipMemsetAsync(h->ws.gram_scratch_res[l].p, 0, size_t(D) * D * 4, s));
     }
+  }
+
+  // a part without a class column: what exists once per batch has been added above.  (GraphSAGE goes on: its whole
+  // top-layer Gram belongs to part 0, and every loop over the classes [cb, ce) below is empty)
+  if (no_classes && h->kind == LGNN_KIND_GCN) {
+    LGNN_CALL(batch_epilogue(h, idx, M, s));
+    return 0;
   }
 
   // ---- top layer ---------------------------------------------------------------------------------
@@ -853,11 +878,12 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
       // a single-layer model needs the Gram only -- and so does the two-hop path route (paths.hip), which never reads planes
       const bool paths_route = plan.paths && !fisher;
       float* gplanes = (L > 1 && !paths_route) ? gtop : nullptr;
+      const bool top_here = !share_nodes || first;  // node shares: B_{L-1} (all classes, 0.24 ms) goes with part 0
       if (L > 1 && !plan.fuse[L - 1] && !paths_route)
         // the unfused lower path reads every row of the planes: the rows this kernel skips must be zero
         LGNN_HIP_CHECK(hipMemsetAsync(gtop + cb * N * C, 0, size_t(N) * nq * 4, s));
       float* sc = h->ws.gram_scratch[L - 1].as<float>();
-      switch (int(cdiv(C, 16))) {
+      if (top_here) switch (int(cdiv(C, 16))) {
         case 1: LGNN_CALL(seed_spmm_gram_launch<1>(h, fork_exact, gplanes, cb, ce, sc, s)); break;
         case 2: LGNN_CALL(seed_spmm_gram_launch<2>(h, fork_exact, gplanes, cb, ce, sc, s)); break;
         case 3: LGNN_CALL(seed_spmm_gram_launch<3>(h, fork_exact, gplanes, cb, ce, sc, s)); break;
@@ -889,8 +915,9 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
   h->last_route_paths = paths_route;
   if (paths_route) {
     const int mode = h->lik == LGNN_LIK_REGRESSION ? 2 : (fork_exact ? 1 : 0);
-    if (h->kind == LGNN_KIND_GCN) LGNN_CALL(kfac_paths_first_layer(h, idx, M, mode, cb, ce, h->ws.gram_scratch[0].as<float>(), s));
-    else LGNN_CALL(kfac_paths_first_layer_sage(h, idx, M, mode, cb, ce, h->ws.gram_scratch[0].as<float>(), s));
+    if (h->kind == LGNN_KIND_GCN)
+      LGNN_CALL(kfac_paths_first_layer(h, idx, M, mode, cb, ce, h->ws.gram_scratch[0].as<float>(), s, nb, ne));
+    else LGNN_CALL(kfac_paths_first_layer_sage(h, idx, M, mode, cb, ce, h->ws.gram_scratch[0].as<float>(), s, nb, ne));
   }
 
   // ---- lower layers, chunked over classes ----------------------------------------------------------

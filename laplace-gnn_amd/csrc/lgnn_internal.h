@@ -350,9 +350,10 @@ struct KfacFisherOpts {
   float b_scale;        // B_out += b_scale * g^T g               (1 / mc_samples)
   bool add_loss_and_A;  // this call also adds the loss of the true labels `y` and the A increment
 };
+struct KfacShare { int64_t begin, end, count; };  // parts [begin, end) of `count` equal parts of a batch (lgnn_kfac_accumulate_share)
 int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train, uint32_t flags,
                     int64_t class_begin, int64_t class_end, float* const* A_out, float* const* B_out, float* loss_out,
-                    hipStream_t s, const KfacFisherOpts* fisher = nullptr);
+                    hipStream_t s, const KfacFisherOpts* fisher = nullptr, const KfacShare* share = nullptr);
 int batch_prologue(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bool want_seeds, bool fork_exact,
                    float* loss_out, hipStream_t s, const void* y_seed = nullptr, float resid_scale = 1.0f);
 int batch_epilogue(lgnn_ctx* h, const int64_t* idx, int64_t M, hipStream_t s);
@@ -363,10 +364,11 @@ bool paths_supported(int kind, int L, const int64_t* dims, int act, int64_t nnz)
 int two_hop_ensure(lgnn_ctx* h, hipStream_t s);   // h->two_hop = 2-hop paths of the graph, counted once (one synchronisation)
 bool paths_pay(const lgnn_ctx* h, int64_t M);     // expected paths per destination node of a batch of M small enough
 // scratch [H, H] += B_0 of this batch's class columns [cb, ce) (seed_mode: 0 upstream, 1 fork exact, 2 regression)
+// (nb, ne: the destination nodes whose Y_n^T Y_n this call adds -- B_0 is a sum over nodes: the multi-GPU cut of these routes)
 int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce, float* scratch,
-                           hipStream_t s);
+                           hipStream_t s, int64_t nb = 0, int64_t ne = -1);
 int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce,
-                                float* scratch, hipStream_t s);  // GraphSAGE: one-hop paths through the same fused kernel
+                                float* scratch, hipStream_t s, int64_t nb = 0, int64_t ne = -1);  // GraphSAGE: one-hop paths through the same fused kernel
 // scratch [width, width] (upper 32 x 32 sub-tiles) += Y^T Y for rows of `width` floats (row stride ld), 128 < width <= 256:
 // all eight waves of a persistent workgroup per CU on the matrix pipes, row blocks by LDS-DMA (paths.hip)
 int launch_gram256_stream(const float* Y, int64_t ld, int64_t rows, int64_t width, float* scratch, hipStream_t s,

@@ -173,7 +173,8 @@ struct YArgs {
   const float* W1;          // [C][w1_ld]: the H columns Y is multiplied with (GraphSAGE: the neighbour half of W_1)
   int w1_ld;
   float* Y;                 // [N][R][H]
-  int64_t N, M;
+  int64_t N, M;             // all nodes (pptr has N + 1 entries); rows of a table half
+  int64_t n0, n1;           // the destination nodes this launch visits: [n0, n1)
   int H, c0, R;
   int no_bg;                // regression / nothing but the diagonal term: the beta / gamma products vanish
 };
@@ -471,7 +472,7 @@ struct YPipe {
 };
 __device__ __forceinline__ void y_range(const YArgs& a, int64_t cnt, int64_t i, int32_t& p0, int32_t& p1) {
   p0 = p1 = 0;
-  if (i < cnt) { const int64_t n = blockIdx.x + i * int64_t(gridDim.x); p0 = a.pptr[n]; p1 = a.pptr[n + 1]; }
+  if (i < cnt) { const int64_t n = a.n0 + blockIdx.x + i * int64_t(gridDim.x); p0 = a.pptr[n]; p1 = a.pptr[n + 1]; }
 }
 __device__ __forceinline__ void y_pipe_prologue(const YArgs& a, YWin (&win)[2], YMeta (&meta)[4], const YRole& ro, int64_t cnt,
                                                 YPipe& pp) {
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(512, 4) void ybuild_kernel(YArgs a) {
   const int tid = threadIdx.x, lane = ro.lane, wave = ro.wave, H = a.H;
   const int nthreads = blockDim.x, nwaves = ro.nwaves;
   const bool no_bg = a.no_bg != 0;
-  for (int64_t n = blockIdx.x; n < a.N; n += gridDim.x) {
+  for (int64_t n = a.n0 + blockIdx.x; n < a.n1; n += gridDim.x) {
     f32x16 t1[2], y2[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -643,7 +644,8 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
   // the tile is zero where nobody writes: columns >= H, the odd row out
   for (int q = tid; q < kYRows * 256; q += 512) (&sh.y[0][0])[q] = 0.f;
   const int64_t stride = gridDim.x;
-  const int64_t cnt = a.N > int64_t(blockIdx.x) ? (a.N - blockIdx.x + stride - 1) / stride : 0;
+  const int64_t nn = a.n1 - a.n0;  // nodes of this launch; node i of this workgroup is n0 + blockIdx.x + i * stride
+  const int64_t cnt = nn > int64_t(blockIdx.x) ? (nn - blockIdx.x + stride - 1) / stride : 0;
   YPipe pp;
   y_pipe_prologue(a, sh.win, sh.meta, ro, cnt, pp);
 #ifdef LGNN_DEV
@@ -1012,8 +1014,11 @@ static int64_t fused_workgroups() {
 // B_0 scratch += sum over the class columns [cb, ce) of this batch (see the file header).  Needs batch_prologue's
 // probabilities / multiplicities / positions and the cached forward (logits, mask bits).
 int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce, float* scratch,
-                           hipStream_t s) {
+                           hipStream_t s, int64_t nb, int64_t ne) {
   const int64_t N = h->N, C = h->dims[2], H = h->dims[1];
+  if (ne < 0) ne = N;
+  LGNN_REQUIRE(nb >= 0 && nb <= ne && ne <= N, "internal: node range");
+  if (nb == ne) return 0;
   Workspace& ws = h->ws;
   LGNN_REQUIRE(paths_supported(h->kind, h->L, h->dims, h->act, h->nnz), "internal: path route on an unsupported model");
   // ---- per-sample tables and b_m / g_m
@@ -1082,10 +1087,10 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.pw = ws.path_pw.as<float>(); y.cap = cap;
     y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>(); y.zeros = ws.path_zeros.as<float>();
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
-    y.W1 = h->W[1]; y.w1_ld = int(H); y.Y = nullptr; y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
+    y.W1 = h->W[1]; y.w1_ld = int(H); y.Y = nullptr; y.N = N; y.n0 = nb; y.n1 = ne; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel(s) of the KFAC path (bench.py roofline)
-    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, fused_workgroups()))), dim3(512), 0, s, y, scratch);
+    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, scratch);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }
@@ -1104,12 +1109,12 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.pptr = ws.path_pptr.as<int32_t>(); y.cap = cap;
     y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>(); y.zeros = ws.path_zeros.as<float>();
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
-    y.W1 = h->W[1]; y.w1_ld = int(H); y.Y = ws.planes_a.as<float>(); y.N = N; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
+    y.W1 = h->W[1]; y.w1_ld = int(H); y.Y = ws.planes_a.as<float>(); y.N = N; y.n0 = nb; y.n1 = ne; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
     const unsigned threads = unsigned(64 * cdiv(H, 64) * cdiv(R, 32));  // (column groups) x (32-class row tiles) waves
-    hipLaunchKernelGGL(ybuild_kernel, dim3(unsigned(std::min<int64_t>(N, 1024))), dim3(threads), 0, s, y);
+    hipLaunchKernelGGL(ybuild_kernel, dim3(unsigned(std::min<int64_t>(ne - nb, 1024))), dim3(threads), 0, s, y);
     LGNN_HIP_CHECK(hipGetLastError());
-    LGNN_CALL(launch_gram256_stream(y.Y, H, N * R, H, scratch, s, ws.path_pptr.as<int32_t>() + N, cap));
+    LGNN_CALL(launch_gram256_stream(y.Y + nb * R * H, H, (ne - nb) * R, H, scratch, s, ws.path_pptr.as<int32_t>() + N, cap));
   }
   return 0;
 }
@@ -1117,8 +1122,11 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
 // GraphSAGE: B_0 scratch += the class columns [cb, ce) of this batch from the one-hop paths (see sage_path_tables_kernel).
 // Needs batch_prologue's probabilities / multiplicities / positions and the cached forward (logits, mask bits).
 int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_mode, int64_t cb, int64_t ce, float* scratch,
-                                hipStream_t s) {
+                                hipStream_t s, int64_t nb, int64_t ne) {
   const int64_t N = h->N, C = h->dims[2], H = h->dims[1];
+  if (ne < 0) ne = N;
+  LGNN_REQUIRE(nb >= 0 && nb <= ne && ne <= N, "internal: node range");
+  if (nb == ne) return 0;
   Workspace& ws = h->ws;
   LGNN_REQUIRE(h->kind == LGNN_KIND_SAGE && paths_supported(h->kind, h->L, h->dims, h->act, h->nnz),
                "internal: path route on an unsupported model");
@@ -1172,10 +1180,10 @@ int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int 
     y.coef = ws.path_coef.as<float>(); y.bg = bg; y.zeros = ws.path_zeros.as<float>();
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
     y.W1 = h->W[1] + H; y.w1_ld = int(2 * H);  // the neighbour half: the alpha term of the neighbour paths
-    y.Y = nullptr; y.N = N; y.M = T; y.H = int(H); y.c0 = int(c0); y.R = int(R);
+    y.Y = nullptr; y.N = N; y.n0 = nb; y.n1 = ne; y.M = T; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = 0;  // (the one-hot alpha paths go through the beta product: never skipped)
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the KFAC path (bench.py roofline)
-    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(N, fused_workgroups()))), dim3(512), 0, s, y, scratch);
+    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, scratch);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }

@@ -114,6 +114,13 @@ class HipCurvatureInterface:
         """Add this batch's RAW factors (A_l/N_train, B_l) and loss into caller-owned buffers; ``classes``
         restricts the call to a range of class columns (exact additive share, see the C ABI)."""
         self.engine.set_likelihood(self.likelihood)  # regression: sqrt(2) I seeds and the MSE loss on the device
+        if classes is not None and getattr(self.engine, "supports_shares", False):
+            # the multi-GPU unit (begin, end) of C parts per batch: the engine cuts a batch the way its route splits best
+            # (lgnn_kfac_accumulate_share: destination-node ranges on the path routes -- a class range would repeat the
+            # path products on every rank -- class ranges otherwise); the parts still add up to the batch exactly
+            self.engine.kfac_accumulate(x, y, N, views, loss_buf, fork_exact=self.fork_exact_seed, fuse=fuse,
+                                        share=(int(classes[0]), int(classes[1]), self.num_classes))
+            return
         self.engine.kfac_accumulate(x, y, N, views, loss_buf, fork_exact=self.fork_exact_seed, fuse=fuse,
                                     classes=classes)
 

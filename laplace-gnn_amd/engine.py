@@ -72,6 +72,7 @@ class _IdentityKey:
 
 class GraphEngine:
     """Graph ingest + model binding + per-batch curvature accumulation on one GPU."""
+    supports_shares = True  # kfac_accumulate(share=...): lgnn_kfac_accumulate_share
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, kind: str = "gcn", symmetric: bool = False):
         self.lib = _lib.load()
@@ -331,10 +332,13 @@ class GraphEngine:
         return flat, views, loss
 
     def kfac_accumulate(self, idx, y, n_train: int, views, loss, fork_exact: bool = True, fuse: bool = True,
-                        classes: tuple[int, int] | None = None, paths: bool | None = None):
+                        classes: tuple[int, int] | None = None, paths: bool | None = None,
+                        share: tuple[int, int, int] | None = None):
         """Add one batch's factors into the caller-owned buffers.  ``classes=(begin, end)`` restricts the call to
         that range of class columns (an exact additive share of the batch; the share with class 0 also adds
-        the loss and the A increment)."""
+        the loss and the A increment).  ``share=(begin, end, count)``: parts ``[begin, end)`` of ``count`` equal parts of
+        the batch's work, cut the way the route in use splits best (``lgnn_kfac_accumulate_share``: destination-node ranges
+        on the path routes, class ranges otherwise) -- what a data-parallel caller deals to its ranks."""
         self._sync_versions()
         idx = idx.contiguous()
         yp = self._labels(y, idx.shape[0])
@@ -345,6 +349,14 @@ class GraphEngine:
             (_lib.FLAG_NO_PATHS if no_paths else 0) | (_lib.FLAG_FORCE_PATHS if paths else 0)
         A = _lib.ptr_array([a.data_ptr() for a, _ in views])
         B = _lib.ptr_array([b.data_ptr() for _, b in views])
+        if share is not None:
+            if classes is not None:
+                raise ValueError("pass either classes or share")
+            rc = self.lib.lgnn_kfac_accumulate_share(
+                self._h, _dev_ptr(idx, torch.int64, "idx"), yp, idx.shape[0], int(n_train),
+                flags, int(share[0]), int(share[1]), int(share[2]), A, B, loss.data_ptr(), _stream(self.device))
+            _lib.check(rc, "lgnn_kfac_accumulate_share")
+            return
         cb, ce = (0, self.dims[-1]) if classes is None else (int(classes[0]), int(classes[1]))
         rc = self.lib.lgnn_kfac_accumulate_classes(
             self._h, _dev_ptr(idx, torch.int64, "idx"), yp, idx.shape[0], int(n_train),

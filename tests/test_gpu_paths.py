@@ -230,3 +230,40 @@ def test_graphsage_path_route_regression_and_isolated_nodes():
             assert rel(B.cpu().numpy() * np.sqrt(0.5), okf[2 * l][0]) < RTOL, (paths, l)
     eng.check_async_errors()
     eng.close()
+
+
+@pytest.mark.parametrize("kind,paths", [("gcn", None), ("sage", None), ("gcn", False), ("sage", False)])
+def test_shares_of_a_batch_add_up_whichever_way_the_route_cuts_it(kind, paths):
+    """lgnn_kfac_accumulate_share: the multi-GPU unit.  On the path routes a part is a range of destination nodes (B_0 is a sum
+    over nodes: no rank repeats the path products), otherwise a class range; either way the parts of a batch add up to the
+    whole batch, part 0 carries the loss and the A increment, and uneven part counts (more parts than classes) are fine."""
+    import laplace_gnn_amd as lg
+
+    N, F, H, C, E = 3000, 40, 256, 10, 12000
+    ei, X, Ws, bs = _make(kind, N, F, H, C, E, L=2, seed=17)
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randperm(N, generator=g)[:600]
+    idx[590:] = idx[:10]
+    y = torch.randint(0, C, (600,), generator=g)
+    eng = lg.GraphEngine(ei.cuda(), N, kind=kind, symmetric=True)
+    eng.bind(X.cuda(), [w.cuda() for w in Ws], [b.cuda() for b in bs])
+    flat, views, loss = eng.new_kfac_buffers()
+    for s in (0, 300):
+        eng.kfac_accumulate(idx[s:s + 300].cuda(), y[s:s + 300].cuda(), 600, views, loss, paths=paths)
+    used_paths = eng.last_kfac_used_paths
+    assert used_paths == (paths is None)
+    for count, cuts in ((C, [0, 1, 4, 9, C]), (7, [0, 3, 7]), (25, [0, 2, 11, 12, 25])):  # 25 parts of 10 classes: empty class ranges
+        flat2, v2, l2 = eng.new_kfac_buffers()
+        for s in (0, 300):
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                eng.kfac_accumulate(idx[s:s + 300].cuda(), y[s:s + 300].cuda(), 600, v2, l2, share=(a, b, count), paths=paths)
+                assert eng.last_kfac_used_paths == used_paths
+        torch.cuda.synchronize()
+        assert rel(flat2.cpu().numpy(), flat.cpu().numpy()) < 1e-5, (count, cuts)
+    # a single part that is not part 0 adds neither loss nor A
+    flat3, v3, l3 = eng.new_kfac_buffers()
+    eng.kfac_accumulate(idx[:300].cuda(), y[:300].cuda(), 600, v3, l3, share=(3, 5, C), paths=paths)
+    torch.cuda.synchronize()
+    assert float(l3) == 0.0 and all(float(A.abs().max()) == 0.0 for A, _ in v3) and float(v3[0][1].abs().max()) > 0
+    eng.check_async_errors()
+    eng.close()

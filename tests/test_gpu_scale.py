@@ -612,3 +612,30 @@ def test_headline_shape_B0_against_an_independent_fp64_restatement(workload):
     assert abs(float(loss) - ce) < RTOL * ce
     eng.check_async_errors()
     eng.close()
+
+
+@pytest.mark.parametrize("kind,structure", [("gcn", "kron"), ("sage", "kron"), ("gcn", "diag")])
+def test_no_device_allocation_after_the_first_fit(kind, structure):
+    """the workspace is sized by the first fit; a second fit of the same shape allocates nothing
+    (``lgnn_device_bytes`` before / after), whichever route the batches take (two-hop / one-hop paths, closed-form diagonal)."""
+    import laplace_gnn_amd as lg
+
+    N, F, H, C, E = 6000, 64, 256 if structure == "kron" else 64, 12, 30000
+    g = torch.Generator().manual_seed(11)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    X = torch.randn(N, F, generator=g)
+    torch.manual_seed(3)
+    model = (lg.GCN if kind == "gcn" else lg.GraphSAGE)(F, H, C, 2, X, ei, symmetric=True).to("cuda").eval()
+    idx, y = torch.randperm(N, generator=g)[:2500].cuda(), torch.randint(0, C, (2500,), generator=g).cuda()
+    loader = lg.TensorBatchLoader(idx, y, batch_size=1000)  # 1000 / 1000 / 500
+    la = lg.Laplace(model, "classification", subset_of_weights="all", hessian_structure=structure)
+    la.fit(loader)
+    torch.cuda.synchronize()
+    before = model.engine.device_bytes()
+    for _ in range(2):
+        model.engine.invalidate()
+        la.fit(loader)
+    torch.cuda.synchronize()
+    assert model.engine.device_bytes() == before
+    if structure == "kron":
+        assert model.engine.last_kfac_used_paths
