@@ -608,3 +608,24 @@ def test_model_constructor_validation():
     assert isinstance(b.norms[0], torch.nn.BatchNorm1d) and len(b.res) == 0
     with pytest.raises(NotImplementedError):
         lg.GraphSAGE(4, 5, 3, 2, X, adj, 5)
+
+
+def test_the_flattened_mean_is_reused_only_while_no_parameter_changed():
+    """fit() flattens the parameters into ``mean`` (laplace/baselaplace.py:800); the concatenation is skipped when neither a
+    parameter's storage nor its version counter moved since the last fit -- and only then."""
+    g = np.load(os.path.join(GOLDEN, "gcn_small_3batch_s1.npz"))
+    model = _cpu_model(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"]), int(g["batch_size"]))
+    la = lg.Laplace(model, "classification", "all", "diag", backend=OracleBackend)
+    la.fit(loader)
+    m0 = la.mean
+    la.fit(loader)
+    assert la.mean is m0  # nothing changed: the same tensor
+    with torch.no_grad():
+        model.convs[0].lin.bias.add_(0.25)  # in place: the version counter moves
+    la.fit(loader)
+    assert la.mean is not m0 and torch.equal(la.mean, torch.nn.utils.parameters_to_vector(la.params).detach())
+    m1 = la.mean
+    torch.nn.utils.vector_to_parameters(m1.clone() * 0.5, la.params)  # storage replaced
+    la.fit(loader)
+    assert la.mean is not m1 and torch.equal(la.mean, m1 * 0.5)
