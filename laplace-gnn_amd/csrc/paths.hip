@@ -175,6 +175,8 @@ struct YArgs {
   float* Y;                 // [N][R][H]
   int64_t N, M;             // all nodes (pptr has N + 1 entries); rows of a table half
   int64_t n0, n1;           // the destination nodes this launch visits: [n0, n1)
+  const int32_t* list;      // optional: the nodes of that range that have a path (relative to n0), ...
+  const int32_t* n_list;    // ... and how many (device side: no host round trip); null: every node of the range
   int H, c0, R;
   int no_bg;                // regression / nothing but the diagonal term: the beta / gamma products vanish
 };
@@ -470,24 +472,30 @@ struct YPipe {
   int kwc, kwn;
   uint32_t mwn;
 };
+template <bool LIST>
 __device__ __forceinline__ void y_range(const YArgs& a, int64_t cnt, int64_t i, int32_t& p0, int32_t& p1) {
   p0 = p1 = 0;
-  if (i < cnt) { const int64_t n = a.n0 + blockIdx.x + i * int64_t(gridDim.x); p0 = a.pptr[n]; p1 = a.pptr[n + 1]; }
+  if (i < cnt) {
+    const int64_t k = blockIdx.x + i * int64_t(gridDim.x);
+    const int64_t n = a.n0 + (LIST ? int64_t(a.list[k]) : k);
+    p0 = a.pptr[n]; p1 = a.pptr[n + 1];
+  }
 }
+template <bool LIST>
 __device__ __forceinline__ void y_pipe_prologue(const YArgs& a, YWin (&win)[2], YMeta (&meta)[4], const YRole& ro, int64_t cnt,
                                                 YPipe& pp) {
   const int tid = threadIdx.x;
-  y_range(a, cnt, 0, pp.p0c, pp.p1c);
+  y_range<LIST>(a, cnt, 0, pp.p0c, pp.p1c);
   pp.kwc = min(kWin, pp.p1c - pp.p0c);
   if (tid < pp.kwc) { meta[0].m[tid] = a.pm[pp.p0c + tid]; meta[0].v[tid] = a.pv[pp.p0c + tid]; meta[0].w[tid] = a.pw[pp.p0c + tid]; }
   __syncthreads();
   stage_dma(a, win[0], meta[0], pp.kwc, ro.wave, 8, ro.lane);
   if (tid < 8 * kWin) win[0].mask[tid >> 3][tid & 7] = load_mask_word(a, meta[0], pp.kwc, tid);
-  y_range(a, cnt, 1, pp.p0n, pp.p1n);
+  y_range<LIST>(a, cnt, 1, pp.p0n, pp.p1n);
   pp.kwn = min(kWin, pp.p1n - pp.p0n);
   pp.trm = 0; pp.trv = 0; pp.trw = 0.f;
   if (tid < pp.kwn) { pp.trm = a.pm[pp.p0n + tid]; pp.trv = a.pv[pp.p0n + tid]; pp.trw = a.pw[pp.p0n + tid]; }
-  y_range(a, cnt, 2, pp.p0f, pp.p1f);
+  y_range<LIST>(a, cnt, 2, pp.p0f, pp.p1f);
 }
 
 // The fallback when the batch's path list does not fit its buffer (very large batches on hub-heavy graphs): a grid-stride loop
@@ -625,7 +633,7 @@ struct FusedShared {
   float y[kYRows][256];
 };
 
-template <int W, int LO, int HI>
+template <int W, int LO, int HI, bool LIST>
 __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, float* __restrict__ scratch) {
   constexpr int NT = HI - LO;
   constexpr bool RT1 = LO != 0;  // hardware waves 4 .. 7: the second class tile, the second half of the SIMD pair's sub-tiles
@@ -644,10 +652,11 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
   // the tile is zero where nobody writes: columns >= H, the odd row out
   for (int q = tid; q < kYRows * 256; q += 512) (&sh.y[0][0])[q] = 0.f;
   const int64_t stride = gridDim.x;
-  const int64_t nn = a.n1 - a.n0;  // nodes of this launch; node i of this workgroup is n0 + blockIdx.x + i * stride
+  // nodes of this launch: entry blockIdx.x + i * stride of the list of nodes with paths (or of the whole range)
+  const int64_t nn = LIST ? int64_t(__builtin_amdgcn_readfirstlane(*a.n_list)) : a.n1 - a.n0;
   const int64_t cnt = nn > int64_t(blockIdx.x) ? (nn - blockIdx.x + stride - 1) / stride : 0;
   YPipe pp;
-  y_pipe_prologue(a, sh.win, sh.meta, ro, cnt, pp);
+  y_pipe_prologue<LIST>(a, sh.win, sh.meta, ro, cnt, pp);
 #ifdef LGNN_DEV
   Ph ph;
   ph.t = __builtin_amdgcn_s_memtime();
@@ -668,7 +677,7 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
     // (node i + 2's range was fetched one node ago: its triples' addresses do not wait for a pointer load -- measured with
     //  the DEV build's phase counters: 10.6 % of the kernel sat in that dependent load; node i + 3's range starts now)
     const int32_t p0nn = pp.p0f, p1nn = pp.p1f;
-    y_range(a, cnt, i + 3, pp.p0f, pp.p1f);
+    y_range<LIST>(a, cnt, i + 3, pp.p0f, pp.p1f);
     const int kwnn = min(kWin, p1nn - p0nn);
     pp.trm = 0; pp.trv = 0; pp.trw = 0.f;
     if (tid < kwnn) { pp.trm = a.pm[p0nn + tid]; pp.trv = a.pv[p0nn + tid]; pp.trw = a.pw[p0nn + tid]; }
@@ -721,19 +730,22 @@ __device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, floa
   }
 }
 
+// LIST: the node loop runs over a device-side list of the nodes that have a path (a separate instance: the indirection
+// costs the full-batch GCN launch, where every node has paths, 0.14 ms)
+template <bool LIST>
 __global__ __launch_bounds__(512, 2) void paths_fused_kernel(YArgs a, float* __restrict__ scratch) {
   __shared__ FusedShared sh;  // ONE LDS object (a second one makes hipcc drain vmcnt before its reads)
   if (int64_t(a.pptr[a.N]) > a.cap) return;  // the path list overflowed its buffer: the enumerating route takes over
   const int hw = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
   switch (hw) {  // hardware waves g and g + 4 share a SIMD: 5 + 4 of the group's 9 sub-tiles
-    case 0: fused_wave<0, 0, 5>(a, sh, scratch); break;
-    case 4: fused_wave<0, 5, 9>(a, sh, scratch); break;
-    case 1: fused_wave<1, 0, 5>(a, sh, scratch); break;
-    case 5: fused_wave<1, 5, 9>(a, sh, scratch); break;
-    case 2: fused_wave<2, 0, 5>(a, sh, scratch); break;
-    case 6: fused_wave<2, 5, 9>(a, sh, scratch); break;
-    case 3: fused_wave<3, 0, 5>(a, sh, scratch); break;
-    default: fused_wave<3, 5, 9>(a, sh, scratch); break;
+    case 0: fused_wave<0, 0, 5, LIST>(a, sh, scratch); break;
+    case 4: fused_wave<0, 5, 9, LIST>(a, sh, scratch); break;
+    case 1: fused_wave<1, 0, 5, LIST>(a, sh, scratch); break;
+    case 5: fused_wave<1, 5, 9, LIST>(a, sh, scratch); break;
+    case 2: fused_wave<2, 0, 5, LIST>(a, sh, scratch); break;
+    case 6: fused_wave<2, 5, 9, LIST>(a, sh, scratch); break;
+    case 3: fused_wave<3, 0, 5, LIST>(a, sh, scratch); break;
+    default: fused_wave<3, 5, 9, LIST>(a, sh, scratch); break;
   }
 }
 
@@ -923,6 +935,11 @@ __global__ __launch_bounds__(256) void sage_path_list_kernel(const int32_t* __re
   if (!FILL && lane == 0) pcnt[n] = run;
 }
 
+__global__ void path_flag_kernel(const int32_t* __restrict__ pptr, int64_t n0, int64_t n, uint8_t* __restrict__ flags) {
+  const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k < n) flags[k] = pptr[n0 + k + 1] > pptr[n0 + k] ? 1 : 0;
+}
+
 // S2 = sum_v (entries of row v of P) * (entries of row v of P^T): the number of 2-hop paths n <- v <- m of the whole graph
 __global__ void two_hop_count_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ rpt, int64_t N,
                                      unsigned long long* __restrict__ out) {
@@ -1005,6 +1022,20 @@ void paths_phase_report() {
 }
 #endif
 
+// The nodes of [nb, ne) that have a path, as a device-side list (GraphSAGE: 65 % of the nodes at the arxiv shape; a short last
+// batch of a GCN: 70 %): the fused kernel's node loop, its barriers and its staging pipeline then only see those.
+static int path_node_list(lgnn_ctx* h, int64_t nb, int64_t ne, hipStream_t s) {
+  Workspace& ws = h->ws;
+  const int64_t n = ne - nb;
+  LGNN_CALL(ws.path_flags.reserve(size_t(h->N)));
+  LGNN_CALL(ws.path_nodes.reserve(size_t(h->N) * 4));
+  LGNN_CALL(ws.path_nnodes.reserve(64));
+  hipLaunchKernelGGL(path_flag_kernel, dim3(unsigned(cdiv(n, 256))), dim3(256), 0, s, ws.path_pptr.as<int32_t>(), nb, n,
+                     ws.path_flags.as<uint8_t>());
+  LGNN_HIP_CHECK(hipGetLastError());
+  return compact_flags(ws.path_flags.as<uint8_t>(), n, ws.path_nodes.as<int32_t>(), ws.path_nnodes.as<int32_t>(), ws.select_tmp, s);
+}
+
 // persistent workgroups of paths_fused_kernel: one per CU (149 KB of LDS each); LGNN_FUSED_WGS (dev) leaves CUs to other streams
 static int64_t fused_workgroups() {
   static const int64_t n = getenv("LGNN_FUSED_WGS") ? std::max<int64_t>(1, atoll(getenv("LGNN_FUSED_WGS"))) : 256;
@@ -1078,9 +1109,16 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
   // buffer do the two launches behind it run: the enumerating Y builder (planes in HBM, under the workspace cap) and the
   // streaming Gram over them; otherwise they return at once and no plane is ever allocated.
   LGNN_REQUIRE(N < (int64_t(1) << 31), "too many nodes for one launch");
+  // the list of nodes with paths pays when a good share of the nodes has none: with p expected paths per node that share is
+  // about exp(-p) (a full arxiv-shaped batch: p = 13.7, every node has paths -- the list would be pure overhead, measured
+  // +0.17 ms per launch; its last batch of 941 samples: p = 1.3, 28 % of the nodes without)
+  const double ppn = h->two_hop >= 0 ? h->two_hop / double(N) * double(M) / double(N) : 1e9;
+  const bool use_list = ppn < 2.5;
+  if (use_list) LGNN_CALL(path_node_list(h, nb, ne, s));
   for (int64_t c0 = cb; c0 < ce; c0 += kYRows) {
     const int64_t R = std::min<int64_t>(kYRows, ce - c0);
     YArgs y{};
+    if (use_list) { y.list = ws.path_nodes.as<int32_t>(); y.n_list = ws.path_nnodes.as<int32_t>(); }
     y.rowptr = h->PT.rowptr; y.col = h->PT.col; y.val = h->PT.val;
     y.rptr = ws.path_rptr.as<int32_t>(); y.r_m = ws.path_rm.as<int32_t>(); y.r_w = ws.path_rw.as<float>();
     y.pptr = ws.path_pptr.as<int32_t>(); y.pm = ws.path_pm.as<int32_t>(); y.pv = ws.path_pv.as<int32_t>();
@@ -1090,7 +1128,8 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.W1 = h->W[1]; y.w1_ld = int(H); y.Y = nullptr; y.N = N; y.n0 = nb; y.n1 = ne; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = no_bg ? 1 : 0;
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel(s) of the KFAC path (bench.py roofline)
-    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, scratch);
+    if (y.list) hipLaunchKernelGGL(paths_fused_kernel<true>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, scratch);
+    else hipLaunchKernelGGL(paths_fused_kernel<false>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, scratch);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }
@@ -1171,9 +1210,11 @@ int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int 
                      ws.path_pptr.as<int32_t>(), ws.path_pm.as<int32_t>(), ws.path_pv.as<int32_t>(), ws.path_pw.as<float>());
   LGNN_HIP_CHECK(hipGetLastError());
   LGNN_REQUIRE(N < (int64_t(1) << 31), "too many nodes for one launch");
+  LGNN_CALL(path_node_list(h, nb, ne, s));
   for (int64_t c0 = cb; c0 < ce; c0 += kYRows) {
     const int64_t R = std::min<int64_t>(kYRows, ce - c0);
     YArgs y{};
+    y.list = ws.path_nodes.as<int32_t>(); y.n_list = ws.path_nnodes.as<int32_t>();
     y.rowptr = h->PT.rowptr; y.col = h->PT.col; y.val = h->PT.val;
     y.pptr = ws.path_pptr.as<int32_t>(); y.pm = ws.path_pm.as<int32_t>(); y.pv = ws.path_pv.as<int32_t>();
     y.pw = ws.path_pw.as<float>(); y.cap = cap;
@@ -1183,7 +1224,8 @@ int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int 
     y.Y = nullptr; y.N = N; y.n0 = nb; y.n1 = ne; y.M = T; y.H = int(H); y.c0 = int(c0); y.R = int(R);
     y.no_bg = 0;  // (the one-hot alpha paths go through the beta product: never skipped)
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the KFAC path (bench.py roofline)
-    hipLaunchKernelGGL(paths_fused_kernel, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, scratch);
+    if (y.list) hipLaunchKernelGGL(paths_fused_kernel<true>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, scratch);
+    else hipLaunchKernelGGL(paths_fused_kernel<false>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, scratch);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }
