@@ -670,6 +670,8 @@ class KronLaplace(ParametricLaplace):
         return self.H * self._H_factor + pp
 
     # ---- 8(f)-4: what the GNN driver differentiates (gnn/marglik_training.py:197-216) ------------------------------
+    _FP64_EIG_MAX = 512  # factors up to this size are re-decomposed in fp64 for the adjacency gradient
+
     def _logdet_factor_gradients(self):
         """``d logdet(P) / d B_l`` and ``/ d A_l`` per layer (laplace/utils/matrix.py:371-394: ``sum log(f lB_i lA_j + delta)``
         per weight block, ``sum log(f lB_i + delta)`` per bias block, f = H_factor): ``Q diag(.) Q^T`` in the factor's own
@@ -684,15 +686,30 @@ class KronLaplace(ParametricLaplace):
         kf = self.H_facs.kfacs
         eig = {}  # the bias block's factor is its weight block's B: decompose it once
 
-        def eigh64(t):
+        def eigh64(block, k):
+            t = kf[block][k]
             key = (t.data_ptr(), tuple(t.shape))
             if key not in eig:
-                eig[key] = torch.linalg.eigh(t.double())
+                if t.shape[0] <= 128:
+                    # small factors on the host: an fp64 eigh of a 64 x 64 matrix is ~2 ms of launches on the device and
+                    # ~0.1 ms on a core (the Cora-shaped gradient is a 1 ms call)
+                    # (numpy: torch's CPU eigh spins up the whole intra-op thread pool -- 100 ms on a 128-core host)
+                    import numpy as np
+                    lam, Q = np.linalg.eigh(t.double().cpu().numpy())
+                    eig[key] = (torch.from_numpy(lam).to(t.device), torch.from_numpy(Q).to(t.device))
+                elif t.shape[0] <= self._FP64_EIG_MAX:
+                    eig[key] = torch.linalg.eigh(t.double())
+                else:
+                    # a large input covariance (Cora's 1 433 x 1 433 X^T X: 40 ms in fp64 on a 1 ms call): the fit's own
+                    # eigenpairs.  Its eigenvalues enter the other factors' coefficients only through f lA_j / (f lB_i lA_j
+                    # + delta), which is insensitive to the small ones; its own gradient matrix is read by the GraphSAGE
+                    # adjoint only (a GCN's first input covariance does not depend on the adjacency)
+                    eig[key] = (self.H.eigenvalues[block][k].double(), self.H.eigenvectors[block][k].double())
             return eig[key]
 
         gB, gA = [], []
         for l in range(len(kf) // 2):
-            (lB, QB), (lA, QA), (lBb, QBb) = eigh64(kf[2 * l][0]), eigh64(kf[2 * l][1]), eigh64(kf[2 * l + 1][0])
+            (lB, QB), (lA, QA), (lBb, QBb) = eigh64(2 * l, 0), eigh64(2 * l, 1), eigh64(2 * l + 1, 0)
             den = f * torch.outer(lB, lA) + deltas[2 * l]
             cB = (f * lA.unsqueeze(0) / den).sum(dim=1)
             cA = (f * lB.unsqueeze(1) / den).sum(dim=0)
