@@ -390,7 +390,7 @@ def main():
                                    "share of skipped rows" if w.get("kind") == "sage" else "")})
             elif structure == "diag":
                 # dominant kernel: the first-layer contraction (GCN: diag_first_layer_mfma_kernel, GraphSAGE:
-                # diag_first_layer_dma_kernel), one launch per batch.  ALGORITHMIC bytes per launch (SURVEY.md 8(d)
+                # diag_first_layer_kernel<1>), one launch per batch.  ALGORITHMIC bytes per launch (SURVEY.md 8(d)
                 # "Diag (C2)"): N*F*4 + nnz*8 + 2*P*4; flops 2*M*dbar*H*(F+1).  HBM bound by that count (in practice latency
                 # bound: ~16 MB per launch; DESIGN.md has the phase breakdown).
                 P = eng.n_params
@@ -398,7 +398,7 @@ def main():
                 ach = bytes_l * launches / (kern_ms * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": ach / PEAK_HBM_GBS, **common,
-                            "kernel": "diag_first_layer_dma_kernel" if w.get("kind") == "sage" else "diag_first_layer_mfma_kernel",
+                            "kernel": "diag_first_layer_kernel<1>" if w.get("kind") == "sage" else "diag_first_layer_mfma_kernel",
                             "samples_per_launch": upl, "algorithmic_bytes_per_launch": bytes_l,
                             "algorithmic_TFLOPs": 2.0 * units * (nnz / N) * H * (F + 1) / (kern_ms * 1e-3) / 1e12}
             else:

@@ -938,8 +938,14 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
   // (measured at the Cora shape: 1 024 - 2 048 workgroups are the optimum -- fewer lengthen the per-workgroup chain,
   //  more multiply the float atomics of the flush: 0.13 ms at 2 048, 0.26 ms at 8 192)
   int64_t slab = std::max<int64_t>(8, std::min<int64_t>(64, cdiv(M * tiles, 2048)));
+  // First-layer kernel: 2 = matrix cores (GCN), 1 = LDS-DMA rows + v_readlane operand, 0 = the register-staged kernel of
+  // round 2.  GraphSAGE takes 0: its self path needs three q rows and the node's own rows per closing entry, and at the
+  // arxiv shape the staged kernel is the faster one there (2.02 against 2.21 ms per batch; at the Cora shape 0.131 / 0.122).
+  // LGNN_DIAG_STAGED / LGNN_DIAG_VALU force 0 / 1 for either family (A/B runs, tests).
+  const int route = getenv("LGNN_DIAG_STAGED") != nullptr ? 0
+                    : getenv("LGNN_DIAG_VALU") != nullptr ? 1 : (h->kind == LGNN_KIND_SAGE ? 0 : 2);
   // the LDS-DMA kernel hides the chain: longer slabs, fewer atomics (~768 workgroups, three per CU)
-  if (getenv("LGNN_DIAG_STAGED") == nullptr) slab = std::max<int64_t>(8, std::min<int64_t>(64, cdiv(M * tiles, 768)));
+  if (route != 0) slab = std::max<int64_t>(8, std::min<int64_t>(64, cdiv(M * tiles, 768)));
   if (const char* e = getenv("LGNN_DIAG_SLAB")) slab = std::max<int64_t>(1, std::min<int64_t>(64, atoll(e)));
   const unsigned nslab = unsigned(cdiv(M, slab));
 
@@ -967,14 +973,14 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
       feat_views(h, 0, E);
       const dim3 grid{unsigned(cdiv(E.width + 1, 64)), unsigned(cdiv(H, 64)), nslab};
       if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the diagonal path (bench.py roofline)
-      if (getenv("LGNN_DIAG_STAGED") != nullptr) {  // the register-staged kernel (A/B runs)
+      if (route == 0) {  // the register-staged kernel
         if (has_self)
           hipLaunchKernelGGL(diag_first_layer_kernel<1>, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab,
                              E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
         else
           hipLaunchKernelGGL(diag_first_layer_kernel<0>, grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val, idx, M, slab,
                              E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
-      } else if (has_self || getenv("LGNN_DIAG_VALU") != nullptr) {
+      } else if (route == 1 || has_self) {
         if (has_self)
           hipLaunchKernelGGL((diag_first_layer_dma_kernel<1, 16, 3>), grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val,
                              idx, M, slab, E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);

@@ -50,10 +50,13 @@ def test_small_graph_diag_route_vs_oracle(kind, F, H, C, E, skew, slab, monkeypa
     ol, od = O.diag_batch(om, idx.numpy(), y.numpy())
     assert rel(Hd, od) < RTOL
     assert abs(loss - float(ol)) < RTOL * abs(float(ol))
-    # the register-staged kernel of rounds 1-2 computes the same numbers (kept for A/B runs)
-    monkeypatch.setenv("LGNN_DIAG_STAGED", "1")
-    Hs, _ = _diag(eng, idx, y)
-    assert rel(Hs, od) < RTOL and rel(Hs, Hd) < 1e-5
+    # every first-layer kernel computes the same numbers: the default (matrix cores for a GCN, the register-staged kernel for
+    # GraphSAGE), the LDS-DMA / v_readlane kernel and the register-staged kernel of rounds 1-2
+    for switch in ("LGNN_DIAG_VALU", "LGNN_DIAG_STAGED"):
+        monkeypatch.setenv(switch, "1")
+        Hs, _ = _diag(eng, idx, y)
+        assert rel(Hs, od) < RTOL and rel(Hs, Hd) < 1e-5, switch
+        monkeypatch.delenv(switch)
     eng.check_async_errors()
     eng.close()
 
