@@ -68,6 +68,29 @@ def main():
             val, ei, grad, gc = lp.neg_marglik_adj_grad(loader, candidates=cand)
             assert rel(grad.cpu().numpy(), g["adjgrad_vals"]) < 1e-3 and rel(gc.cpu().numpy(), g["adjgrad_ne_val"]) < 1e-3
         model.engine.check_async_errors()
+    # the path routes (hidden width > 128) cut a batch by DESTINATION NODES (lgnn_kfac_accumulate_share): the ranks' node ranges
+    # of every batch must add up to the single-process fit, for the GCN's two-hop and GraphSAGE's one-hop paths
+    solo = [dist.new_group([r]) for r in range(world)][rank]  # (every rank creates every group, in the same order)
+    for kind in ("gcn", "sage"):
+        N, F, H, C, E = 3000, 40, 256, 10, 12000
+        gen = torch.Generator().manual_seed(31)
+        ei = torch.randint(0, N, (2, E), generator=gen)
+        X = torch.randn(N, F, generator=gen)
+        torch.manual_seed(4)
+        model = (lg.GCN if kind == "gcn" else lg.GraphSAGE)(F, H, C, 2, X, ei, symmetric=True).to("cuda").eval()
+        idx = torch.randperm(N, generator=gen)[:700].cuda()
+        y = torch.randint(0, C, (700,), generator=gen).cuda()
+        loader = lg.TensorBatchLoader(idx, y, batch_size=300)  # 300 / 300 / 100: 30 (batch, part) units over the ranks
+        la = lg.KronLaplace(model, "classification")
+        la.fit(loader)
+        assert model.engine.last_kfac_used_paths, kind
+        la1 = lg.KronLaplace(model, "classification")
+        la1.fit(loader, process_group=solo)
+        for Fa, Fb in zip(la.H_facs.kfacs, la1.H_facs.kfacs):
+            for a_, b_ in zip(Fa, Fb):
+                assert rel(a_.cpu().numpy(), b_.cpu().numpy()) < 1e-5, (kind, rank, "node shares")
+        assert abs(float(la.loss) - float(la1.loss)) < 1e-5 * abs(float(la1.loss))
+        model.engine.check_async_errors()
     dist.barrier()
     if rank == 0:
         print(f"DIST_GPU_OK world={world}", flush=True)
