@@ -32,6 +32,9 @@ for seed in range(first, last):
         la.fit(loader)
         cand = torch.randint(0, N, (2, 50), generator=g)
         cand = cand[:, cand[0] != cand[1]]
+        sr, sc = model.engine.export_adj()  # stored entries are not candidates (refused by neg_marglik_adj_grad)
+        stored0 = set(zip(sr.cpu().tolist(), sc.cpu().tolist()))
+        cand = cand[:, torch.tensor([(int(i), int(j)) not in stored0 for i, j in cand.t().tolist()], dtype=torch.bool)]
         val, e2, grad, gc = la.neg_marglik_adj_grad(loader, candidates=cand.cuda())
         Ws = [c.lin.weight.detach().cpu().numpy() for c in model.convs]
         bsn = [c.lin.bias.detach().cpu().numpy() for c in model.convs]
@@ -47,7 +50,7 @@ for seed in range(first, last):
         e_c = rel(gc.cpu().numpy()[keep], ref_c) if keep.any() else 0.0
         e_g = rel(np.concatenate([grad.cpu().numpy(), gc.cpu().numpy()[keep]]), np.concatenate([og, ref_c]))
         model.engine.check_async_errors()
-        if not (e_val < 5e-4 and e_g < 2e-3 and e_c < 2e-3):
+        if not (e_val < 5e-5 and e_g < 2e-4 and e_c < 2e-4):  # fp32 sums of the value: up to 2.2e-5 seen at H = 256
             bad.append((seed, kind, N, F, H, C, E, M, bs, sym, fe, e_val, e_g, e_c))
             print("MISMATCH", bad[-1], flush=True)
     except Exception as e:  # noqa: BLE001
