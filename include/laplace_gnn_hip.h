@@ -23,7 +23,7 @@
  *         number of rows the second backward level can reach sizes its gather / GEMM / scatter
  *         (a host-side bound would be N on hub-heavy graphs: 5x the buffers at the products shape);
  *       lgnn_kfac_adjgrad_batch on GraphSAGE models, once per batch: the active-row count sizes a
- *         library GEMM;   lgnn_glm_variance, once per call: the size of the rotated-row table.
+ *         library GEMM;   lgnn_glm_variance(_mapped), once per call: the size of the rotated-row table.
  *     The headline paths -- 2-layer GCN / GraphSAGE KFAC, diagonal and last-layer GGN, forward,
  *     Jacobians -- enqueue only; workspaces grow on first use of a shape and are reused after;
  *   - every function returns 0 on success, non-zero on error; the message is available
@@ -324,6 +324,18 @@ LGNN_API int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float*
 LGNN_API int lgnn_glm_variance(lgnn_ctx* h, const int64_t* idx, int64_t M, const float* QA0, const float* QB0, const float* S0,
                       const float* QA1, const float* S1, const float* QB1sq, const float* kappa, float* f_mu,
                       float* f_var_diag, void* stream);
+/* The same for a linear map of the logits: var_mapped [M, Cm] = diag(E J P^-1 J^T E^T) for E [Cm, C], handed over as the
+ * mapped head W1m = E W_1 [Cm, in_dim_1] (row major; GraphSAGE: both halves).  With E = [I ; 1^T / C ; I + 1 1^T / C]
+ * (Cm = 2 C + 1) polarisation gives the row sums and the total of the C x C predictive covariance next to its diagonal --
+ * all that the Laplace bridge with its zero-mean correction reads (link_approx "bridge" / "bridge_norm",
+ * laplace/baselaplace.py:637-661: f_var.sum(-1), f_var.sum((1, 2)), diagonal) -- so those links no longer need Jacobians.
+ * Operands as above except: Kronecker posterior S1 [C, .] as above, QB1sq [Cm, C] = (E Q_B1)[r, i]^2,
+ * kappa [Cm] = sum_i (E Q_B1)[r, i]^2 / (f lB1_i + delta_b1);  diagonal posterior S1 [Cm, .] = (E * E) S1,
+ * kappa [Cm] = (E * E) kappa (elementwise squares of E: the posterior is independent across parameters).
+ * f_mu [M, C] stays the model's logits (may be NULL).  Cm <= 4096.                                                  */
+LGNN_API int lgnn_glm_variance_mapped(lgnn_ctx* h, const int64_t* idx, int64_t M, const float* W1m, int64_t Cm,
+                             const float* QA0, const float* QB0, const float* S0, const float* QA1, const float* S1,
+                             const float* QB1sq, const float* kappa, float* f_mu, float* var_mapped, void* stream);
 
 /* ---- decomposition of the fitted factors ("next" row: KronLaplace.fit -> Kron.decompose) ----------
  * Replaces the per-factor torch.linalg.eigh calls of laplace/utils/matrix.py:118-145 (symeig,

@@ -81,7 +81,9 @@ __device__ __forceinline__ float wave_sum_p(float v) {
 //   Zt  [N, ldz]   : ztilde (KRON) / [xhat | rowsum] (diag), F1 = F + 1 columns used
 //   R   [slots, C, H] (KRON) ; dact [N, H] (diag)
 //   S0  [H, F1]    : weights of the squared tile entries (KRON: rotated basis; diag: 1 / prec of W_0 | b_0)
-//   last layer: Pt [M, H] = phitilde (KRON) / phi (diag) of the batch rows; S1 [C, H]; QB1sq [C, C] (KRON) ; kappa [C]
+//   last layer: Pt [M, H] = phitilde (KRON) / phi (diag) of the batch rows; S1 [Ce, H] (KRON) / [C, H]; QB1sq [C, Ce] (KRON);
+//   kappa [C].  C counts the OUTPUT rows -- the model's classes, or the rows of a linear map of the logits whose head E W_1
+//   the caller passes as W1 (lgnn_glm_variance_mapped) -- and Ce = the model's classes (the eigen-directions of B_1)
 //   SAGE = 1: one more staged entry per node (the node itself, weight 1; rows R_self[m] resp. the self half of W_1),
 //   bias column 1 (rowsum == nullptr), last-layer width D1 = 2 H; W1 has row stride ldw, its neighbour half starts at wn_off
 template <int KRON, int SAGE>
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(512) void glm_var_kernel(const int64_t* __restrict_
                                                       const float* __restrict__ Zt, int64_t ldz, int64_t F1,
                                                       const float* __restrict__ R, const float* __restrict__ Rs,
                                                       const float* __restrict__ dact, const float* __restrict__ W1,
-                                                      int64_t ldw, int64_t wn_off, int64_t H, int64_t C, int Hp,
+                                                      int64_t ldw, int64_t wn_off, int64_t H, int64_t C, int64_t Ce, int Hp,
                                                       const float* __restrict__ S0, const float* __restrict__ Pt, int64_t D1,
                                                       const float* __restrict__ S1, const float* __restrict__ QB1sq,
                                                       const float* __restrict__ kappa, const float* __restrict__ rowsum,
@@ -108,13 +110,14 @@ __global__ __launch_bounds__(512) void glm_var_kernel(const int64_t* __restrict_
   float* __restrict__ sy = sm;                       // [PUC][CW] staged p_au * ztilde_u (chunk columns)
   float* __restrict__ syb = sm + size_t(PUC) * CW;   // [PUC] staged p_au * rowsum(P)[u]: the bias column
   float* __restrict__ svar = syb + PUC;              // [C] per-class variance
-  float* __restrict__ sg = svar + C;                 // [H] (diag: g[h]) / [C] scratch (kron: t_i)
-  int32_t* __restrict__ su = reinterpret_cast<int32_t*>(sg + max(int(H), int(C)));  // [PUC] slot / node of the staged neighbours
+  float* __restrict__ sg = svar + C;                 // [H] (diag: g[h]) / [Ce] scratch (kron: t_i)
+  const int nsg = max(int(H), max(int(C), int(Ce)));
+  int32_t* __restrict__ su = reinterpret_cast<int32_t*>(sg + nsg);  // [PUC] slot / node of the staged neighbours
   if (a < 0 || a >= N) {  // flagged by the marking kernel
     for (int c = tid; c < C; c += 512) var_out[m * C + c] = 0.f;
     return;
   }
-  for (int c = tid; c < max(int(C), int(H)); c += 512) { if (c < C) svar[c] = 0.f; sg[c] = 0.f; }
+  for (int c = tid; c < nsg; c += 512) { if (c < C) svar[c] = 0.f; sg[c] = 0.f; }
   const int32_t ps = rowptr[a], pe = rowptr[a + 1];
   const int deg = pe - ps + SAGE;  // GraphSAGE: the node itself is one more entry (the last)
   const int nub = (deg + PUC - 1) / PUC;
@@ -211,9 +214,9 @@ __global__ __launch_bounds__(512) void glm_var_kernel(const int64_t* __restrict_
       var_out[m * C + c] = v + sa * sa * kappa[c];
     }
   } else {
-    // t_i = sum_j phitilde_j^2 S1[i, j]  (i < C), then var_c += sum_i QB1sq[c, i] t_i + s_a^2 kappa_c
+    // t_i = sum_j phitilde_j^2 S1[i, j]  (i < Ce), then var_c += sum_i QB1sq[c, i] t_i + s_a^2 kappa_c
     __syncthreads();
-    for (int c = tid; c < C; c += 512) {
+    for (int c = tid; c < Ce; c += 512) {
       float t = 0.f;
       for (int64_t j = 0; j < D1; ++j) t = fmaf(ph[j] * ph[j], S1[c * D1 + j], t);
       sg[c] = t;
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(512) void glm_var_kernel(const int64_t* __restrict_
     __syncthreads();
     for (int c = tid; c < C; c += 512) {
       float v = svar[c];
-      for (int64_t k = 0; k < C; ++k) v = fmaf(QB1sq[c * C + k], sg[k], v);
+      for (int64_t k = 0; k < Ce; ++k) v = fmaf(QB1sq[c * Ce + k], sg[k], v);
       var_out[m * C + c] = v + sa * sa * kappa[c];
     }
   }
@@ -244,9 +247,11 @@ int sgemm_rm_p(hipStream_t s, int64_t R, int64_t Nout, int64_t K, const float* A
 
 // kron: QA0 [F, F], QB0 [H, H], QA1 [H, H] rotate; diag posterior: the three are null.  S0 [H, F + 1], S1 [C, H],
 // QB1sq [C, C] (kron only), kappa [C].
-int glm_variance(lgnn_ctx* h, const int64_t* idx, int64_t M, const float* QA0, const float* QB0, const float* S0,
-                 const float* QA1, const float* S1, const float* QB1sq, const float* kappa, float* f_mu, float* f_var,
-                 hipStream_t s) {
+// W1m [Cm, in_dim_1] (row major, or null): the head E W_1 of a linear map E [Cm, C] of the logits; f_var is then [M, Cm] =
+// diag(E J P^-1 J^T E^T) and S1 / QB1sq / kappa are the caller's mapped operands (see the header).
+int glm_variance(lgnn_ctx* h, const int64_t* idx, int64_t M, const float* W1m, int64_t Cm, const float* QA0, const float* QB0,
+                 const float* S0, const float* QA1, const float* S1, const float* QB1sq, const float* kappa, float* f_mu,
+                 float* f_var, hipStream_t s) {
   LGNN_REQUIRE(h->L == 2, "matrix-free GLM predictive: 2-layer models");
   LGNN_REQUIRE(!h->extras(), "matrix-free GLM predictive: models without res / norm (use the Jacobian route)");
   LGNN_REQUIRE(M > 0 && idx && S0 && S1 && kappa && f_var, "empty batch or null pointers");
@@ -255,11 +260,14 @@ int glm_variance(lgnn_ctx* h, const int64_t* idx, int64_t M, const float* QA0, c
   LGNN_REQUIRE(!kron || (QB0 && QA1 && QB1sq), "kron posterior needs all eigenvector matrices");
   LGNN_CALL(forward_ensure_aux(h, s));
   // F: width of what the first Linear multiplies (GraphSAGE: the concatenation), D1: the same for the last Linear
-  const int64_t N = h->N, F = h->in_dim[0], H = h->dims[1], C = h->dims[2], F1 = F + 1, D1 = h->in_dim[1];
+  const int64_t N = h->N, F = h->in_dim[0], H = h->dims[1], Ce = h->dims[2], F1 = F + 1, D1 = h->in_dim[1];
   LGNN_REQUIRE(H <= 256, "matrix-free GLM predictive: hidden width <= 256");
+  LGNN_REQUIRE(W1m == nullptr || (Cm > 0 && Cm <= 4096), "mapped GLM predictive: 1 <= rows of the map <= 4096");
+  const int64_t C = W1m ? Cm : Ce;           // output rows
+  const float* W1 = W1m ? W1m : h->W[1];     // their head [C, in_dim_1]
   const int Hp = H <= 64 ? 64 : (H <= 128 ? 128 : 256);
   int* bad = h->ws.flags.as<int>();
-  if (f_mu) LGNN_CALL(launch_gather_rows(h->fc.out.as<float>(), C, N, idx, M, C, f_mu, bad + 2, s));
+  if (f_mu) LGNN_CALL(launch_gather_rows(h->fc.out.as<float>(), Ce, N, idx, M, Ce, f_mu, bad + 2, s));
 
   // ztilde [N, ldz]: E Q_A0 (kron) or E itself (diag), E = P X (GCN) / cat_0 (GraphSAGE); the bias column (rowsum(P) / 1)
   // is read where it is used
@@ -313,21 +321,21 @@ int glm_variance(lgnn_ctx* h, const int64_t* idx, int64_t M, const float* QA0, c
     for (int64_t k0 = 0; k0 < nneed; k0 += chunk) {
       const int64_t kn = std::min<int64_t>(chunk, nneed - k0);
       hipLaunchKernelGGL(pred_dw_kernel, dim3(unsigned(std::min<int64_t>(cdiv(kn * C * H, 256), 8192))), dim3(256), 0, s,
-                         h->ws.act_list.as<int32_t>(), k0, kn, h->fc.dact0.as<float>(), H, h->W[1] + wn_off, ldw, C,
+                         h->ws.act_list.as<int32_t>(), k0, kn, h->fc.dact0.as<float>(), H, W1 + wn_off, ldw, C,
                          h->ws.planes_b.as<float>());
       LGNN_CALL(sgemm_rm_p(s, kn * C, H, H, h->ws.planes_b.as<float>(), H, QB0, H, Rw + k0 * C * H, H));
     }
     for (int64_t m0 = 0; m0 < rows_s; m0 += chunk) {
       const int64_t mn = std::min<int64_t>(chunk, rows_s - m0);
       hipLaunchKernelGGL(pred_dw_self_kernel, dim3(unsigned(std::min<int64_t>(cdiv(mn * C * H, 256), 8192))), dim3(256), 0, s,
-                         idx, m0, mn, N, h->fc.dact0.as<float>(), H, h->W[1], ldw, C, h->ws.planes_b.as<float>());
+                         idx, m0, mn, N, h->fc.dact0.as<float>(), H, W1, ldw, C, h->ws.planes_b.as<float>());
       LGNN_CALL(sgemm_rm_p(s, mn * C, H, H, h->ws.planes_b.as<float>(), H, QB0, H, Rsw + m0 * C * H, H));
     }
     R = Rw;
     Rs = Rsw;
   }
   const int NG = 512 / Hp, CW = NG * PJT;
-  const size_t smem = (size_t(PUC) * CW + PUC + size_t(C) + size_t(std::max<int64_t>(H, C)) + PUC) * 4;
+  const size_t smem = (size_t(PUC) * CW + PUC + size_t(C) + size_t(std::max<int64_t>(H, std::max(C, Ce))) + PUC) * 4;
   LGNN_REQUIRE(smem <= 150 * 1024, "matrix-free GLM predictive: tile does not fit LDS");
   const float* rowsum = sage ? nullptr : h->fc.rowsum.as<float>();
 #define LGNN_GLM_VAR(K, S)                                                                                                   \
@@ -339,7 +347,7 @@ int glm_variance(lgnn_ctx* h, const int64_t* idx, int64_t M, const float* QA0, c
       attr = true;                                                                                                           \
     }                                                                                                                        \
     hipLaunchKernelGGL((glm_var_kernel<K, S>), dim3(unsigned(M)), dim3(512), smem, s, idx, M, N, h->P.rowptr, h->P.col,      \
-                       h->P.val, slot, Zt, ldz, F1, R, Rs, h->fc.dact0.as<float>(), h->W[1], ldw, wn_off, H, C, Hp, S0, Pt,  \
+                       h->P.val, slot, Zt, ldz, F1, R, Rs, h->fc.dact0.as<float>(), W1, ldw, wn_off, H, C, Ce, Hp, S0, Pt,   \
                        D1, S1, QB1sq, kappa, rowsum, f_var);                                                                 \
   } while (0)
   if (kron && sage) LGNN_GLM_VAR(1, 1);
@@ -357,5 +365,15 @@ extern "C" int lgnn_glm_variance(lgnn_ctx* h, const int64_t* idx, int64_t M, con
                                  const float* QA1, const float* S1, const float* QB1sq, const float* kappa, float* f_mu,
                                  float* f_var_diag, void* stream) {
   if (!h) { lgnn::set_error("null context"); return 2; }
-  return lgnn::glm_variance(h, idx, M, QA0, QB0, S0, QA1, S1, QB1sq, kappa, f_mu, f_var_diag, static_cast<hipStream_t>(stream));
+  return lgnn::glm_variance(h, idx, M, nullptr, 0, QA0, QB0, S0, QA1, S1, QB1sq, kappa, f_mu, f_var_diag,
+                            static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lgnn_glm_variance_mapped(lgnn_ctx* h, const int64_t* idx, int64_t M, const float* W1m, int64_t Cm, const float* QA0,
+                                        const float* QB0, const float* S0, const float* QA1, const float* S1, const float* QB1sq,
+                                        const float* kappa, float* f_mu, float* var_mapped, void* stream) {
+  if (!h) { lgnn::set_error("null context"); return 2; }
+  if (!W1m) { lgnn::set_error("lgnn_glm_variance_mapped: null head of the map"); return 2; }
+  return lgnn::glm_variance(h, idx, M, W1m, Cm, QA0, QB0, S0, QA1, S1, QB1sq, kappa, f_mu, var_mapped,
+                            static_cast<hipStream_t>(stream));
 }

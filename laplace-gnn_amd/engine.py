@@ -517,19 +517,30 @@ class GraphEngine:
         _lib.check(rc, "lgnn_adjgrad_finish")
         return out if cand is None else (out, cout)
 
-    def glm_variance(self, idx: torch.Tensor, S0, S1, kappa, QA0=None, QB0=None, QA1=None, QB1sq=None):
-        """Matrix-free GLM predictive of a 2-layer GCN: (f_mu [M, C], diag(J P^-1 J^T) [M, C]) from the closed-form
-        Jacobian (see include/laplace_gnn_hip.h lgnn_glm_variance for the operand conventions)."""
+    def glm_variance(self, idx: torch.Tensor, S0, S1, kappa, QA0=None, QB0=None, QA1=None, QB1sq=None, out_map=None):
+        """Matrix-free GLM predictive of a 2-layer GCN / GraphSAGE: (f_mu [M, C], diag(J P^-1 J^T) [M, C]) from the closed-form
+        Jacobian (see include/laplace_gnn_hip.h lgnn_glm_variance for the operand conventions).  ``out_map`` = E [Cm, C]:
+        the variances of the linear map E f instead, [M, Cm]; S1 / QB1sq / kappa are then the caller's mapped operands
+        (lgnn_glm_variance_mapped)."""
         self._sync_versions()
         idx = idx.contiguous()
         M, C = idx.shape[0], self.dims[-1]
+        Cm = C if out_map is None else int(out_map.shape[0])
         f_mu = torch.empty(M, C, dtype=torch.float32, device=self.device)
-        f_var = torch.empty(M, C, dtype=torch.float32, device=self.device)
+        f_var = torch.empty(M, Cm, dtype=torch.float32, device=self.device)
         keep = [t.contiguous().to(torch.float32) if t is not None else None for t in (QA0, QB0, S0, QA1, S1, QB1sq, kappa)]
         ptr = [None if t is None else _dev_ptr(t, torch.float32, "posterior operand") for t in keep]
-        rc = self.lib.lgnn_glm_variance(self._h, _dev_ptr(idx, torch.int64, "idx"), M, *ptr, f_mu.data_ptr(), f_var.data_ptr(),
-                                        _stream(self.device))
-        _lib.check(rc, "lgnn_glm_variance")
+        if out_map is None:
+            rc = self.lib.lgnn_glm_variance(self._h, _dev_ptr(idx, torch.int64, "idx"), M, *ptr, f_mu.data_ptr(),
+                                            f_var.data_ptr(), _stream(self.device))
+            _lib.check(rc, "lgnn_glm_variance")
+            return f_mu, f_var
+        if out_map.ndim != 2 or out_map.shape[1] != C:
+            raise ValueError(f"out_map must be [rows, {C}]")
+        W1m = (out_map.to(device=self.device, dtype=torch.float32) @ self._bound[1][-1].detach().to(torch.float32)).contiguous()
+        rc = self.lib.lgnn_glm_variance_mapped(self._h, _dev_ptr(idx, torch.int64, "idx"), M, W1m.data_ptr(), Cm, *ptr,
+                                               f_mu.data_ptr(), f_var.data_ptr(), _stream(self.device))
+        _lib.check(rc, "lgnn_glm_variance_mapped")
         return f_mu, f_var
 
     def check_async_errors(self):

@@ -296,23 +296,40 @@ class ParametricLaplace(BaseLaplace):
     def functional_variance(self, Js: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
 
-    def _matrix_free_operands(self):
-        """Operands of ``GraphEngine.glm_variance`` for this posterior, or None when the matrix-free route does not apply."""
+    def _matrix_free_operands(self, out_map=None):
+        """Operands of ``GraphEngine.glm_variance`` for this posterior (mapped by ``out_map`` = E [Cm, C] where they depend on
+        the outputs), or None when the matrix-free route does not apply."""
         return None
 
-    def _glm_variance_matrix_free(self, x):
+    def _glm_variance_matrix_free(self, x, out_map=None):
         """(f_mu [M, C], diag f_var [M, C]) without Jacobians (csrc/predictive.hip), or None: 2-layer GCN / GraphSAGE models
-        with a ReLU, hidden width <= 256, classification, Kronecker or diagonal posterior over all weights."""
+        with a ReLU, hidden width <= 256, classification, Kronecker or diagonal posterior over all weights.  ``out_map`` =
+        E [Cm, C]: the variances of E f instead ([M, Cm])."""
         eng = getattr(self.backend, "engine", None)
         if (eng is None or not hasattr(eng, "glm_variance") or getattr(eng, "kind", None) not in ("gcn", "sage") or len(eng.dims) != 3
                 or getattr(eng, "has_extras", False)
                 or eng.dims[1] > 256 or getattr(eng, "_bind_opts", ("relu",))[0] != "relu" or self.likelihood != "classification"):
             return None
-        ops = self._matrix_free_operands()
+        ops = self._matrix_free_operands(out_map)
         if ops is None:
             return None
         eng.set_likelihood("classification")
-        return eng.glm_variance(x, **ops)
+        return eng.glm_variance(x, **ops) if out_map is None else eng.glm_variance(x, out_map=out_map, **ops)
+
+    def _bridge_moments_matrix_free(self, x):
+        """What the Laplace bridge reads of the C x C predictive covariance S (laplace/baselaplace.py:637-661) -- its diagonal,
+        its row sums S 1 and its total 1^T S 1 -- without Jacobians, or None.  One matrix-free pass over the 2 C + 1 outputs
+        E f, E = [I ; 1^T / C ; I + 1 1^T / C]: with m = mean(f), var(f_c + m) - var(f_c) - var(m) = 2 cov(f_c, m) = 2 (S 1)_c / C
+        and 1^T S 1 = C^2 var(m) (polarisation against the MEAN keeps the three terms at the same magnitude)."""
+        C = self.n_outputs
+        eye = torch.eye(C, device=self._device)
+        ones = torch.full((1, C), 1.0 / C, device=self._device)
+        fast = self._glm_variance_matrix_free(x, out_map=torch.cat([eye, ones, eye + ones], dim=0))
+        if fast is None:
+            return None
+        f_mu, v = fast
+        diag, vm, vsum = v[:, :C], v[:, C:C + 1], v[:, C + 1:]
+        return f_mu, diag, 0.5 * C * (vsum - diag - vm), (C * C) * vm.squeeze(1)
 
     def _glm_predictive_distribution(self, x, diagonal_output: bool = False):
         """(f_mu [M, C], f_var [M, C, C]) (laplace/baselaplace.py:1123-1158); ``diagonal_output``: f_var [M, C], matrix free
@@ -335,14 +352,21 @@ class ParametricLaplace(BaseLaplace):
             f_mu, f_var_diag = self._glm_predictive_distribution(x, diagonal_output=True)
             kappa = 1 / torch.sqrt(1.0 + pi / 8 * f_var_diag)
             return torch.softmax(kappa * f_mu, dim=-1)
-        f_mu, f_var = self._glm_predictive_distribution(x)
         if link_approx == "mc":
+            if diagonal_output:  # samples of N(f_mu, diag f_var): the diagonal is all that is read (:667-709)
+                f_mu, f_var_diag = self._glm_predictive_distribution(x, diagonal_output=True)
+                return self._glm_predictive_samples(f_mu, f_var_diag, n_samples, False, generator, eps).mean(dim=0)
+            f_mu, f_var = self._glm_predictive_distribution(x)
             return self._glm_predictive_samples(f_mu, f_var, n_samples, diagonal_output, generator, eps).mean(dim=0)
-        # Laplace bridge with zero-mean correction (:630-660)
-        f_mu = f_mu - (f_var.sum(-1) * f_mu.sum(-1).reshape(-1, 1) / f_var.sum(dim=(1, 2)).reshape(-1, 1))
-        f_var = f_var - torch.einsum("bi,bj->bij", f_var.sum(-1), f_var.sum(-2)) / f_var.sum(dim=(1, 2)).reshape(-1, 1, 1)
+        # Laplace bridge with zero-mean correction (:630-660): reads the diagonal, the row sums and the total of f_var only
+        moments = self._bridge_moments_matrix_free(x)
+        if moments is None:
+            f_mu, f_var = self._glm_predictive_distribution(x)
+            moments = (f_mu, torch.diagonal(f_var, dim1=1, dim2=2), f_var.sum(-1), f_var.sum(dim=(1, 2)))
+        f_mu, f_var_diag, rows, total = moments  # (symmetric f_var: f_var.sum(-1) == f_var.sum(-2))
+        f_mu = f_mu - rows * f_mu.sum(-1).reshape(-1, 1) / total.reshape(-1, 1)
+        f_var_diag = f_var_diag - rows * rows / total.reshape(-1, 1)
         K = f_mu.size(-1)
-        f_var_diag = torch.diagonal(f_var, dim1=1, dim2=2).clone()
         if link_approx == "bridge_norm":
             f_var_diag_mean = f_var_diag.mean(dim=1)
             f_var_diag_mean = f_var_diag_mean / torch.as_tensor([K / 2], device=self._device).sqrt()
@@ -789,7 +813,7 @@ class KronLaplace(ParametricLaplace):
     def log_det_posterior_precision(self) -> torch.Tensor:
         return self.posterior_precision.logdet()
 
-    def _matrix_free_operands(self):
+    def _matrix_free_operands(self, out_map=None):
         H = self.H
         if not isinstance(H, KronDecomposed) or H.damping or len(H.eigenvalues) != 4:
             return None
@@ -804,6 +828,9 @@ class KronLaplace(ParametricLaplace):
         f = self._H_factor
         S0 = torch.cat([1.0 / (f * torch.outer(lB0, lA0) + d[0]), (1.0 / (f * lB0b + d[1])).unsqueeze(1)], dim=1)
         S1 = 1.0 / (f * torch.outer(lB1, lA1) + d[2])
+        if out_map is not None:  # the rows of E f: E Q_B takes Q_B's place in the last-layer blocks
+            E = out_map.to(QB1)
+            QB1, QB1b = E @ QB1, E @ QB1b
         kappa = (QB1b * QB1b) @ (1.0 / (f * lB1b + d[3]))
         return dict(S0=S0, S1=S1, kappa=kappa, QA0=QA0, QB0=QB0, QA1=QA1, QB1sq=QB1 * QB1)
 
@@ -868,7 +895,7 @@ class DiagLaplace(ParametricLaplace):
     def log_det_posterior_precision(self) -> torch.Tensor:
         return self.posterior_precision.log().sum()
 
-    def _matrix_free_operands(self):
+    def _matrix_free_operands(self, out_map=None):
         shapes = [tuple(p.shape) for p in self.params]
         if len(shapes) != 4:
             return None
@@ -878,7 +905,11 @@ class DiagLaplace(ParametricLaplace):
         w0 = inv[o:o + Hd * F].view(Hd, F); o += Hd * F
         b0 = inv[o:o + Hd].view(Hd, 1); o += Hd
         w1 = inv[o:o + C * D1].view(C, D1); o += C * D1
-        return dict(S0=torch.cat([w0, b0], dim=1), S1=w1, kappa=inv[o:o + C])
+        b1 = inv[o:o + C]
+        if out_map is not None:  # independent parameters: the variance of a combination weighs each class by E^2
+            E2 = out_map.to(w1).square()
+            w1, b1 = E2 @ w1, E2 @ b1
+        return dict(S0=torch.cat([w0, b0], dim=1), S1=w1, kappa=b1)
 
     def _scale_samples(self, eps):  # laplace/baselaplace.py:1912-1919: samples * posterior_scale
         return eps * (1.0 / self.posterior_precision.sqrt()).reshape(1, self.n_params)

@@ -486,6 +486,47 @@ def test_matrix_free_glm_variance_matches_the_jacobian_route_and_the_reference(n
     model.engine.check_async_errors()
 
 
+@pytest.mark.parametrize("name", ["gcn_small_1batch_s0", "gcn_mid_3batch_sym_s1", "gcn_small_isolated_s0",
+                                  "sage_small_3batch_s1", "sage_mid_2batch_s2"])
+def test_laplace_bridge_without_jacobians_matches_the_reference(name):
+    """link_approx "bridge" / "bridge_norm" read the diagonal, the row sums and the total of the C x C predictive covariance
+    (laplace/baselaplace.py:637-661): one matrix-free pass over 2 C + 1 linear outputs (lgnn_glm_variance_mapped) gives them.
+    Against (a) the reference's f_var golden reduced the same way, (b) the reference's bridge / bridge_norm outputs, (c) this
+    package's Jacobian route with a per-block prior.  fp32 <= 1e-4 relative."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = model_from_golden(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(),
+                                  batch_size=int(g["batch_size"]))
+    x = torch.from_numpy(g["pred_idx"]).cuda()
+    for cls, key in ((lg.KronLaplace, "kron"), (lg.DiagLaplace, "diag")):
+        la = cls(model, "classification")
+        la.fit(loader)
+        moments = la._bridge_moments_matrix_free(x)
+        assert moments is not None
+        f_mu, diag, rows, total = (t.cpu().numpy() for t in moments)
+        gold = g[key + "_glm_fvar"]
+        assert rel(f_mu, g[key + "_glm_fmu"]) < 1e-5
+        assert rel(diag, np.diagonal(gold, axis1=1, axis2=2)) < 1e-4, key
+        assert rel(rows, gold.sum(-1)) < 1e-4 and rel(total, gold.sum((1, 2))) < 1e-4, key
+        for link in ("bridge", "bridge_norm"):
+            assert rel(la(x, link_approx=link).cpu().numpy(), g[f"{key}_glm_{link}"]) < 1e-4, (key, link)
+        # per-block / per-parameter prior: against the Jacobian route (what a backend without the mapped call would take)
+        la.prior_precision = torch.tensor([0.5, 2.0, 1.5, 0.25]) if cls is lg.KronLaplace else 0.3
+        fast = {link: la(x, link_approx=link) for link in ("bridge", "bridge_norm")}
+        la._bridge_moments_matrix_free = lambda x: None
+        for link, out in fast.items():
+            assert rel(out.cpu().numpy(), la(x, link_approx=link).cpu().numpy()) < 1e-4, (key, link)
+        # samples of N(f_mu, diag f_var) read the diagonal only: the same draws through both routes
+        eps = torch.from_numpy(g["glm_eps"]).cuda()
+        a = la(x, link_approx="mc", diagonal_output=True, eps=eps)
+        f_mu_j, f_var_j = la._glm_predictive_distribution(x)
+        b = la._glm_predictive_samples(f_mu_j, f_var_j, eps.shape[1], True, None, eps).mean(dim=0)
+        assert rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
+    model.engine.check_async_errors()
+
+
 def test_decomposition_groups_small_factors_and_caches_large_ones():
     """Kron.decompose on the GPU: factors of up to 256 rows share one call of the hand-written path, larger ones (a
     Cora-shaped model's 1 433 x 1 433 input covariance) get a call of their own and are served from the CALLER's cache under

@@ -530,6 +530,21 @@ def test_glm_predictive_on_every_node_of_the_arxiv_shape(arxiv):
     assert rel(f_vd.cpu().numpy(), ref.cpu().numpy()) < 1e-4 and rel(f_mu.cpu().numpy(), f.cpu().numpy()) < 1e-6
     print(f"GLM predictive of {w['N']} nodes: {dt * 1e3:.1f} ms")
     assert dt < 30.0
+    # the Laplace bridge on every node: 2 C + 1 mapped outputs per node instead of the C x C covariance (lgnn_glm_variance_mapped)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bridge = la(every, link_approx="bridge_norm")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert bridge.shape == (w["N"], w["C"]) and bool(torch.isfinite(bridge).all())
+    assert float((bridge.sum(-1) - 1).abs().max()) < 1e-4
+    fv = la.functional_variance(Js)
+    _, diag, rows, total = la._bridge_moments_matrix_free(sub)
+    assert rel(diag.cpu().numpy(), ref.cpu().numpy()) < 1e-4
+    assert rel(rows.cpu().numpy(), fv.sum(-1).cpu().numpy()) < 1e-4 and rel(total.cpu().numpy(), fv.sum((1, 2)).cpu().numpy()) < 1e-4
+    assert rel(bridge[sub].cpu().numpy(), la(sub, link_approx="bridge_norm").cpu().numpy()) < 1e-5
+    print(f"Laplace bridge of {w['N']} nodes: {dt * 1e3:.1f} ms")
+    assert dt < 60.0
 
 
 # ---- independent reference of the dominant kernel's output at the headline shape -------------------
