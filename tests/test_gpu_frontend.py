@@ -527,6 +527,34 @@ def test_laplace_bridge_without_jacobians_matches_the_reference(name):
     model.engine.check_async_errors()
 
 
+@pytest.mark.parametrize("name,rows", [("gcn_mid_1batch_s0", 1), ("gcn_small_3batch_s1", 100), ("sage_mid_2batch_s2", 19)])
+def test_variances_of_an_arbitrary_linear_map_of_the_logits(name, rows):
+    """lgnn_glm_variance_mapped with a random E [rows, C] (fewer and more rows than classes): diag(E S E^T) against the Jacobian
+    route's full covariance S, Kronecker (per-block prior) and diagonal posterior; the logits it returns stay the model's."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = model_from_golden(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(),
+                                  batch_size=int(g["batch_size"]))
+    x = torch.from_numpy(g["pred_idx"]).cuda()
+    for cls in (lg.KronLaplace, lg.DiagLaplace):
+        la = cls(model, "classification")
+        la.fit(loader)
+        la.prior_precision = torch.tensor([0.5, 2.0, 1.5, 0.25]) if cls is lg.KronLaplace else 0.7
+        E = torch.randn(rows, la.n_outputs, generator=torch.Generator().manual_seed(rows)).cuda()
+        f_mu, v = la._glm_variance_matrix_free(x, out_map=E)
+        Js, f_j = la.backend.jacobians(x)
+        S = la.functional_variance(Js).double()
+        ref = torch.einsum("rc,mcd,rd->mr", E.double(), S, E.double())
+        assert v.shape == (x.numel(), rows)
+        assert rel(v.cpu().numpy(), ref.cpu().numpy()) < 1e-4, cls.__name__
+        assert rel(f_mu.cpu().numpy(), f_j.cpu().numpy()) < 1e-6
+    with pytest.raises(ValueError, match="out_map"):
+        model.engine.glm_variance(x, **la._matrix_free_operands(), out_map=torch.ones(3, la.n_outputs + 1).cuda())
+    model.engine.check_async_errors()
+
+
 def test_decomposition_groups_small_factors_and_caches_large_ones():
     """Kron.decompose on the GPU: factors of up to 256 rows share one call of the hand-written path, larger ones (a
     Cora-shaped model's 1 433 x 1 433 input covariance) get a call of their own and are served from the CALLER's cache under
