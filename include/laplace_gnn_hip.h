@@ -309,6 +309,25 @@ LGNN_API int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float*
                         float a_scale, float* grad_P, float* grad_adj, const int32_t* cand_a, const int32_t* cand_b,
                         int64_t num_cand, float* grad_cand, float* grad_cand_adj, void* stream);
 
+/* The same gradient under a DIAGONAL posterior -- what the shipped STE-GCN configuration differentiates
+ * (gnn/configs/original/stegcn_config.yaml:7 hessian_structure: diag; gnn/marglik_training.py:197-216 with DiagLaplace,
+ * laplace/baselaplace.py:1848-1857; the fork's GGNInterface.jacobians keeps the graph, laplace/curvature/curvature.py:89-130,
+ * so diag() (:412-432) is differentiable in the adjacency).  2-layer GCN, ReLU, classification.
+ *   gamma [n_params] (parameter order W_0, b_0, W_1, b_1) = d(-marglik)/dH_p = f / (2 (f H_p + delta_p)), f = H_factor;
+ *   per batch :  grad_P [nnz] += the terms on the stored entries of the batch nodes' rows;  out_bar [N, C] += d/d(logits) of
+ *                loss_scale * CE and of the softmax inside the GGN;  h1_bar [N, H] += d/dH_1 and e_bar [N, F + 1] +=
+ *                d/d[P X | rowsum(P)] of the closed-form diagonal;  candidates as above;
+ *   once      :  lgnn_diag_adjgrad_finish propagates out_bar, h1_bar and e_bar through the forward pass into grad_P and writes
+ *                grad_adj [nnz] / grad_cand_adj exactly like lgnn_adjgrad_finish.
+ * Workspace: [chunk][H][F + 1] floats for the first-layer tiles of a chunk of samples (0.5 GB for a Cora-shaped batch), under the
+ * workspace limit.                                                                                                   */
+LGNN_API int lgnn_diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, const float* gamma,
+                            float loss_scale, float* grad_P, float* out_bar, float* h1_bar, float* e_bar,
+                            const int32_t* cand_a, const int32_t* cand_b, int64_t num_cand, float* grad_cand, void* stream);
+LGNN_API int lgnn_diag_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* h1_bar, const float* e_bar, float* grad_P,
+                             float* grad_adj, const int32_t* cand_a, const int32_t* cand_b, int64_t num_cand,
+                             float* grad_cand, float* grad_cand_adj, void* stream);
+
 /* ---- matrix-free GLM predictive ("next" row 8(f)-3 at scale) -------------------------------------------------------
  * Replaces the Jacobian route of the default la(x) (laplace/baselaplace.py:1123-1158 + laplace/utils/matrix.py:396-451 resp.
  * baselaplace.py:1901-1903) for 2-layer GCN and GraphSAGE models: f_mu [M, C] = logits and f_var_diag [M, C] = diag(J P^-1 J^T) per

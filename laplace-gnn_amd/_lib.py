@@ -57,6 +57,8 @@ SIGNATURES = {
     "lgnn_kernel_timing_read": (_i32, [_vp, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "lgnn_kfac_adjgrad_batch": (_i32, [_vp, _vp, _vp, _i64, _u32, _pp, C.c_float, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "lgnn_adjgrad_finish": (_i32, [_vp, _vp, _pp, C.c_float, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "lgnn_diag_adjgrad_batch": (_i32, [_vp, _vp, _vp, _i64, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "lgnn_diag_adjgrad_finish": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "lgnn_glm_variance": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lgnn_glm_variance_mapped": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lgnn_symeig_batched": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),

@@ -1098,12 +1098,313 @@ int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   return 0;
 }
 
+namespace {
+// ---------------------------------------------------------------------------------------------------------------------------
+// Diagonal posterior (DiagLaplace on an STE-GCN: the shipped gnn/configs/original/stegcn_config.yaml:7).  With
+// gamma_p = f / (2 (H_p f + delta_p)) held fixed (f = the likelihood's H_factor), d(-marglik) = f dCE + sum_p gamma_p dH_p, and the diagonal GGN of a
+// 2-layer GCN is closed form per batch sample n (laplace/curvature/curvature.py:412-432 with the fork's
+// attached Jacobians, :89-130), Ee = [P X | rowsum(P)], H1e = [H_1 | 1], g0e [H, F+1] / g1e [C, H+1] = gamma by (W | b) rows:
+//     T_n[j, :] = sum_v P[n, v] mask[v, j] Ee[v, :]      H_{W0|b0}[j, :] += q_n[j] T_n[j, :]^2
+//     phi_n     = (P H1e)[n]                             H_{W1|b1}[c, :] += p_c (1 - p_c) phi_n^2
+//     q_n[j]    = sum_c p_c W1[c, j]^2 - (sum_c p_c W1[c, j])^2,   p_n = softmax(f_n)
+// Reverse, per sample (oracle: diag_marglik_adj_grad, pinned to the reference's model.adj.grad):
+//     r[j] = sum_i g0e[j, i] T[j, i]^2      a[c] = sum_j g1e[c, j] phi[j]^2
+//     pbar[c] = (1 - 2 p_c) a[c] + sum_j r[j] (W1[c, j]^2 - 2 W1[c, j] m[j]),  m = p W1;   fbar = p * pbar - p (p . pbar) + CE'
+//     phibar = 2 phi * (sum_c p_c (1 - p_c) g1e[c, :])        Tbar[j, :] = 2 q[j] g0e[j, :] T[j, :]
+//     gradP[(n, v)] += sum_j mask[v, j] <Tbar[j, :], Ee[v, :]> + <phibar, H1e[v]>
+//     h1_bar[v] += P[n, v] phibar[:H]        e_bar[v, :] += P[n, v] sum_j mask[v, j] Tbar[j, :]
+// (h1_bar, e_bar and out_bar are propagated once per fit by adjgrad_finish.)  T of a chunk of samples lives in the workspace
+// ([chunk][H][F + 1] floats: 0.5 GB for a Cora-shaped batch); one workgroup per sample throughout.
+
+__global__ void add_inplace_kernel(float* __restrict__ x, const float* __restrict__ y, int64_t n) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t q = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; q < n; q += stride) x[q] += y[q];
+}
+
+// gradP[p] += c[a] for every entry p of row a (c has row stride ld);  candidates (a, b): grad_cand[k] += c[a]
+__global__ __launch_bounds__(256) void row_const_kernel(const int32_t* __restrict__ rowptr, int64_t N, const float* __restrict__ c,
+                                                        int64_t ld, float* __restrict__ gradP, const int32_t* __restrict__ ca,
+                                                        int64_t K, float* __restrict__ grad_cand) {
+  const int lane = threadIdx.x & 63;
+  const int64_t a = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (a < N) {
+    const float v = c[a * ld];
+    for (int32_t p = rowptr[a] + lane; p < rowptr[a + 1]; p += 64) gradP[p] += v;
+  }
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; k < K; k += stride) grad_cand[k] += c[int64_t(ca[k]) * ld];
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {  // red: 4 floats of LDS; every thread gets the sum
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();  // (red may still be read from the previous call)
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// T[m][j][i] = sum_v P[n, v] mask[v, j] Ee[v, i], n = idx[m0 + m]; the row's entries are staged VCH at a time
+__global__ __launch_bounds__(256) void dadj_T_kernel(const int64_t* __restrict__ idx, int64_t m0, int64_t N,
+                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                     const float* __restrict__ val, const float* __restrict__ mask, int64_t H,
+                                                     const float* __restrict__ PX, int64_t ldx, const float* __restrict__ rowsum,
+                                                     int64_t F, int VCH, float* __restrict__ T) {
+  extern __shared__ float sm[];
+  const int64_t F1 = F + 1, HF = H * F1;
+  float* __restrict__ wv = sm;                    // [VCH]
+  float* __restrict__ mk = wv + VCH;              // [VCH][H]
+  float* __restrict__ ev = mk + int64_t(VCH) * H; // [VCH][F1]
+  const int64_t n = idx[m0 + blockIdx.x];
+  float* __restrict__ Tm = T + int64_t(blockIdx.x) * HF;
+  const int tid = threadIdx.x;
+  if (n < 0 || n >= N) {  // flagged by the prologue
+    for (int64_t e = tid; e < HF; e += 256) Tm[e] = 0.f;
+    return;
+  }
+  const int32_t ps = rowptr[n], pe = rowptr[n + 1];
+  if (ps == pe)
+    for (int64_t e = tid; e < HF; e += 256) Tm[e] = 0.f;
+  for (int32_t p0 = ps; p0 < pe; p0 += VCH) {
+    const int un = min(VCH, pe - p0);
+    __syncthreads();
+    for (int64_t t = tid; t < int64_t(un) * (H + F1); t += 256) {
+      const int u = int(t / (H + F1));
+      const int64_t k = t - int64_t(u) * (H + F1);
+      const int64_t v = col[p0 + u];
+      if (k < H) mk[int64_t(u) * H + k] = mask[v * H + k];
+      else ev[int64_t(u) * F1 + (k - H)] = (k - H) < F ? PX[v * ldx + (k - H)] : rowsum[v];
+    }
+    if (tid < un) wv[tid] = val[p0 + tid];
+    __syncthreads();
+    for (int64_t e = tid; e < HF; e += 256) {
+      const int64_t j = e / F1, i = e - j * F1;
+      float acc = p0 == ps ? 0.f : Tm[e];
+      for (int u = 0; u < un; ++u) acc = fmaf(wv[u] * mk[int64_t(u) * H + j], ev[int64_t(u) * F1 + i], acc);
+      Tm[e] = acc;
+    }
+  }
+}
+
+// per sample: the adjoint of the logits (into out_bar), phibar [H + 1] and T -> Tbar in place
+__global__ __launch_bounds__(256) void dadj_sample_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
+                                                          int64_t m0, int64_t N, const float* __restrict__ probs, int64_t C,
+                                                          int64_t H, int64_t F, const float* __restrict__ W1,
+                                                          const float* __restrict__ PH, int64_t ldp,
+                                                          const float* __restrict__ rowsum, const float* __restrict__ gamma,
+                                                          float loss_scale, float* __restrict__ T, float* __restrict__ phibar,
+                                                          float* __restrict__ out_bar) {
+  extern __shared__ float sm[];
+  const int64_t F1 = F + 1, HF = H * F1, H1 = H + 1;
+  float* __restrict__ r = sm;          // [H]
+  float* __restrict__ q = r + H;       // [H]
+  float* __restrict__ mv = q + H;      // [H]
+  float* __restrict__ phi = mv + H;    // [H + 1]
+  float* __restrict__ p = phi + H1;    // [C]
+  float* __restrict__ a = p + C;       // [C]
+  float* __restrict__ pb = a + C;      // [C]
+  float* __restrict__ red = pb + C;    // [4]
+  const float* __restrict__ g0 = gamma;
+  const float* __restrict__ gb0 = g0 + H * F;
+  const float* __restrict__ g1 = gb0 + H;
+  const float* __restrict__ gb1 = g1 + C * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m = m0 + blockIdx.x;
+  const int64_t n = idx[m];
+  float* __restrict__ Tm = T + int64_t(blockIdx.x) * HF;
+  float* __restrict__ pbm = phibar + int64_t(blockIdx.x) * H1;
+  if (n < 0 || n >= N) {
+    for (int64_t j = tid; j < H1; j += 256) pbm[j] = 0.f;
+    return;  // T is zero already
+  }
+  for (int64_t c = tid; c < C; c += 256) p[c] = probs[m * C + c];
+  for (int64_t j = tid; j < H1; j += 256) phi[j] = j < H ? PH[n * ldp + j] : rowsum[n];
+  // r[j] = sum_i g0e[j, i] T[j, i]^2
+  for (int64_t j = wave; j < H; j += 4) {
+    float acc = 0.f;
+    for (int64_t i = lane; i < F1; i += 64) {
+      const float t = Tm[j * F1 + i];
+      acc = fmaf((i < F ? g0[j * F + i] : gb0[j]) * t, t, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) r[j] = acc;
+  }
+  __syncthreads();
+  for (int64_t j = tid; j < H; j += 256) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t c = 0; c < C; ++c) {
+      const float w = W1[c * H + j];
+      s1 = fmaf(p[c], w, s1);
+      s2 = fmaf(p[c] * w, w, s2);
+    }
+    mv[j] = s1;
+    q[j] = s2 - s1 * s1;
+  }
+  for (int64_t c = wave; c < C; c += 4) {
+    float acc = 0.f;
+    for (int64_t j = lane; j < H1; j += 64) acc = fmaf((j < H ? g1[c * H + j] : gb1[c]) * phi[j], phi[j], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) a[c] = acc;
+  }
+  __syncthreads();
+  for (int64_t c = wave; c < C; c += 4) {
+    float acc = 0.f;
+    for (int64_t j = lane; j < H; j += 64) {
+      const float w = W1[c * H + j];
+      acc = fmaf(r[j], w * w - 2.f * w * mv[j], acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) pb[c] = (1.f - 2.f * p[c]) * a[c] + acc;
+  }
+  __syncthreads();
+  float part = 0.f;
+  for (int64_t c = tid; c < C; c += 256) part = fmaf(p[c], pb[c], part);
+  const float dot = block_sum_256(part, red);
+  const int64_t yc = y[m];
+  for (int64_t c = tid; c < C; c += 256)
+    atomicAdd(&out_bar[n * C + c], p[c] * (pb[c] - dot) + loss_scale * (p[c] - (c == yc ? 1.f : 0.f)));
+  for (int64_t j = tid; j < H1; j += 256) {
+    float lg = 0.f;
+    for (int64_t c = 0; c < C; ++c) lg = fmaf(p[c] * (1.f - p[c]), j < H ? g1[c * H + j] : gb1[c], lg);
+    pbm[j] = 2.f * phi[j] * lg;
+  }
+  for (int64_t e = tid; e < HF; e += 256) {
+    const int64_t j = e / F1, i = e - j * F1;
+    Tm[e] *= 2.f * q[j] * (i < F ? g0[j * F + i] : gb0[j]);
+  }
+}
+
+// value of one (sample, column node v) pair: sum_j mask[v, j] <Tbar[j, :], Ee[v, :]> + <phibar, H1e[v]>; optionally the
+// scatter adjoints of that entry (weight w = P[n, v]).  mk: [H] floats of LDS.  Every thread returns the value.
+__device__ __forceinline__ float dadj_pair(const float* __restrict__ Tm, const float* __restrict__ pbm, int64_t v, int64_t H,
+                                           int64_t F, const float* __restrict__ mask, const float* __restrict__ PX, int64_t ldx,
+                                           const float* __restrict__ rowsum, const float* __restrict__ H1p, int64_t ldh, float w,
+                                           float* __restrict__ h1_bar, float* __restrict__ e_bar, float* __restrict__ mk,
+                                           float* __restrict__ red) {
+  const int tid = threadIdx.x;
+  const int64_t F1 = F + 1;
+  __syncthreads();
+  for (int64_t j = tid; j < H; j += 256) mk[j] = mask[v * H + j];
+  __syncthreads();
+  float part = 0.f;
+  for (int64_t i = tid; i < F1; i += 256) {
+    float ca = 0.f;
+    for (int64_t j = 0; j < H; ++j)
+      if (mk[j] != 0.f) ca = fmaf(mk[j], Tm[j * F1 + i], ca);
+    part = fmaf(ca, i < F ? PX[v * ldx + i] : rowsum[v], part);
+    if (e_bar && ca != 0.f) atomicAdd(&e_bar[v * F1 + i], w * ca);
+  }
+  for (int64_t j = tid; j < H; j += 256) {
+    part = fmaf(pbm[j], H1p[v * ldh + j], part);
+    if (h1_bar) atomicAdd(&h1_bar[v * H + j], w * pbm[j]);
+  }
+  if (tid == 0) part += pbm[H];
+  return block_sum_256(part, red);
+}
+
+__global__ __launch_bounds__(256) void dadj_entry_kernel(const int64_t* __restrict__ idx, int64_t m0, int64_t N,
+                                                         const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                         const float* __restrict__ val, const float* __restrict__ mask, int64_t H,
+                                                         const float* __restrict__ PX, int64_t ldx,
+                                                         const float* __restrict__ rowsum, int64_t F,
+                                                         const float* __restrict__ H1p, int64_t ldh, const float* __restrict__ T,
+                                                         const float* __restrict__ phibar, float* __restrict__ gradP, float* __restrict__ h1_bar,
+                                                         float* __restrict__ e_bar) {
+  extern __shared__ float sm[];
+  float* __restrict__ mk = sm;       // [H]
+  float* __restrict__ red = mk + H;  // [4]
+  const int64_t n = idx[m0 + blockIdx.x];
+  if (n < 0 || n >= N) return;
+  const float* __restrict__ Tm = T + int64_t(blockIdx.x) * H * (F + 1);
+  const float* __restrict__ pbm = phibar + int64_t(blockIdx.x) * (H + 1);
+  for (int32_t p = rowptr[n]; p < rowptr[n + 1]; ++p) {
+    const float tot = dadj_pair(Tm, pbm, col[p], H, F, mask, PX, ldx, rowsum, H1p, ldh, val[p], h1_bar, e_bar, mk, red);
+    if (threadIdx.x == 0) atomicAdd(&gradP[p], tot);  // (a repeated node id: several samples share the entry)
+  }
+}
+
+// candidate pairs (a, b): a contributes through the samples that are a -- the first one's tile, times its multiplicity
+__global__ __launch_bounds__(256) void dadj_cand_kernel(const int32_t* __restrict__ ca, const int32_t* __restrict__ cb, int64_t K,
+                                                        const int32_t* __restrict__ pos, const int32_t* __restrict__ mult,
+                                                        int64_t m0, int64_t mc, const float* __restrict__ mask, int64_t H,
+                                                        const float* __restrict__ PX, int64_t ldx,
+                                                        const float* __restrict__ rowsum, int64_t F,
+                                                        const float* __restrict__ H1p, int64_t ldh, const float* __restrict__ T,
+                                                        const float* __restrict__ phibar, float* __restrict__ grad_cand) {
+  extern __shared__ float sm[];
+  float* __restrict__ mk = sm;
+  float* __restrict__ red = mk + H;
+  for (int64_t k = blockIdx.x; k < K; k += gridDim.x) {
+    const int32_t m = pos[ca[k]];
+    if (m == INT32_MAX || m < m0 || m >= m0 + mc) continue;  // (uniform over the workgroup)
+    const float* __restrict__ Tm = T + int64_t(m - m0) * H * (F + 1);
+    const float* __restrict__ pbm = phibar + int64_t(m - m0) * (H + 1);
+    const float tot = dadj_pair(Tm, pbm, cb[k], H, F, mask, PX, ldx, rowsum, H1p, ldh, 0.f, nullptr, nullptr, mk, red);
+    if (threadIdx.x == 0) grad_cand[k] += float(mult[m]) * tot;
+  }
+}
+
+}  // namespace
+
+int diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, const float* gamma, float loss_scale,
+                       float* grad_P, float* out_bar, float* h1_bar, float* e_bar, const int32_t* cand_a, const int32_t* cand_b,
+                       int64_t K, float* grad_cand, hipStream_t s) {
+  LGNN_REQUIRE(K == 0 || (cand_a && cand_b && grad_cand), "candidate pairs without their buffers");
+  LGNN_CALL(check_model(h));
+  LGNN_REQUIRE(h->kind == LGNN_KIND_GCN, "adjacency gradient, diagonal posterior: GCN models");
+  LGNN_REQUIRE(M > 0 && idx && y && gamma && grad_P && out_bar && h1_bar && e_bar, "empty batch or null pointers");
+  LGNN_CALL(forward_ensure_aux(h, s));
+  const int64_t N = h->N, C = h->dims[2], H = h->dims[1], F = h->dims[0], F1 = F + 1;
+  LGNN_REQUIRE(h->in_dim[1] == H, "internal: GCN head stride");
+  LGNN_CALL(batch_prologue(h, idx, y, M, false, false, nullptr, s));
+  // T of a chunk of samples under the workspace cap
+  const int64_t per_sample = H * F1 * 4;
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(M, h->ws_limit / per_sample));
+  LGNN_CALL(h->ws.jac.reserve(size_t(chunk) * per_sample));
+  LGNN_CALL(h->ws.misc.reserve(size_t(chunk) * (H + 1) * 4));
+  float* T = h->ws.jac.as<float>();
+  float* phibar = h->ws.misc.as<float>();
+  const int vch = int(std::max<int64_t>(1, std::min<int64_t>(8, (60 * 1024 / 4) / (H + F1 + 1))));
+  const size_t smem_t = size_t(vch) * (H + F1 + 1) * 4;
+  LGNN_REQUIRE(smem_t <= 60 * 1024, "adjacency gradient, diagonal posterior: hidden + input width too large");
+  const size_t smem_s = size_t(3 * H + (H + 1) + 3 * C + 4) * 4;
+  LGNN_REQUIRE(smem_s <= 60 * 1024, "adjacency gradient, diagonal posterior: hidden width / classes too large");
+  const size_t smem_e = size_t(H + 4) * 4;
+  const float* mask = h->fc.dact0.as<float>();
+  const float* PX = h->fc.prop_in[0].as<float>();
+  const int64_t ldx = h->fc.prop_ld[0];
+  const float* rowsum = h->fc.rowsum.as<float>();
+  for (int64_t m0 = 0; m0 < M; m0 += chunk) {
+    const int64_t mc = std::min(chunk, M - m0);
+    hipLaunchKernelGGL(dadj_T_kernel, dim3(unsigned(mc)), dim3(256), smem_t, s, idx, m0, N, h->P.rowptr, h->P.col, h->P.val, mask,
+                       H, PX, ldx, rowsum, F, vch, T);
+    hipLaunchKernelGGL(dadj_sample_kernel, dim3(unsigned(mc)), dim3(256), smem_s, s, idx, static_cast<const int64_t*>(y), m0, N,
+                       h->ws.probs.as<float>(), C, H, F, h->W[1], h->fc.prop_in[1].as<float>(), h->fc.prop_ld[1], rowsum, gamma,
+                       loss_scale, T, phibar, out_bar);
+    hipLaunchKernelGGL(dadj_entry_kernel, dim3(unsigned(mc)), dim3(256), smem_e, s, idx, m0, N, h->P.rowptr, h->P.col, h->P.val,
+                       mask, H, PX, ldx, rowsum, F, h->fc.hact_p[0], h->fc.hact_ld[0], T, phibar, grad_P, h1_bar, e_bar);
+    if (K > 0)
+      hipLaunchKernelGGL(dadj_cand_kernel, dim3(unsigned(std::min<int64_t>(K, 65535))), dim3(256), smem_e, s, cand_a, cand_b, K,
+                         h->ws.pos.as<int32_t>(), h->ws.mult.as<int32_t>(), m0, mc, mask, H, PX, ldx, rowsum, F,
+                         h->fc.hact_p[0], h->fc.hact_ld[0], T, phibar, grad_cand);
+    LGNN_HIP_CHECK(hipGetLastError());
+  }
+  LGNN_CALL(batch_epilogue(h, idx, M, s));
+  return 0;
+}
+
+// h1_bar [N, H] / e_bar [N, F + 1] (diagonal posterior, GCN: diag_adjgrad_batch): adjoints of H_1 and of [P X | rowsum(P)]
+// that take the place of the Kronecker posterior's 2 a_scale H_1 Gamma_A1 (gamma_A1 is null then)
 int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0, const float* gamma_A1, float a1_scale,
                    float* grad_P, float* grad_adj, const int32_t* cand_a, const int32_t* cand_b, int64_t K, float* grad_cand,
-                   float* grad_cand_adj, hipStream_t s) {
+                   float* grad_cand_adj, hipStream_t s, const float* h1_bar, const float* e_bar) {
   LGNN_REQUIRE(K == 0 || (cand_a && cand_b && grad_cand && grad_cand_adj), "candidate pairs without their buffers");
   LGNN_CALL(check_model(h));
-  LGNN_REQUIRE(out_bar && gamma_A1 && grad_P && grad_adj, "null pointers");
+  LGNN_REQUIRE(out_bar && (gamma_A1 || (h1_bar && e_bar)) && grad_P && grad_adj, "null pointers");
+  LGNN_REQUIRE(!(h1_bar || e_bar) || h->kind == LGNN_KIND_GCN, "adjacency gradient, diagonal posterior: GCN models");
   if (h->kind == LGNN_KIND_SAGE) {
     LGNN_REQUIRE(gamma_A0 != nullptr, "GraphSAGE: the first layer's input covariance depends on the adjacency (gamma_A[0])");
     return sage_adjgrad_finish(h, out_bar, gamma_A0, gamma_A1, a1_scale, grad_P, grad_adj, cand_a, cand_b, K, grad_cand,
@@ -1127,7 +1428,12 @@ int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0, con
   // Z1bar = P^T outbar;  H1bar = Z1bar W1 + 2 a1_scale H1 Gamma_A1;  P0bar = mask * H1bar
   LGNN_CALL(launch_spmm(h->PT, N, out_bar, C, Zb, C, C, 0, s));
   LGNN_CALL(sgemm_rm(s, N, H, C, 1.f, Zb, C, h->W[1], H, 0.f, Hb, H));
-  LGNN_CALL(sgemm_rm(s, N, H, H, 2.f * a1_scale, h->fc.hact_p[0], h->fc.hact_ld[0], gamma_A1, H, 1.f, Hb, H));
+  if (gamma_A1) LGNN_CALL(sgemm_rm(s, N, H, H, 2.f * a1_scale, h->fc.hact_p[0], h->fc.hact_ld[0], gamma_A1, H, 1.f, Hb, H));
+  if (h1_bar) {
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(unsigned(std::min<int64_t>(cdiv(N * H, 256), 4096))), dim3(256), 0, s, Hb, h1_bar,
+                       N * H);
+    LGNN_HIP_CHECK(hipGetLastError());
+  }
   hipLaunchKernelGGL(relu_mask_inplace_kernel, dim3(unsigned(std::min<int64_t>(cdiv(N * H, 256), 4096))), dim3(256), 0, s,
                      Hb, h->fc.hact_p[0], N * H);
   LGNN_HIP_CHECK(hipGetLastError());
@@ -1136,6 +1442,17 @@ int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0, con
   LGNN_CALL(launch_gemm(h->fc.lin_in_p[0], h->fc.lin_in_ld[0], h->Wt[0].as<float>(), H, Z, H, N, F, H, eb0, s));
   LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, Hb, H, 0, Z, H, 0, H, 1, grad_P, s));
   LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, Hb, H, 0, Z, H, 0, H, 1, nullptr, grad_cand, s));
+  if (e_bar) {
+    // P X = sum_u P[v, u] X[u]: gradP[(v, u)] += <e_bar[v, :F], X[u]>;  rowsum(P)[v] = sum_u P[v, u]: += e_bar[v, F]
+    const int64_t F1 = F + 1;
+    LGNN_CALL(forward_input_view(h, s));
+    LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, e_bar, F1, 0, h->fc.lin_in_p[0], h->fc.lin_in_ld[0], 0, F, 1, grad_P, s));
+    LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, e_bar, F1, 0, h->fc.lin_in_p[0], h->fc.lin_in_ld[0], 0, F, 1, nullptr,
+                               grad_cand, s));
+    hipLaunchKernelGGL(row_const_kernel, dim3(unsigned(cdiv(N, 4))), dim3(256), 0, s, h->P.rowptr, N, e_bar + F, F1, grad_P,
+                       cand_a, K, grad_cand);
+    LGNN_HIP_CHECK(hipGetLastError());
+  }
   // normalize_adj backward + the straight-through binarisation
   LGNN_CALL(h->ws.misc.reserve(size_t(2) * N * 4 + size_t(h->nnz) * 4));
   float* rs = h->ws.misc.as<float>();
@@ -1173,5 +1490,23 @@ extern "C" int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const floa
                                    int64_t num_cand, float* grad_cand, float* grad_cand_adj, void* stream) {
   if (!h || !gamma_A) { lgnn::set_error("null argument"); return 2; }
   return lgnn::adjgrad_finish(h, out_bar, gamma_A[0], gamma_A[1], a_scale, grad_P, grad_adj, cand_a, cand_b, num_cand, grad_cand,
-                              grad_cand_adj, static_cast<hipStream_t>(stream));
+                              grad_cand_adj, static_cast<hipStream_t>(stream), nullptr, nullptr);
+}
+
+extern "C" int lgnn_diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, const float* gamma,
+                                       float loss_scale, float* grad_P, float* out_bar, float* h1_bar, float* e_bar,
+                                       const int32_t* cand_a, const int32_t* cand_b, int64_t num_cand, float* grad_cand,
+                                       void* stream) {
+  if (!h) { lgnn::set_error("null context"); return 2; }
+  return lgnn::diag_adjgrad_batch(h, idx, y, M, gamma, loss_scale, grad_P, out_bar, h1_bar, e_bar, cand_a, cand_b, num_cand,
+                                  grad_cand, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int lgnn_diag_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* h1_bar, const float* e_bar,
+                                        float* grad_P, float* grad_adj, const int32_t* cand_a, const int32_t* cand_b,
+                                        int64_t num_cand, float* grad_cand, float* grad_cand_adj, void* stream) {
+  if (!h) { lgnn::set_error("null context"); return 2; }
+  if (!h1_bar || !e_bar) { lgnn::set_error("lgnn_diag_adjgrad_finish: null adjoint buffers"); return 2; }
+  return lgnn::adjgrad_finish(h, out_bar, nullptr, nullptr, 0.f, grad_P, grad_adj, cand_a, cand_b, num_cand, grad_cand,
+                              grad_cand_adj, static_cast<hipStream_t>(stream), h1_bar, e_bar);
 }

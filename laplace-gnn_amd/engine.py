@@ -517,6 +517,35 @@ class GraphEngine:
         _lib.check(rc, "lgnn_adjgrad_finish")
         return out if cand is None else (out, cout)
 
+    def diag_adjgrad_batch(self, idx, y, gamma: torch.Tensor, grad_P: torch.Tensor, out_bar: torch.Tensor, h1_bar: torch.Tensor,
+                           e_bar: torch.Tensor, loss_scale: float = 1.0, cand=None):
+        """Diagonal posterior (2-layer GCN): add one batch's terms to ``grad_P`` [nnz], ``out_bar`` [N, C], ``h1_bar`` [N, H],
+        ``e_bar`` [N, F + 1] and the candidates' accumulator; ``gamma`` [n_params] = d(-marglik)/dH (lgnn_diag_adjgrad_batch)."""
+        self._sync_versions()
+        idx, y = idx.contiguous(), y.contiguous()
+        self._keep = gamma.contiguous()
+        ca, cb, K, cacc = self._cand_ptrs(cand)
+        rc = self.lib.lgnn_diag_adjgrad_batch(
+            self._h, _dev_ptr(idx, torch.int64, "idx"), _dev_ptr(y, torch.int64, "y"), idx.shape[0],
+            _dev_ptr(self._keep, torch.float32, "gamma"), float(loss_scale), _dev_ptr(grad_P, torch.float32, "grad_P"),
+            _dev_ptr(out_bar, torch.float32, "out_bar"), _dev_ptr(h1_bar, torch.float32, "h1_bar"),
+            _dev_ptr(e_bar, torch.float32, "e_bar"), ca, cb, K, cacc, _stream(self.device))
+        _lib.check(rc, "lgnn_diag_adjgrad_batch")
+
+    def diag_adjgrad_finish(self, out_bar: torch.Tensor, h1_bar: torch.Tensor, e_bar: torch.Tensor, grad_P: torch.Tensor,
+                            cand=None):
+        """The forward-pass terms of ``out_bar`` / ``h1_bar`` / ``e_bar`` + normalize_adj / STE backward (as ``adjgrad_finish``)."""
+        self._sync_versions()
+        out = torch.zeros(self.nnz, dtype=torch.float32, device=self.device)
+        ca, cb, K, cacc = self._cand_ptrs(cand)
+        cout = torch.zeros(K, dtype=torch.float32, device=self.device) if K else None
+        rc = self.lib.lgnn_diag_adjgrad_finish(self._h, _dev_ptr(out_bar, torch.float32, "out_bar"),
+                                               _dev_ptr(h1_bar, torch.float32, "h1_bar"), _dev_ptr(e_bar, torch.float32, "e_bar"),
+                                               _dev_ptr(grad_P, torch.float32, "grad_P"), out.data_ptr(), ca, cb, K, cacc,
+                                               None if cout is None else cout.data_ptr(), _stream(self.device))
+        _lib.check(rc, "lgnn_diag_adjgrad_finish")
+        return out if cand is None else (out, cout)
+
     def glm_variance(self, idx: torch.Tensor, S0, S1, kappa, QA0=None, QB0=None, QA1=None, QB1sq=None, out_map=None):
         """Matrix-free GLM predictive of a 2-layer GCN / GraphSAGE: (f_mu [M, C], diag(J P^-1 J^T) [M, C]) from the closed-form
         Jacobian (see include/laplace_gnn_hip.h lgnn_glm_variance for the operand conventions).  ``out_map`` = E [Cm, C]:

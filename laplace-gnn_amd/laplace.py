@@ -126,6 +126,33 @@ def _is_zero_number(v) -> bool:
     return isinstance(v, (int, float)) and v == 0
 
 
+def _adjacency_candidates(eng, candidates, sym: bool):
+    """Candidate pairs (i, j) of ``neg_marglik_adj_grad`` -> (a, b, accumulator) in the propagation matrix's coordinates, or
+    None.  The device kernels index rows with these pairs: validated before the cast to int32 (one host round trip; this is not
+    the per-batch path).  Stored pairs are not candidates: their gradient comes back with the stored entries (a GCN stores its
+    diagonal, gnn/models/models.py:23; GraphSAGE's diagonal entries are genuine non-edges of the reference's dense adj.grad,
+    gnn/models/models.py:47)."""
+    if candidates is None:
+        return None
+    ci, cj = candidates[0].to(eng.device).to(torch.int64), candidates[1].to(eng.device).to(torch.int64)
+    Nn = eng.num_nodes
+    if ci.numel():
+        if bool(((ci < 0) | (ci >= Nn) | (cj < 0) | (cj >= Nn)).any()):
+            raise ValueError(f"candidate pairs must index nodes in [0, {Nn})")
+        sr, sc = eng.export_adj()  # row-major sorted
+        skey, ckey = sr * Nn + sc, ci * Nn + cj
+        pos = torch.searchsorted(skey, ckey).clamp(max=max(skey.numel() - 1, 0))
+        if skey.numel() and bool((skey[pos] == ckey).any()):
+            raise ValueError("candidate pairs must not be stored entries of the adjacency")
+    if sym:  # (adj + adj^T) / 2 feeds the model: both orientations are needed
+        ci, cj = torch.cat([ci, cj]), torch.cat([cj, ci])
+    # entry (i, j) of the adjacency is entry (a = j, b = i) of the GCN propagation matrix D A^T D and entry
+    # (a = i, b = j) of GraphSAGE's A / rowsum
+    ca, cb = (cj, ci) if eng.kind == "gcn" else (ci, cj)
+    return (ca.to(torch.int32).contiguous(), cb.to(torch.int32).contiguous(),
+            torch.zeros(ci.shape[0], dtype=torch.float32, device=eng.device))
+
+
 class ParametricLaplace(BaseLaplace):
     def _init_H(self):
         raise NotImplementedError
@@ -768,29 +795,8 @@ class KronLaplace(ParametricLaplace):
         grad_P = torch.zeros(eng.nnz, dtype=torch.float32, device=eng.device)
         out_bar = torch.zeros(eng.num_nodes, eng.dims[-1], dtype=torch.float32, device=eng.device)
         rank, world = _dist_info(process_group)
-        cand, sym = None, bool(getattr(self.model, "symmetric", False))
-        if candidates is not None:
-            ci, cj = candidates[0].to(eng.device).to(torch.int64), candidates[1].to(eng.device).to(torch.int64)
-            # the device kernels index rows with these pairs: validate before the cast to int32 (one host round trip; this
-            # is not the per-batch path).  Stored pairs are not candidates: their gradient comes back with the stored
-            # entries (a GCN stores its diagonal, gnn/models/models.py:23; GraphSAGE's diagonal entries are genuine
-            # non-edges of the reference's dense adj.grad, gnn/models/models.py:47).
-            Nn = eng.num_nodes
-            if ci.numel():
-                if bool(((ci < 0) | (ci >= Nn) | (cj < 0) | (cj >= Nn)).any()):
-                    raise ValueError(f"candidate pairs must index nodes in [0, {Nn})")
-                sr, sc = eng.export_adj()  # row-major sorted
-                skey, ckey = sr * Nn + sc, ci * Nn + cj
-                pos = torch.searchsorted(skey, ckey).clamp(max=max(skey.numel() - 1, 0))
-                if skey.numel() and bool((skey[pos] == ckey).any()):
-                    raise ValueError("candidate pairs must not be stored entries of the adjacency")
-            if sym:  # (adj + adj^T) / 2 feeds the model: both orientations are needed
-                ci, cj = torch.cat([ci, cj]), torch.cat([cj, ci])
-            # entry (i, j) of the adjacency is entry (a = j, b = i) of the GCN propagation matrix D A^T D and entry
-            # (a = i, b = j) of GraphSAGE's A / rowsum
-            ca, cb = (cj, ci) if eng.kind == "gcn" else (ci, cj)
-            cand = (ca.to(torch.int32).contiguous(), cb.to(torch.int32).contiguous(),
-                    torch.zeros(ci.shape[0], dtype=torch.float32, device=eng.device))
+        sym = bool(getattr(self.model, "symmetric", False))
+        cand = _adjacency_candidates(eng, candidates, sym)
         for t, (X, y) in enumerate(train_loader):
             if t % world != rank:
                 continue
@@ -910,6 +916,50 @@ class DiagLaplace(ParametricLaplace):
             E2 = out_map.to(w1).square()
             w1, b1 = E2 @ w1, E2 @ b1
         return dict(S0=torch.cat([w0, b0], dim=1), S1=w1, kappa=b1)
+
+    def neg_marglik_adj_grad(self, train_loader, prior_precision=None, process_group=None, candidates=None):
+        """``-log_marginal_likelihood()`` of this fit and its gradient w.r.t. the adjacency -- what ``neg_marglik.backward()``
+        leaves in ``model.adj.grad`` when the structure-learning loop runs with ``hessian_structure="diag"``, the shipped
+        STE-GCN configuration (gnn/configs/original/stegcn_config.yaml:7; gnn/marglik_training.py:197-216; the fork's
+        Jacobians keep the graph, laplace/curvature/curvature.py:89-130).  Same return values and candidate pairs as
+        ``KronLaplace.neg_marglik_adj_grad``.  2-layer GCN (STEGCN), classification; the diagonal GGN is a sum over samples, so
+        the loader's batch boundaries do not matter."""
+        if self.H is None or not self.n_data:
+            raise AttributeError("Laplace not fitted. Run fit() first.")
+        if prior_precision is not None:
+            self.prior_precision = prior_precision
+        if self.likelihood != "classification":
+            raise NotImplementedError("adjacency gradient: classification likelihood")
+        eng = getattr(self.backend, "engine", None)
+        if eng is None or not hasattr(eng, "diag_adjgrad_batch") or eng.kind != "gcn":
+            raise NotImplementedError("adjacency gradient under a diagonal posterior: 2-layer GCN on the HIP backend")
+        value = -self.log_marginal_likelihood()
+        f = self._H_factor
+        gamma = (0.5 * f / self.posterior_precision).to(torch.float32).contiguous()  # d(1/2 logdet P) / dH_p
+        N, Hd, F, C = eng.num_nodes, eng.dims[1], eng.dims[0], eng.dims[-1]
+        grad_P = torch.zeros(eng.nnz, dtype=torch.float32, device=eng.device)
+        out_bar = torch.zeros(N, C, dtype=torch.float32, device=eng.device)
+        h1_bar = torch.zeros(N, Hd, dtype=torch.float32, device=eng.device)
+        e_bar = torch.zeros(N, F + 1, dtype=torch.float32, device=eng.device)
+        rank, world = _dist_info(process_group)
+        sym = bool(getattr(self.model, "symmetric", False))
+        cand = _adjacency_candidates(eng, candidates, sym)
+        eng.set_likelihood("classification")
+        for t, (X, y) in enumerate(train_loader):
+            if t % world != rank:
+                continue
+            eng.diag_adjgrad_batch(X.to(eng.device), y.to(eng.device), gamma, grad_P, out_bar, h1_bar, e_bar, loss_scale=f,
+                                   cand=cand)
+        if world > 1:
+            all_reduce_flat_([grad_P, out_bar, h1_bar, e_bar] + ([cand[2]] if cand is not None else []), process_group)
+        rows, cols = eng.export_adj()
+        if cand is None:
+            return value, torch.stack([rows, cols]), eng.diag_adjgrad_finish(out_bar, h1_bar, e_bar, grad_P)
+        grad, gc = eng.diag_adjgrad_finish(out_bar, h1_bar, e_bar, grad_P, cand=cand)
+        if sym:
+            K = candidates.shape[1]
+            gc = 0.5 * (gc[:K] + gc[K:])
+        return value, torch.stack([rows, cols]), grad, gc
 
     def _scale_samples(self, eps):  # laplace/baselaplace.py:1912-1919: samples * posterior_scale
         return eps * (1.0 / self.posterior_precision.sqrt()).reshape(1, self.n_params)

@@ -136,3 +136,92 @@ def test_candidate_pairs_are_validated_before_they_reach_the_device():
     assert len(out) == 4 and out[3].shape[0] == ne.shape[1] and torch.isfinite(out[3]).all()
     model.engine.check_async_errors()
 
+
+
+# ---- diagonal posterior: what the shipped STE-GCN configuration differentiates (gnn/configs/original/stegcn_config.yaml:7) ----
+DIAG_CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "adjgrad_diag_vals" in np.load(p))
+
+
+@pytest.mark.parametrize("path", DIAG_CASES, ids=[os.path.basename(p)[:-4] for p in DIAG_CASES])
+def test_diag_adjacency_gradient_matches_reference_autograd(path):
+    """``DiagLaplace.neg_marglik_adj_grad`` (lgnn_diag_adjgrad_batch / _finish) against ``model.adj.grad`` of the reference's
+    STEGCN after ``(-DiagLaplace.log_marginal_likelihood()).backward()``: stored entries and the fixture's 200 non-edges.
+    fp32 with float atomics; the oracle's fp64 chain is at 3e-7 of the same goldens."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(path)
+    model = model_from_golden(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(),
+                                  batch_size=int(g["batch_size"]))
+    la = lg.DiagLaplace(model, "classification", prior_precision=float(g["adjgrad_prior"]))
+    with pytest.raises(AttributeError):
+        la.neg_marglik_adj_grad(loader)
+    la.fit(loader)
+    val, ei, grad = la.neg_marglik_adj_grad(loader)
+    assert np.array_equal(ei[0].cpu().numpy(), g["adj_nz_row"]) and np.array_equal(ei[1].cpu().numpy(), g["adj_nz_col"])
+    assert abs(float(val) - float(g["adjgrad_diag_neg_marglik"])) <= 5e-6 * abs(float(g["adjgrad_diag_neg_marglik"]))
+    assert rel(grad.cpu().numpy(), g["adjgrad_diag_vals"]) < 1e-5
+    diag = g["adj_nz_row"] == g["adj_nz_col"]
+    assert float(np.abs(grad.cpu().numpy()[diag]).max()) == 0.0  # overwritten by fill_diagonal_(1) in the reference
+    cand = torch.from_numpy(np.stack([g["adjgrad_ne_row"], g["adjgrad_ne_col"]])).cuda()
+    _, _, grad2, gc = la.neg_marglik_adj_grad(loader, candidates=cand)
+    assert rel(grad2.cpu().numpy(), grad.cpu().numpy()) < 1e-5
+    assert rel(gc.cpu().numpy(), g["adjgrad_diag_ne_val"]) < 1e-5
+    model.engine.check_async_errors()
+
+
+@pytest.mark.parametrize("sym,F,H,C,limit", [(True, 24, 64, 10, None), (False, 37, 33, 7, 1 << 20), (False, 130, 256, 12, 8 << 20)])
+def test_diag_adjacency_gradient_midsize_vs_oracle(sym, F, H, C, limit):
+    """Mid-size graphs against the oracle's reverse chain: widths that fill no tile, repeated node ids, sample chunks under a
+    small workspace cap (the first-layer tiles of a chunk of samples live in the workspace), candidates vs the dense gradient."""
+    import laplace_gnn_amd as lg
+
+    N, E, M = 1500, 6000, 300
+    gen = torch.Generator().manual_seed(17)
+    ei = torch.randint(0, N, (2, E), generator=gen)
+    X = torch.randn(N, F, generator=gen)
+    torch.manual_seed(2)
+    model = lg.GCN(F, H, C, 2, X, ei, symmetric=sym).to("cuda").eval()
+    idx = torch.randperm(N, generator=gen)[:M]
+    idx[M // 2:M // 2 + 15] = idx[:15]  # repeated node ids (with their own labels) inside and across batches
+    y = torch.randint(0, C, (M,), generator=gen)
+    loader = lg.TensorBatchLoader(idx.cuda(), y.cuda(), batch_size=128)
+    if limit is not None:
+        model.engine.set_workspace_limit(limit)
+    la = lg.DiagLaplace(model, "classification", prior_precision=0.5)
+    la.fit(loader)
+    cand = torch.randint(0, N, (2, 300), generator=torch.Generator().manual_seed(5))
+    cand = cand[:, cand[0] != cand[1]]
+    rows_s, cols_s = model.engine.export_adj()
+    stored = set(zip(rows_s.cpu().tolist(), cols_s.cpu().tolist()))
+    cand = cand[:, torch.tensor([(int(i), int(j)) not in stored for i, j in cand.t().tolist()])]
+    # make sure some candidates start at batch nodes (only those see the first-layer tiles), one of them a repeated id
+    extra = torch.stack([idx[:40], (idx[:40] + 7) % N])
+    extra = extra[:, torch.tensor([(int(i), int(j)) not in stored and int(i) != int(j) for i, j in extra.t().tolist()])]
+    cand = torch.cat([cand, extra, extra.flip(0)], dim=1)
+    cand = cand[:, torch.tensor([(int(i), int(j)) not in stored for i, j in cand.t().tolist()])]
+    val0, _, grad0 = la.neg_marglik_adj_grad(loader)
+    val, e2, grad, gc = la.neg_marglik_adj_grad(loader, candidates=cand.cuda())
+    assert abs(float(val0) - float(val)) <= 1e-6 * abs(float(val)) and rel(grad0.cpu().numpy(), grad.cpu().numpy()) < 1e-5
+    Ws = [c.lin.weight.detach().cpu().numpy() for c in model.convs]
+    bs = [c.lin.bias.detach().cpu().numpy() for c in model.convs]
+    om = oracle_from_arrays("gcn", N, ei.numpy(), X.numpy(), Ws, bs, sym)
+    oval, rows, cols, og = O.diag_marglik_adj_grad(om, idx.numpy(), y.numpy(), 128, 0.5, sym)
+    assert np.array_equal(e2[0].cpu().numpy(), rows) and np.array_equal(e2[1].cpu().numpy(), cols)
+    assert abs(float(val) - oval) <= 5e-6 * abs(oval)
+    assert rel(grad.cpu().numpy(), og) < 1e-4
+    _, gd = O.diag_marglik_adj_grad(om, idx.numpy(), y.numpy(), 128, 0.5, sym, dense=True)
+    assert rel(gc.cpu().numpy(), gd[cand[0].numpy(), cand[1].numpy()]) < 1e-4
+    model.engine.check_async_errors()
+
+
+def test_diag_adjacency_gradient_is_refused_for_graphsage():
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, "sage_small_1batch_s0.npz"))
+    model = model_from_golden(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(), 10000)
+    la = lg.DiagLaplace(model, "classification")
+    la.fit(loader)
+    with pytest.raises(NotImplementedError, match="GCN"):
+        la.neg_marglik_adj_grad(loader)
