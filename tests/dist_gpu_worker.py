@@ -66,7 +66,14 @@ def main():
             lp.fit(loader)
             cand = torch.from_numpy(np.stack([g["adjgrad_ne_row"], g["adjgrad_ne_col"]])).cuda()
             val, ei, grad, gc = lp.neg_marglik_adj_grad(loader, candidates=cand)
-            assert rel(grad.cpu().numpy(), g["adjgrad_vals"]) < 1e-3 and rel(gc.cpu().numpy(), g["adjgrad_ne_val"]) < 1e-3
+            assert rel(grad.cpu().numpy(), g["adjgrad_vals"]) < 1e-5 and rel(gc.cpu().numpy(), g["adjgrad_ne_val"]) < 1e-5
+        if "adjgrad_diag_vals" in g:  # the same under the diagonal posterior (four accumulators + the candidates', one all-reduce)
+            ldg = lg.DiagLaplace(model, "classification", prior_precision=float(g["adjgrad_prior"]))
+            ldg.fit(loader)
+            cand = torch.from_numpy(np.stack([g["adjgrad_ne_row"], g["adjgrad_ne_col"]])).cuda()
+            val, ei, grad, gc = ldg.neg_marglik_adj_grad(loader, candidates=cand)
+            assert abs(float(val) - float(g["adjgrad_diag_neg_marglik"])) <= 5e-6 * abs(float(g["adjgrad_diag_neg_marglik"]))
+            assert rel(grad.cpu().numpy(), g["adjgrad_diag_vals"]) < 1e-5 and rel(gc.cpu().numpy(), g["adjgrad_diag_ne_val"]) < 1e-5
         model.engine.check_async_errors()
     # the path routes (hidden width > 128) cut a batch by DESTINATION NODES (lgnn_kfac_accumulate_share): the ranks' node ranges
     # of every batch must add up to the single-process fit, for the GCN's two-hop and GraphSAGE's one-hop paths
