@@ -1305,24 +1305,85 @@ __device__ __forceinline__ float dadj_pair(const float* __restrict__ Tm, const f
   return block_sum_256(part, red);
 }
 
+// The entries of a sample's row, EV at a time: the tile is read once for the EV column nodes (their mask rows are staged j-major
+// in LDS, two 16-byte broadcasts per tile element), thread t owns columns i = t, t + 256, ... of the tile.
+constexpr int EV = 8;
 __global__ __launch_bounds__(256) void dadj_entry_kernel(const int64_t* __restrict__ idx, int64_t m0, int64_t N,
                                                          const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                          const float* __restrict__ val, const float* __restrict__ mask, int64_t H,
                                                          const float* __restrict__ PX, int64_t ldx,
                                                          const float* __restrict__ rowsum, int64_t F,
                                                          const float* __restrict__ H1p, int64_t ldh, const float* __restrict__ T,
-                                                         const float* __restrict__ phibar, float* __restrict__ gradP, float* __restrict__ h1_bar,
-                                                         float* __restrict__ e_bar) {
-  extern __shared__ float sm[];
-  float* __restrict__ mk = sm;       // [H]
-  float* __restrict__ red = mk + H;  // [4]
+                                                         const float* __restrict__ phibar, float* __restrict__ gradP,
+                                                         float* __restrict__ h1_bar, float* __restrict__ e_bar) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* __restrict__ mk = sm;                   // [H][EV]
+  float* __restrict__ red = mk + H * EV;         // [4][EV]
+  float* __restrict__ wv = red + 4 * EV;         // [EV]
+  int32_t* __restrict__ vid = reinterpret_cast<int32_t*>(wv + EV);  // [EV]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t F1 = F + 1;
   const int64_t n = idx[m0 + blockIdx.x];
   if (n < 0 || n >= N) return;
-  const float* __restrict__ Tm = T + int64_t(blockIdx.x) * H * (F + 1);
+  const float* __restrict__ Tm = T + int64_t(blockIdx.x) * H * F1;
   const float* __restrict__ pbm = phibar + int64_t(blockIdx.x) * (H + 1);
-  for (int32_t p = rowptr[n]; p < rowptr[n + 1]; ++p) {
-    const float tot = dadj_pair(Tm, pbm, col[p], H, F, mask, PX, ldx, rowsum, H1p, ldh, val[p], h1_bar, e_bar, mk, red);
-    if (threadIdx.x == 0) atomicAdd(&gradP[p], tot);  // (a repeated node id: several samples share the entry)
+  const int32_t ps = rowptr[n], pe = rowptr[n + 1];
+  for (int32_t p0 = ps; p0 < pe; p0 += EV) {
+    const int un = min(EV, pe - p0);
+    __syncthreads();
+    if (tid < EV) {
+      vid[tid] = tid < un ? col[p0 + tid] : 0;
+      wv[tid] = tid < un ? val[p0 + tid] : 0.f;
+    }
+    __syncthreads();
+    for (int64_t t = tid; t < H * EV; t += 256) {
+      const int u = int(t % EV);
+      const int64_t j = t / EV;
+      mk[t] = u < un ? mask[int64_t(vid[u]) * H + j] : 0.f;
+    }
+    __syncthreads();
+    float part[EV];
+#pragma unroll
+    for (int u = 0; u < EV; ++u) part[u] = 0.f;
+    for (int64_t i = tid; i < F1; i += 256) {
+      float ca[EV];
+#pragma unroll
+      for (int u = 0; u < EV; ++u) ca[u] = 0.f;
+      for (int64_t j = 0; j < H; ++j) {
+        const float t = Tm[j * F1 + i];
+        const float4 m0v = *reinterpret_cast<const float4*>(mk + j * EV);
+        const float4 m1v = *reinterpret_cast<const float4*>(mk + j * EV + 4);
+        ca[0] = fmaf(m0v.x, t, ca[0]); ca[1] = fmaf(m0v.y, t, ca[1]); ca[2] = fmaf(m0v.z, t, ca[2]); ca[3] = fmaf(m0v.w, t, ca[3]);
+        ca[4] = fmaf(m1v.x, t, ca[4]); ca[5] = fmaf(m1v.y, t, ca[5]); ca[6] = fmaf(m1v.z, t, ca[6]); ca[7] = fmaf(m1v.w, t, ca[7]);
+      }
+#pragma unroll
+      for (int u = 0; u < EV; ++u)
+        if (u < un) {
+          const int64_t v = vid[u];
+          part[u] = fmaf(ca[u], i < F ? PX[v * ldx + i] : rowsum[v], part[u]);
+          if (ca[u] != 0.f) atomicAdd(&e_bar[v * F1 + i], wv[u] * ca[u]);
+        }
+    }
+    for (int64_t j = tid; j < H; j += 256) {
+      const float pj = pbm[j];
+#pragma unroll
+      for (int u = 0; u < EV; ++u)
+        if (u < un) {
+          const int64_t v = vid[u];
+          part[u] = fmaf(pj, H1p[v * ldh + j], part[u]);
+          atomicAdd(&h1_bar[v * H + j], wv[u] * pj);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < EV; ++u) {
+      float x = part[u];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+      if (lane == 0) red[wave * EV + u] = x;
+    }
+    __syncthreads();
+    if (tid < un)  // (a repeated node id: several samples share the entry, hence the atomic)
+      atomicAdd(&gradP[p0 + tid], red[tid] + red[EV + tid] + red[2 * EV + tid] + red[3 * EV + tid] + pbm[H]);
   }
 }
 
@@ -1372,7 +1433,8 @@ int diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   LGNN_REQUIRE(smem_t <= 60 * 1024, "adjacency gradient, diagonal posterior: hidden + input width too large");
   const size_t smem_s = size_t(3 * H + (H + 1) + 3 * C + 4) * 4;
   LGNN_REQUIRE(smem_s <= 60 * 1024, "adjacency gradient, diagonal posterior: hidden width / classes too large");
-  const size_t smem_e = size_t(H + 4) * 4;
+  const size_t smem_e = size_t(H * 8 + 4 * 8 + 8 + 8) * 4;  // (dadj_entry_kernel: EV = 8 mask rows; the candidates' kernel needs H + 4)
+  LGNN_REQUIRE(smem_e <= 60 * 1024, "adjacency gradient, diagonal posterior: hidden width too large");
   const float* mask = h->fc.dact0.as<float>();
   const float* PX = h->fc.prop_in[0].as<float>();
   const int64_t ldx = h->fc.prop_ld[0];

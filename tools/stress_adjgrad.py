@@ -1,5 +1,6 @@
-"""dev: KronLaplace.neg_marglik_adj_grad on random small configurations (both model families, isolated nodes, repeated node
-ids, symmetric parameter, candidates) against the oracle's reverse chain (usage: python tools/stress_adjgrad.py FIRST LAST)."""
+"""dev: KronLaplace.neg_marglik_adj_grad -- and, for GCN configurations, DiagLaplace.neg_marglik_adj_grad -- on random small
+configurations (both model families, isolated nodes, repeated node ids, symmetric parameter, candidates) against the oracle's
+reverse chains (usage: python tools/stress_adjgrad.py FIRST LAST)."""
 import os, sys, traceback
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
@@ -53,6 +54,20 @@ for seed in range(first, last):
         if not (e_val < 5e-5 and e_g < 2e-4 and e_c < 2e-4):  # fp32 sums of the value: up to 2.2e-5 seen at H = 256
             bad.append((seed, kind, N, F, H, C, E, M, bs, sym, fe, e_val, e_g, e_c))
             print("MISMATCH", bad[-1], flush=True)
+        if kind == "gcn":  # the diagonal posterior's gradient (lgnn_diag_adjgrad_batch / _finish)
+            ld = lg.DiagLaplace(model, "classification", prior_precision=0.6)
+            ld.fit(loader)
+            val, e2, grad, gc = ld.neg_marglik_adj_grad(loader, candidates=cand.cuda())
+            oval, rows, cols, og = O.diag_marglik_adj_grad(om, idx.numpy(), y.numpy(), bs, 0.6, sym)
+            _, gd = O.diag_marglik_adj_grad(om, idx.numpy(), y.numpy(), bs, 0.6, sym, dense=True)
+            ref_c = gd[cand[0].numpy()[keep], cand[1].numpy()[keep]]
+            e_val = abs(float(val) - oval) / abs(oval)
+            e_c = rel(gc.cpu().numpy()[keep], ref_c) if keep.any() else 0.0
+            e_g = rel(np.concatenate([grad.cpu().numpy(), gc.cpu().numpy()[keep]]), np.concatenate([og, ref_c]))
+            model.engine.check_async_errors()
+            if not (e_val < 5e-5 and e_g < 2e-4 and e_c < 2e-4):
+                bad.append((seed, "gcn-diag", N, F, H, C, E, M, bs, sym, e_val, e_g, e_c))
+                print("MISMATCH", bad[-1], flush=True)
     except Exception as e:  # noqa: BLE001
         bad.append((seed, kind, N, F, H, C, E, M, bs, sym, fe, repr(e)[:200]))
         traceback.print_exc()
