@@ -1111,7 +1111,7 @@ namespace {
 //     r[j] = sum_i g0e[j, i] T[j, i]^2      a[c] = sum_j g1e[c, j] phi[j]^2
 //     pbar[c] = (1 - 2 p_c) a[c] + sum_j r[j] (W1[c, j]^2 - 2 W1[c, j] m[j]),  m = p W1;   fbar = p * pbar - p (p . pbar) + CE'
 //     phibar = 2 phi * (sum_c p_c (1 - p_c) g1e[c, :])        Tbar[j, :] = 2 q[j] g0e[j, :] T[j, :]
-//     gradP[(n, v)] += sum_j mask[v, j] <Tbar[j, :], Ee[v, :]> + <phibar, H1e[v]>
+//     gradP[(n, v)] += sum_j mask[v, j] <Tbar[j, :], Ee[v, :]> + <phibar, H1e[v]>          (dadj_entry_kernel; candidates: dadj_cand_kernel)
 //     h1_bar[v] += P[n, v] phibar[:H]        e_bar[v, :] += P[n, v] sum_j mask[v, j] Tbar[j, :]
 // (h1_bar, e_bar and out_bar are propagated once per fit by adjgrad_finish.)  T of a chunk of samples lives in the workspace
 // ([chunk][H][F + 1] floats: 0.5 GB for a Cora-shaped batch); one workgroup per sample throughout.
@@ -1277,13 +1277,12 @@ __global__ __launch_bounds__(256) void dadj_sample_kernel(const int64_t* __restr
   }
 }
 
-// value of one (sample, column node v) pair: sum_j mask[v, j] <Tbar[j, :], Ee[v, :]> + <phibar, H1e[v]>; optionally the
-// scatter adjoints of that entry (weight w = P[n, v]).  mk: [H] floats of LDS.  Every thread returns the value.
+// value of one (sample, column node v) pair: sum_j mask[v, j] <Tbar[j, :], Ee[v, :]> + <phibar, H1e[v]> (candidate pairs; the
+// stored entries take dadj_entry_kernel).  mk: [H] floats of LDS.  Every thread returns the value.
 __device__ __forceinline__ float dadj_pair(const float* __restrict__ Tm, const float* __restrict__ pbm, int64_t v, int64_t H,
                                            int64_t F, const float* __restrict__ mask, const float* __restrict__ PX, int64_t ldx,
-                                           const float* __restrict__ rowsum, const float* __restrict__ H1p, int64_t ldh, float w,
-                                           float* __restrict__ h1_bar, float* __restrict__ e_bar, float* __restrict__ mk,
-                                           float* __restrict__ red) {
+                                           const float* __restrict__ rowsum, const float* __restrict__ H1p, int64_t ldh,
+                                           float* __restrict__ mk, float* __restrict__ red) {
   const int tid = threadIdx.x;
   const int64_t F1 = F + 1;
   __syncthreads();
@@ -1295,12 +1294,8 @@ __device__ __forceinline__ float dadj_pair(const float* __restrict__ Tm, const f
     for (int64_t j = 0; j < H; ++j)
       if (mk[j] != 0.f) ca = fmaf(mk[j], Tm[j * F1 + i], ca);
     part = fmaf(ca, i < F ? PX[v * ldx + i] : rowsum[v], part);
-    if (e_bar && ca != 0.f) atomicAdd(&e_bar[v * F1 + i], w * ca);
   }
-  for (int64_t j = tid; j < H; j += 256) {
-    part = fmaf(pbm[j], H1p[v * ldh + j], part);
-    if (h1_bar) atomicAdd(&h1_bar[v * H + j], w * pbm[j]);
-  }
+  for (int64_t j = tid; j < H; j += 256) part = fmaf(pbm[j], H1p[v * ldh + j], part);
   if (tid == 0) part += pbm[H];
   return block_sum_256(part, red);
 }
@@ -1403,7 +1398,7 @@ __global__ __launch_bounds__(256) void dadj_cand_kernel(const int32_t* __restric
     if (m == INT32_MAX || m < m0 || m >= m0 + mc) continue;  // (uniform over the workgroup)
     const float* __restrict__ Tm = T + int64_t(m - m0) * H * (F + 1);
     const float* __restrict__ pbm = phibar + int64_t(m - m0) * (H + 1);
-    const float tot = dadj_pair(Tm, pbm, cb[k], H, F, mask, PX, ldx, rowsum, H1p, ldh, 0.f, nullptr, nullptr, mk, red);
+    const float tot = dadj_pair(Tm, pbm, cb[k], H, F, mask, PX, ldx, rowsum, H1p, ldh, mk, red);
     if (threadIdx.x == 0) grad_cand[k] += float(mult[m]) * tot;
   }
 }
