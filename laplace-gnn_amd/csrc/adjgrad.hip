@@ -1144,57 +1144,15 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {  // red: 4
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// T[m][j][i] = sum_v P[n, v] mask[v, j] Ee[v, i], n = idx[m0 + m]; the row's entries are staged VCH at a time
-__global__ __launch_bounds__(256) void dadj_T_kernel(const int64_t* __restrict__ idx, int64_t m0, int64_t N,
-                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                     const float* __restrict__ val, const float* __restrict__ mask, int64_t H,
-                                                     const float* __restrict__ PX, int64_t ldx, const float* __restrict__ rowsum,
-                                                     int64_t F, int VCH, float* __restrict__ T) {
-  extern __shared__ float sm[];
-  const int64_t F1 = F + 1, HF = H * F1;
-  float* __restrict__ wv = sm;                    // [VCH]
-  float* __restrict__ mk = wv + VCH;              // [VCH][H]
-  float* __restrict__ ev = mk + int64_t(VCH) * H; // [VCH][F1]
-  const int64_t n = idx[m0 + blockIdx.x];
-  float* __restrict__ Tm = T + int64_t(blockIdx.x) * HF;
-  const int tid = threadIdx.x;
-  if (n < 0 || n >= N) {  // flagged by the prologue
-    for (int64_t e = tid; e < HF; e += 256) Tm[e] = 0.f;
-    return;
-  }
-  const int32_t ps = rowptr[n], pe = rowptr[n + 1];
-  if (ps == pe)
-    for (int64_t e = tid; e < HF; e += 256) Tm[e] = 0.f;
-  for (int32_t p0 = ps; p0 < pe; p0 += VCH) {
-    const int un = min(VCH, pe - p0);
-    __syncthreads();
-    for (int64_t t = tid; t < int64_t(un) * (H + F1); t += 256) {
-      const int u = int(t / (H + F1));
-      const int64_t k = t - int64_t(u) * (H + F1);
-      const int64_t v = col[p0 + u];
-      if (k < H) mk[int64_t(u) * H + k] = mask[v * H + k];
-      else ev[int64_t(u) * F1 + (k - H)] = (k - H) < F ? PX[v * ldx + (k - H)] : rowsum[v];
-    }
-    if (tid < un) wv[tid] = val[p0 + tid];
-    __syncthreads();
-    for (int64_t e = tid; e < HF; e += 256) {
-      const int64_t j = e / F1, i = e - j * F1;
-      float acc = p0 == ps ? 0.f : Tm[e];
-      for (int u = 0; u < un; ++u) acc = fmaf(wv[u] * mk[int64_t(u) * H + j], ev[int64_t(u) * F1 + i], acc);
-      Tm[e] = acc;
-    }
-  }
-}
-
-// per sample: the adjoint of the logits (into out_bar), phibar [H + 1] and T -> Tbar in place
-__global__ __launch_bounds__(256) void dadj_sample_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
-                                                          int64_t m0, int64_t N, const float* __restrict__ probs, int64_t C,
-                                                          int64_t H, int64_t F, const float* __restrict__ W1,
-                                                          const float* __restrict__ PH, int64_t ldp,
-                                                          const float* __restrict__ rowsum, const float* __restrict__ gamma,
-                                                          float loss_scale, float* __restrict__ T, float* __restrict__ phibar,
-                                                          float* __restrict__ out_bar) {
-  extern __shared__ float sm[];
+// per sample, behind the tile (same workgroup, the tile still in L2): the adjoint of the logits (into out_bar), phibar [H + 1]
+// and T -> Tbar in place.  sm: (3 H + (H + 1) + 3 C + 4) floats of LDS.
+__device__ __forceinline__ void dadj_sample_part(float* __restrict__ sm, const int64_t* __restrict__ idx,
+                                                 const int64_t* __restrict__ y, int64_t m0, int64_t N,
+                                                 const float* __restrict__ probs, int64_t C, int64_t H, int64_t F,
+                                                 const float* __restrict__ W1, const float* __restrict__ PH, int64_t ldp,
+                                                 const float* __restrict__ rowsum, const float* __restrict__ gamma,
+                                                 float loss_scale, float* __restrict__ T, float* __restrict__ phibar,
+                                                 float* __restrict__ out_bar) {
   const int64_t F1 = F + 1, HF = H * F1, H1 = H + 1;
   float* __restrict__ r = sm;          // [H]
   float* __restrict__ q = r + H;       // [H]
@@ -1271,10 +1229,60 @@ __global__ __launch_bounds__(256) void dadj_sample_kernel(const int64_t* __restr
     for (int64_t c = 0; c < C; ++c) lg = fmaf(p[c] * (1.f - p[c]), j < H ? g1[c * H + j] : gb1[c], lg);
     pbm[j] = 2.f * phi[j] * lg;
   }
+  int64_t j = tid / F1, i = tid - j * F1;
   for (int64_t e = tid; e < HF; e += 256) {
-    const int64_t j = e / F1, i = e - j * F1;
     Tm[e] *= 2.f * q[j] * (i < F ? g0[j * F + i] : gb0[j]);
+    i += 256;
+    while (i >= F1) { i -= F1; ++j; }
   }
+}
+
+// T[m][j][i] = sum_v P[n, v] mask[v, j] Ee[v, i], n = idx[m0 + m]; the row's entries are staged VCH at a time.  The same
+// workgroup then runs the sample's part above on its tile (one launch, the tile read back from L2 instead of HBM).
+__global__ __launch_bounds__(256) void dadj_tile_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
+                                                        int64_t m0, int64_t N, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                        const float* __restrict__ mask, int64_t H, const float* __restrict__ PX,
+                                                        int64_t ldx, const float* __restrict__ rowsum, int64_t F, int VCH,
+                                                        const float* __restrict__ probs, int64_t C, const float* __restrict__ W1,
+                                                        const float* __restrict__ PH, int64_t ldp,
+                                                        const float* __restrict__ gamma, float loss_scale, float* __restrict__ T,
+                                                        float* __restrict__ phibar, float* __restrict__ out_bar) {
+  extern __shared__ float sm[];
+  const int64_t F1 = F + 1, HF = H * F1;
+  float* __restrict__ wv = sm;                    // [VCH]
+  float* __restrict__ mk = wv + VCH;              // [VCH][H]
+  float* __restrict__ ev = mk + int64_t(VCH) * H; // [VCH][F1]
+  const int64_t n = idx[m0 + blockIdx.x];
+  float* __restrict__ Tm = T + int64_t(blockIdx.x) * HF;
+  const int tid = threadIdx.x;
+  const bool valid = n >= 0 && n < N;  // (an invalid id is flagged by the prologue)
+  const int32_t ps = valid ? rowptr[n] : 0, pe = valid ? rowptr[n + 1] : 0;
+  if (ps == pe)
+    for (int64_t e = tid; e < HF; e += 256) Tm[e] = 0.f;
+  for (int32_t p0 = ps; p0 < pe; p0 += VCH) {
+    const int un = min(VCH, pe - p0);
+    __syncthreads();
+    for (int64_t t = tid; t < int64_t(un) * (H + F1); t += 256) {
+      const int u = int(t / (H + F1));
+      const int64_t k = t - int64_t(u) * (H + F1);
+      const int64_t v = col[p0 + u];
+      if (k < H) mk[int64_t(u) * H + k] = mask[v * H + k];
+      else ev[int64_t(u) * F1 + (k - H)] = (k - H) < F ? PX[v * ldx + (k - H)] : rowsum[v];
+    }
+    if (tid < un) wv[tid] = val[p0 + tid];
+    __syncthreads();
+    int64_t j = tid / F1, i = tid - j * F1;  // (j, i) of element e, advanced without a division per element
+    for (int64_t e = tid; e < HF; e += 256) {
+      float acc = p0 == ps ? 0.f : Tm[e];
+      for (int u = 0; u < un; ++u) acc = fmaf(wv[u] * mk[int64_t(u) * H + j], ev[int64_t(u) * F1 + i], acc);
+      Tm[e] = acc;
+      i += 256;
+      while (i >= F1) { i -= F1; ++j; }
+    }
+  }
+  __syncthreads();  // the tile is complete (and visible to the workgroup); the staging buffers are free
+  dadj_sample_part(sm, idx, y, m0, N, probs, C, H, F, W1, PH, ldp, rowsum, gamma, loss_scale, T, phibar, out_bar);
 }
 
 // value of one (sample, column node v) pair: sum_j mask[v, j] <Tbar[j, :], Ee[v, :]> + <phibar, H1e[v]> (candidate pairs; the
@@ -1419,10 +1427,6 @@ int diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   // T of a chunk of samples under the workspace cap
   const int64_t per_sample = H * F1 * 4;
   const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(M, h->ws_limit / per_sample));
-  LGNN_CALL(h->ws.jac.reserve(size_t(chunk) * per_sample));
-  LGNN_CALL(h->ws.misc.reserve(size_t(chunk) * (H + 1) * 4));
-  float* T = h->ws.jac.as<float>();
-  float* phibar = h->ws.misc.as<float>();
   const int vch = int(std::max<int64_t>(1, std::min<int64_t>(8, (60 * 1024 / 4) / (H + F1 + 1))));
   const size_t smem_t = size_t(vch) * (H + F1 + 1) * 4;
   LGNN_REQUIRE(smem_t <= 60 * 1024, "adjacency gradient, diagonal posterior: hidden + input width too large");
@@ -1434,13 +1438,16 @@ int diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   const float* PX = h->fc.prop_in[0].as<float>();
   const int64_t ldx = h->fc.prop_ld[0];
   const float* rowsum = h->fc.rowsum.as<float>();
+  LGNN_CALL(h->ws.jac.reserve(size_t(chunk) * per_sample));
+  LGNN_CALL(h->ws.misc.reserve(size_t(chunk) * (H + 1) * 4));
+  float* T = h->ws.jac.as<float>();
+  float* phibar = h->ws.misc.as<float>();
   for (int64_t m0 = 0; m0 < M; m0 += chunk) {
     const int64_t mc = std::min(chunk, M - m0);
-    hipLaunchKernelGGL(dadj_T_kernel, dim3(unsigned(mc)), dim3(256), smem_t, s, idx, m0, N, h->P.rowptr, h->P.col, h->P.val, mask,
-                       H, PX, ldx, rowsum, F, vch, T);
-    hipLaunchKernelGGL(dadj_sample_kernel, dim3(unsigned(mc)), dim3(256), smem_s, s, idx, static_cast<const int64_t*>(y), m0, N,
-                       h->ws.probs.as<float>(), C, H, F, h->W[1], h->fc.prop_in[1].as<float>(), h->fc.prop_ld[1], rowsum, gamma,
-                       loss_scale, T, phibar, out_bar);
+    hipLaunchKernelGGL(dadj_tile_kernel, dim3(unsigned(mc)), dim3(256), std::max(smem_t, smem_s), s, idx,
+                       static_cast<const int64_t*>(y), m0, N, h->P.rowptr, h->P.col, h->P.val, mask, H, PX, ldx, rowsum, F, vch,
+                       h->ws.probs.as<float>(), C, h->W[1], h->fc.prop_in[1].as<float>(), h->fc.prop_ld[1], gamma, loss_scale, T,
+                       phibar, out_bar);
     hipLaunchKernelGGL(dadj_entry_kernel, dim3(unsigned(mc)), dim3(256), smem_e, s, idx, m0, N, h->P.rowptr, h->P.col, h->P.val,
                        mask, H, PX, ldx, rowsum, F, h->fc.hact_p[0], h->fc.hact_ld[0], T, phibar, grad_P, h1_bar, e_bar);
     if (K > 0)
