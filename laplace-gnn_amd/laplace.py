@@ -923,7 +923,7 @@ class DiagLaplace(ParametricLaplace):
         STE-GCN configuration (gnn/configs/original/stegcn_config.yaml:7; gnn/marglik_training.py:197-216; the fork's
         Jacobians keep the graph, laplace/curvature/curvature.py:89-130).  Same return values and candidate pairs as
         ``KronLaplace.neg_marglik_adj_grad``.  2-layer GCN (STEGCN), classification; the diagonal GGN is a sum over samples, so
-        the loader's batch boundaries do not matter."""
+        the loader's batch boundaries do not matter and the ranks of a job split every batch by samples."""
         if self.H is None or not self.n_data:
             raise AttributeError("Laplace not fitted. Run fit() first.")
         if prior_precision is not None:
@@ -945,11 +945,14 @@ class DiagLaplace(ParametricLaplace):
         sym = bool(getattr(self.model, "symmetric", False))
         cand = _adjacency_candidates(eng, candidates, sym)
         eng.set_likelihood("classification")
-        for t, (X, y) in enumerate(train_loader):
-            if t % world != rank:
-                continue
-            eng.diag_adjgrad_batch(X.to(eng.device), y.to(eng.device), gamma, grad_P, out_bar, h1_bar, e_bar, loss_scale=f,
-                                   cand=cand)
+        for X, y in train_loader:
+            # every term is a sum over samples: inside a job every rank takes its slice of every batch (a Cora-shaped loader has
+            # ONE batch); a candidate pair sees a repeated node id through each slice's own multiplicity
+            M = X.shape[0]
+            lo, hi = M * rank // world, M * (rank + 1) // world
+            if hi > lo:
+                eng.diag_adjgrad_batch(X[lo:hi].to(eng.device), y[lo:hi].to(eng.device), gamma, grad_P, out_bar, h1_bar, e_bar,
+                                       loss_scale=f, cand=cand)
         if world > 1:
             all_reduce_flat_([grad_P, out_bar, h1_bar, e_bar] + ([cand[2]] if cand is not None else []), process_group)
         rows, cols = eng.export_adj()
