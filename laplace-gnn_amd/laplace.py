@@ -358,6 +358,44 @@ class ParametricLaplace(BaseLaplace):
         diag, vm, vsum = v[:, :C], v[:, C:C + 1], v[:, C + 1:]
         return f_mu, diag, 0.5 * C * (vsum - diag - vm), (C * C) * vm.squeeze(1)
 
+    _JACOBIAN_BYTES_MAX = 1 << 30  # above this size of Js [M, C, P] the full-covariance links go matrix free where they can
+
+    def _glm_covariance_matrix_free(self, x, budget_floats: int = 1 << 30):
+        """(f_mu [M, C], f_var [M, C, C]) without Jacobians, or None: the C (C + 1) / 2 variances var(f_c + f_c') of one
+        matrix-free pass (lgnn_glm_variance_mapped) give every entry by polarisation, cov(f_c, f_c') = (var(f_c + f_c') -
+        var(f_c) - var(f_c')) / 2.  Evaluation nodes go in chunks sized so that the rotated-row table of a chunk (needed nodes x
+        pairs x hidden floats) stays near ``budget_floats``.  Off-diagonal entries carry the rounding of the three variances
+        (absolute ~1e-6 of the diagonal): what ``link_approx="mc"`` needs of a model whose Jacobians do not fit."""
+        C = self.n_outputs
+        iu = torch.triu_indices(C, C, device=self._device)
+        if iu.shape[1] > 4096:
+            return None
+        E = torch.zeros(iu.shape[1], C, device=self._device)
+        ar = torch.arange(iu.shape[1], device=self._device)
+        E[ar, iu[0]] += 1.0
+        E[ar, iu[1]] += 1.0
+        eng = getattr(self.backend, "engine", None)
+        if eng is None:
+            return None
+        per_node = iu.shape[1] * eng.dims[1] * (eng.nnz / max(eng.num_nodes, 1) + 2.0)  # table floats per evaluation node
+        chunk = max(1, int(budget_floats / per_node))
+        dsel = (iu[0] == iu[1]).nonzero().squeeze(1)  # positions of the pairs (c, c): var(2 f_c) = 4 var(f_c)
+        mus, covs = [], []
+        for s0 in range(0, x.shape[0], chunk):
+            fast = self._glm_variance_matrix_free(x[s0:s0 + chunk], out_map=E)
+            if fast is None:
+                return None
+            f_mu, v = fast
+            d = 0.25 * v[:, dsel]
+            off = 0.5 * (v - d[:, iu[0]] - d[:, iu[1]])
+            cov = torch.zeros(v.shape[0], C, C, device=v.device)
+            cov[:, iu[0], iu[1]] = off
+            cov[:, iu[1], iu[0]] = off
+            cov[:, dsel.new_tensor(range(C)), dsel.new_tensor(range(C))] = d
+            mus.append(f_mu)
+            covs.append(cov)
+        return torch.cat(mus), torch.cat(covs)
+
     def _glm_predictive_distribution(self, x, diagonal_output: bool = False):
         """(f_mu [M, C], f_var [M, C, C]) (laplace/baselaplace.py:1123-1158); ``diagonal_output``: f_var [M, C], matrix free
         where the model family allows it."""
@@ -383,7 +421,19 @@ class ParametricLaplace(BaseLaplace):
             if diagonal_output:  # samples of N(f_mu, diag f_var): the diagonal is all that is read (:667-709)
                 f_mu, f_var_diag = self._glm_predictive_distribution(x, diagonal_output=True)
                 return self._glm_predictive_samples(f_mu, f_var_diag, n_samples, False, generator, eps).mean(dim=0)
-            f_mu, f_var = self._glm_predictive_distribution(x)
+            big = x.shape[0] * self.n_outputs * self.n_params * 4 > self._JACOBIAN_BYTES_MAX
+            full = self._glm_covariance_matrix_free(x) if big else None
+            if full is not None:
+                f_mu, f_var = full
+                # polarised off-diagonals can leave a node's matrix indefinite in the last bits: those nodes (if any) take the
+                # Jacobian route, 32 at a time
+                info = torch.linalg.cholesky_ex(f_var).info
+                bad = info.nonzero().squeeze(1)
+                for b0 in range(0, bad.numel(), 32):
+                    sel = bad[b0:b0 + 32]
+                    f_var[sel] = self._glm_predictive_distribution(x[sel])[1]
+            else:
+                f_mu, f_var = self._glm_predictive_distribution(x)
             return self._glm_predictive_samples(f_mu, f_var, n_samples, diagonal_output, generator, eps).mean(dim=0)
         # Laplace bridge with zero-mean correction (:630-660): reads the diagonal, the row sums and the total of f_var only
         moments = self._bridge_moments_matrix_free(x)

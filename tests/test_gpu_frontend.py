@@ -555,6 +555,36 @@ def test_variances_of_an_arbitrary_linear_map_of_the_logits(name, rows):
     model.engine.check_async_errors()
 
 
+@pytest.mark.parametrize("name", ["gcn_mid_3batch_sym_s1", "sage_mid_2batch_s2", "gcn_small_isolated_s0"])
+def test_full_predictive_covariance_without_jacobians(name, monkeypatch):
+    """``link_approx="mc"`` samples N(f_mu, f_var) with the full C x C covariance: beyond the size where Jacobians fit, f_var comes
+    from C (C + 1) / 2 polarised variances of one matrix-free pass.  Against the reference's f_var golden and, with the golden's own
+    draws, the reference's ``mc`` output; evaluation nodes in several chunks."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = model_from_golden(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(),
+                                  batch_size=int(g["batch_size"]))
+    x = torch.from_numpy(g["pred_idx"]).cuda()
+    eps = torch.from_numpy(g["glm_eps"]).cuda()
+    for cls, key in ((lg.KronLaplace, "kron"), (lg.DiagLaplace, "diag")):
+        la = cls(model, "classification")
+        la.fit(loader)
+        f_mu, f_var = la._glm_covariance_matrix_free(x, budget_floats=20_000)  # a few evaluation nodes per chunk
+        assert rel(f_mu.cpu().numpy(), g[key + "_glm_fmu"]) < 1e-5
+        # against this fit's own Jacobian route (same factors) and the reference's golden (whose distance also holds the factors'
+        # run-to-run last bits amplified through the small eigenvalues: 5e-4 as in test_frontend_golden)
+        assert rel(f_var.cpu().numpy(), la._glm_predictive_distribution(x)[1].cpu().numpy()) < 1e-4, key
+        assert rel(f_var.cpu().numpy(), g[key + "_glm_fvar"]) < 5e-4, key
+        assert float((f_var - f_var.transpose(1, 2)).abs().max()) == 0.0
+        monkeypatch.setattr(type(la), "_JACOBIAN_BYTES_MAX", 0)  # every call counts as "too large for Jacobians"
+        mc = la(x, link_approx="mc", n_samples=eps.shape[1], eps=eps)
+        assert np.abs(mc.cpu().numpy() - g[key + "_glm_mc"]).max() < 5e-5, key
+        monkeypatch.undo()
+    model.engine.check_async_errors()
+
+
 def test_decomposition_groups_small_factors_and_caches_large_ones():
     """Kron.decompose on the GPU: factors of up to 256 rows share one call of the hand-written path, larger ones (a
     Cora-shaped model's 1 433 x 1 433 input covariance) get a call of their own and are served from the CALLER's cache under

@@ -545,6 +545,20 @@ def test_glm_predictive_on_every_node_of_the_arxiv_shape(arxiv):
     assert rel(bridge[sub].cpu().numpy(), la(sub, link_approx="bridge_norm").cpu().numpy()) < 1e-5
     print(f"Laplace bridge of {w['N']} nodes: {dt * 1e3:.1f} ms")
     assert dt < 60.0
+    # link_approx="mc" over the full covariance of 3 000 nodes (their Jacobians would be 20 GB): 820 polarised variances per node
+    many = torch.randperm(w["N"], generator=torch.Generator().manual_seed(3))[:3000].cuda()
+    many[:24] = sub
+    eps = torch.randn(w["C"], 20, generator=torch.Generator().manual_seed(4)).cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mc = la(many, link_approx="mc", n_samples=20, eps=eps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert mc.shape == (3000, w["C"]) and bool(torch.isfinite(mc).all()) and float((mc.sum(-1) - 1).abs().max()) < 1e-4
+    ref_mc = la._glm_predictive_samples(f, fv, 20, False, None, eps).mean(dim=0)  # the 24 nodes through their Jacobians
+    assert float((mc[:24] - ref_mc).abs().max()) < 1e-4
+    print(f"mc link (full covariance) of 3000 nodes: {dt * 1e3:.1f} ms")
+    assert dt < 120.0
 
 
 # ---- independent reference of the dominant kernel's output at the headline shape -------------------
