@@ -1114,7 +1114,7 @@ namespace {
 //     gradP[(n, v)] += sum_j mask[v, j] <Tbar[j, :], Ee[v, :]> + <phibar, H1e[v]>          (dadj_entry_kernel; candidates: dadj_cand_kernel)
 //     h1_bar[v] += P[n, v] phibar[:H]        e_bar[v, :] += P[n, v] sum_j mask[v, j] Tbar[j, :]
 // (h1_bar, e_bar and out_bar are propagated once per fit by adjgrad_finish.)  T of a chunk of samples lives in the workspace
-// ([chunk][H][F + 1] floats: 0.5 GB for a Cora-shaped batch); one workgroup per sample throughout.
+// ([chunk][H][F + 1 rounded up to 4] floats: 0.5 GB for a Cora-shaped batch); one workgroup per sample throughout.
 
 __global__ void add_inplace_kernel(float* __restrict__ x, const float* __restrict__ y, int64_t n) {
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
@@ -1153,7 +1153,7 @@ __device__ __forceinline__ void dadj_sample_part(float* __restrict__ sm, const i
                                                  const float* __restrict__ rowsum, const float* __restrict__ gamma,
                                                  float loss_scale, float* __restrict__ T, float* __restrict__ phibar,
                                                  float* __restrict__ out_bar) {
-  const int64_t F1 = F + 1, HF = H * F1, H1 = H + 1;
+  const int64_t F1 = F + 1, FP = (F1 + 3) & ~int64_t(3), H1 = H + 1;  // tile rows are FP floats apart (16-byte rows)
   float* __restrict__ r = sm;          // [H]
   float* __restrict__ q = r + H;       // [H]
   float* __restrict__ mv = q + H;      // [H]
@@ -1169,7 +1169,7 @@ __device__ __forceinline__ void dadj_sample_part(float* __restrict__ sm, const i
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t m = m0 + blockIdx.x;
   const int64_t n = idx[m];
-  float* __restrict__ Tm = T + int64_t(blockIdx.x) * HF;
+  float* __restrict__ Tm = T + int64_t(blockIdx.x) * H * FP;
   float* __restrict__ pbm = phibar + int64_t(blockIdx.x) * H1;
   if (n < 0 || n >= N) {
     for (int64_t j = tid; j < H1; j += 256) pbm[j] = 0.f;
@@ -1181,7 +1181,7 @@ __device__ __forceinline__ void dadj_sample_part(float* __restrict__ sm, const i
   for (int64_t j = wave; j < H; j += 4) {
     float acc = 0.f;
     for (int64_t i = lane; i < F1; i += 64) {
-      const float t = Tm[j * F1 + i];
+      const float t = Tm[j * FP + i];
       acc = fmaf((i < F ? g0[j * F + i] : gb0[j]) * t, t, acc);
     }
 #pragma unroll
@@ -1229,11 +1229,9 @@ __device__ __forceinline__ void dadj_sample_part(float* __restrict__ sm, const i
     for (int64_t c = 0; c < C; ++c) lg = fmaf(p[c] * (1.f - p[c]), j < H ? g1[c * H + j] : gb1[c], lg);
     pbm[j] = 2.f * phi[j] * lg;
   }
-  int64_t j = tid / F1, i = tid - j * F1;
-  for (int64_t e = tid; e < HF; e += 256) {
-    Tm[e] *= 2.f * q[j] * (i < F ? g0[j * F + i] : gb0[j]);
-    i += 256;
-    while (i >= F1) { i -= F1; ++j; }
+  for (int64_t j = wave; j < H; j += 4) {  // T -> Tbar (the padding columns hold zeros)
+    const float qj = 2.f * q[j];
+    for (int64_t i = lane; i < F1; i += 64) Tm[j * FP + i] *= qj * (i < F ? g0[j * F + i] : gb0[j]);
   }
 }
 
@@ -1248,37 +1246,54 @@ __global__ __launch_bounds__(256) void dadj_tile_kernel(const int64_t* __restric
                                                         const float* __restrict__ PH, int64_t ldp,
                                                         const float* __restrict__ gamma, float loss_scale, float* __restrict__ T,
                                                         float* __restrict__ phibar, float* __restrict__ out_bar) {
-  extern __shared__ float sm[];
-  const int64_t F1 = F + 1, HF = H * F1;
-  float* __restrict__ wv = sm;                    // [VCH]
-  float* __restrict__ mk = wv + VCH;              // [VCH][H]
-  float* __restrict__ ev = mk + int64_t(VCH) * H; // [VCH][F1]
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int64_t F1 = F + 1, FP = (F1 + 3) & ~int64_t(3), HP = (H + 3) & ~int64_t(3);
+  float* __restrict__ mk = sm;                     // [VCH][HP]  w_u * mask rows, zero padded
+  float* __restrict__ ev = mk + int64_t(VCH) * HP; // [VCH][FP]  rows of Ee, zero padded
   const int64_t n = idx[m0 + blockIdx.x];
-  float* __restrict__ Tm = T + int64_t(blockIdx.x) * HF;
+  float* __restrict__ Tm = T + int64_t(blockIdx.x) * H * FP;
   const int tid = threadIdx.x;
   const bool valid = n >= 0 && n < N;  // (an invalid id is flagged by the prologue)
   const int32_t ps = valid ? rowptr[n] : 0, pe = valid ? rowptr[n + 1] : 0;
   if (ps == pe)
-    for (int64_t e = tid; e < HF; e += 256) Tm[e] = 0.f;
+    for (int64_t e = tid; e < H * FP; e += 256) Tm[e] = 0.f;
+  // thread <-> 4 x 4 sub-tiles (rows 4 jb .., columns 4 ib ..): two 16-byte LDS reads per 16 FMAs and staged entry
+  const int nI = int(FP / 4), nSub = int(HP / 4) * nI;
   for (int32_t p0 = ps; p0 < pe; p0 += VCH) {
     const int un = min(VCH, pe - p0);
     __syncthreads();
-    for (int64_t t = tid; t < int64_t(un) * (H + F1); t += 256) {
-      const int u = int(t / (H + F1));
-      const int64_t k = t - int64_t(u) * (H + F1);
+    for (int64_t t = tid; t < int64_t(un) * (HP + FP); t += 256) {
+      const int u = int(t / (HP + FP));
+      const int64_t k = t - int64_t(u) * (HP + FP);
       const int64_t v = col[p0 + u];
-      if (k < H) mk[int64_t(u) * H + k] = mask[v * H + k];
-      else ev[int64_t(u) * F1 + (k - H)] = (k - H) < F ? PX[v * ldx + (k - H)] : rowsum[v];
+      if (k < HP) mk[int64_t(u) * HP + k] = k < H ? val[p0 + u] * mask[v * H + k] : 0.f;
+      else {
+        const int64_t i = k - HP;
+        ev[int64_t(u) * FP + i] = i < F ? PX[v * ldx + i] : (i == F ? rowsum[v] : 0.f);
+      }
     }
-    if (tid < un) wv[tid] = val[p0 + tid];
     __syncthreads();
-    int64_t j = tid / F1, i = tid - j * F1;  // (j, i) of element e, advanced without a division per element
-    for (int64_t e = tid; e < HF; e += 256) {
-      float acc = p0 == ps ? 0.f : Tm[e];
-      for (int u = 0; u < un; ++u) acc = fmaf(wv[u] * mk[int64_t(u) * H + j], ev[int64_t(u) * F1 + i], acc);
-      Tm[e] = acc;
-      i += 256;
-      while (i >= F1) { i -= F1; ++j; }
+    for (int st = tid; st < nSub; st += 256) {
+      const int jb = st / nI, ib = st - jb * nI;
+      float4 acc[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int64_t j = 4 * jb + rr;
+        acc[rr] = (p0 == ps || j >= H) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(Tm + j * FP + 4 * ib);
+      }
+      for (int u = 0; u < un; ++u) {
+        const float4 m4 = *reinterpret_cast<const float4*>(mk + int64_t(u) * HP + 4 * jb);
+        const float4 e4 = *reinterpret_cast<const float4*>(ev + int64_t(u) * FP + 4 * ib);
+        acc[0].x = fmaf(m4.x, e4.x, acc[0].x); acc[0].y = fmaf(m4.x, e4.y, acc[0].y); acc[0].z = fmaf(m4.x, e4.z, acc[0].z); acc[0].w = fmaf(m4.x, e4.w, acc[0].w);
+        acc[1].x = fmaf(m4.y, e4.x, acc[1].x); acc[1].y = fmaf(m4.y, e4.y, acc[1].y); acc[1].z = fmaf(m4.y, e4.z, acc[1].z); acc[1].w = fmaf(m4.y, e4.w, acc[1].w);
+        acc[2].x = fmaf(m4.z, e4.x, acc[2].x); acc[2].y = fmaf(m4.z, e4.y, acc[2].y); acc[2].z = fmaf(m4.z, e4.z, acc[2].z); acc[2].w = fmaf(m4.z, e4.w, acc[2].w);
+        acc[3].x = fmaf(m4.w, e4.x, acc[3].x); acc[3].y = fmaf(m4.w, e4.y, acc[3].y); acc[3].z = fmaf(m4.w, e4.z, acc[3].z); acc[3].w = fmaf(m4.w, e4.w, acc[3].w);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int64_t j = 4 * jb + rr;
+        if (j < H) *reinterpret_cast<float4*>(Tm + j * FP + 4 * ib) = acc[rr];
+      }
     }
   }
   __syncthreads();  // the tile is complete (and visible to the workgroup); the staging buffers are free
@@ -1292,7 +1307,7 @@ __device__ __forceinline__ float dadj_pair(const float* __restrict__ Tm, const f
                                            const float* __restrict__ rowsum, const float* __restrict__ H1p, int64_t ldh,
                                            float* __restrict__ mk, float* __restrict__ red) {
   const int tid = threadIdx.x;
-  const int64_t F1 = F + 1;
+  const int64_t F1 = F + 1, FP = (F1 + 3) & ~int64_t(3);
   __syncthreads();
   for (int64_t j = tid; j < H; j += 256) mk[j] = mask[v * H + j];
   __syncthreads();
@@ -1300,7 +1315,7 @@ __device__ __forceinline__ float dadj_pair(const float* __restrict__ Tm, const f
   for (int64_t i = tid; i < F1; i += 256) {
     float ca = 0.f;
     for (int64_t j = 0; j < H; ++j)
-      if (mk[j] != 0.f) ca = fmaf(mk[j], Tm[j * F1 + i], ca);
+      if (mk[j] != 0.f) ca = fmaf(mk[j], Tm[j * FP + i], ca);
     part = fmaf(ca, i < F ? PX[v * ldx + i] : rowsum[v], part);
   }
   for (int64_t j = tid; j < H; j += 256) part = fmaf(pbm[j], H1p[v * ldh + j], part);
@@ -1325,10 +1340,10 @@ __global__ __launch_bounds__(256) void dadj_entry_kernel(const int64_t* __restri
   float* __restrict__ wv = red + 4 * EV;         // [EV]
   int32_t* __restrict__ vid = reinterpret_cast<int32_t*>(wv + EV);  // [EV]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t F1 = F + 1;
+  const int64_t F1 = F + 1, FP = (F1 + 3) & ~int64_t(3);
   const int64_t n = idx[m0 + blockIdx.x];
   if (n < 0 || n >= N) return;
-  const float* __restrict__ Tm = T + int64_t(blockIdx.x) * H * F1;
+  const float* __restrict__ Tm = T + int64_t(blockIdx.x) * H * FP;
   const float* __restrict__ pbm = phibar + int64_t(blockIdx.x) * (H + 1);
   const int32_t ps = rowptr[n], pe = rowptr[n + 1];
   for (int32_t p0 = ps; p0 < pe; p0 += EV) {
@@ -1353,7 +1368,7 @@ __global__ __launch_bounds__(256) void dadj_entry_kernel(const int64_t* __restri
 #pragma unroll
       for (int u = 0; u < EV; ++u) ca[u] = 0.f;
       for (int64_t j = 0; j < H; ++j) {
-        const float t = Tm[j * F1 + i];
+        const float t = Tm[j * FP + i];
         const float4 m0v = *reinterpret_cast<const float4*>(mk + j * EV);
         const float4 m1v = *reinterpret_cast<const float4*>(mk + j * EV + 4);
         ca[0] = fmaf(m0v.x, t, ca[0]); ca[1] = fmaf(m0v.y, t, ca[1]); ca[2] = fmaf(m0v.z, t, ca[2]); ca[3] = fmaf(m0v.w, t, ca[3]);
@@ -1404,7 +1419,7 @@ __global__ __launch_bounds__(256) void dadj_cand_kernel(const int32_t* __restric
   for (int64_t k = blockIdx.x; k < K; k += gridDim.x) {
     const int32_t m = pos[ca[k]];
     if (m == INT32_MAX || m < m0 || m >= m0 + mc) continue;  // (uniform over the workgroup)
-    const float* __restrict__ Tm = T + int64_t(m - m0) * H * (F + 1);
+    const float* __restrict__ Tm = T + int64_t(m - m0) * H * ((F + 4) & ~int64_t(3));
     const float* __restrict__ pbm = phibar + int64_t(m - m0) * (H + 1);
     const float tot = dadj_pair(Tm, pbm, cb[k], H, F, mask, PX, ldx, rowsum, H1p, ldh, mk, red);
     if (threadIdx.x == 0) grad_cand[k] += float(mult[m]) * tot;
@@ -1425,10 +1440,11 @@ int diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   LGNN_REQUIRE(h->in_dim[1] == H, "internal: GCN head stride");
   LGNN_CALL(batch_prologue(h, idx, y, M, false, false, nullptr, s));
   // T of a chunk of samples under the workspace cap
-  const int64_t per_sample = H * F1 * 4;
+  const int64_t FP = (F1 + 3) & ~int64_t(3), HP = (H + 3) & ~int64_t(3);  // tile rows / staged rows padded to 16 bytes
+  const int64_t per_sample = H * FP * 4;
   const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(M, h->ws_limit / per_sample));
-  const int vch = int(std::max<int64_t>(1, std::min<int64_t>(8, (60 * 1024 / 4) / (H + F1 + 1))));
-  const size_t smem_t = size_t(vch) * (H + F1 + 1) * 4;
+  const int vch = int(std::max<int64_t>(1, std::min<int64_t>(8, (60 * 1024 / 4) / (HP + FP))));
+  const size_t smem_t = size_t(vch) * (HP + FP) * 4;
   LGNN_REQUIRE(smem_t <= 60 * 1024, "adjacency gradient, diagonal posterior: hidden + input width too large");
   const size_t smem_s = size_t(3 * H + (H + 1) + 3 * C + 4) * 4;
   LGNN_REQUIRE(smem_s <= 60 * 1024, "adjacency gradient, diagonal posterior: hidden width / classes too large");
