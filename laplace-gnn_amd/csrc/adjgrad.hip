@@ -1144,99 +1144,18 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {  // red: 4
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// per sample, behind the tile (same workgroup, the tile still in L2): the adjoint of the logits (into out_bar), phibar [H + 1]
-// and T -> Tbar in place.  sm: (3 H + (H + 1) + 3 C + 4) floats of LDS.
-__device__ __forceinline__ void dadj_sample_part(float* __restrict__ sm, const int64_t* __restrict__ idx,
-                                                 const int64_t* __restrict__ y, int64_t m0, int64_t N,
-                                                 const float* __restrict__ probs, int64_t C, int64_t H, int64_t F,
-                                                 const float* __restrict__ W1, const float* __restrict__ PH, int64_t ldp,
-                                                 const float* __restrict__ rowsum, const float* __restrict__ gamma,
-                                                 float loss_scale, float* __restrict__ T, float* __restrict__ phibar,
-                                                 float* __restrict__ out_bar) {
-  const int64_t F1 = F + 1, FP = (F1 + 3) & ~int64_t(3), H1 = H + 1;  // tile rows are FP floats apart (16-byte rows)
-  float* __restrict__ r = sm;          // [H]
-  float* __restrict__ q = r + H;       // [H]
-  float* __restrict__ mv = q + H;      // [H]
-  float* __restrict__ phi = mv + H;    // [H + 1]
-  float* __restrict__ p = phi + H1;    // [C]
-  float* __restrict__ a = p + C;       // [C]
-  float* __restrict__ pb = a + C;      // [C]
-  float* __restrict__ red = pb + C;    // [4]
-  const float* __restrict__ g0 = gamma;
-  const float* __restrict__ gb0 = g0 + H * F;
-  const float* __restrict__ g1 = gb0 + H;
-  const float* __restrict__ gb1 = g1 + C * H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m = m0 + blockIdx.x;
-  const int64_t n = idx[m];
-  float* __restrict__ Tm = T + int64_t(blockIdx.x) * H * FP;
-  float* __restrict__ pbm = phibar + int64_t(blockIdx.x) * H1;
-  if (n < 0 || n >= N) {
-    for (int64_t j = tid; j < H1; j += 256) pbm[j] = 0.f;
-    return;  // T is zero already
+// The per-sample arrays of the tile kernel in LDS: r, q, mv [H], phi [H + 1], p, a, pb [C], red [4].
+struct DadjSample {
+  float *r, *q, *mv, *phi, *p, *a, *pb, *red;
+  __device__ DadjSample(float* s, int64_t H, int64_t C) {
+    r = s; q = r + H; mv = q + H; phi = mv + H; p = phi + H + 1; a = p + C; pb = a + C; red = pb + C;
   }
-  for (int64_t c = tid; c < C; c += 256) p[c] = probs[m * C + c];
-  for (int64_t j = tid; j < H1; j += 256) phi[j] = j < H ? PH[n * ldp + j] : rowsum[n];
-  // r[j] = sum_i g0e[j, i] T[j, i]^2
-  for (int64_t j = wave; j < H; j += 4) {
-    float acc = 0.f;
-    for (int64_t i = lane; i < F1; i += 64) {
-      const float t = Tm[j * FP + i];
-      acc = fmaf((i < F ? g0[j * F + i] : gb0[j]) * t, t, acc);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) r[j] = acc;
-  }
-  __syncthreads();
-  for (int64_t j = tid; j < H; j += 256) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int64_t c = 0; c < C; ++c) {
-      const float w = W1[c * H + j];
-      s1 = fmaf(p[c], w, s1);
-      s2 = fmaf(p[c] * w, w, s2);
-    }
-    mv[j] = s1;
-    q[j] = s2 - s1 * s1;
-  }
-  for (int64_t c = wave; c < C; c += 4) {
-    float acc = 0.f;
-    for (int64_t j = lane; j < H1; j += 64) acc = fmaf((j < H ? g1[c * H + j] : gb1[c]) * phi[j], phi[j], acc);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) a[c] = acc;
-  }
-  __syncthreads();
-  for (int64_t c = wave; c < C; c += 4) {
-    float acc = 0.f;
-    for (int64_t j = lane; j < H; j += 64) {
-      const float w = W1[c * H + j];
-      acc = fmaf(r[j], w * w - 2.f * w * mv[j], acc);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) pb[c] = (1.f - 2.f * p[c]) * a[c] + acc;
-  }
-  __syncthreads();
-  float part = 0.f;
-  for (int64_t c = tid; c < C; c += 256) part = fmaf(p[c], pb[c], part);
-  const float dot = block_sum_256(part, red);
-  const int64_t yc = y[m];
-  for (int64_t c = tid; c < C; c += 256)
-    atomicAdd(&out_bar[n * C + c], p[c] * (pb[c] - dot) + loss_scale * (p[c] - (c == yc ? 1.f : 0.f)));
-  for (int64_t j = tid; j < H1; j += 256) {
-    float lg = 0.f;
-    for (int64_t c = 0; c < C; ++c) lg = fmaf(p[c] * (1.f - p[c]), j < H ? g1[c * H + j] : gb1[c], lg);
-    pbm[j] = 2.f * phi[j] * lg;
-  }
-  for (int64_t j = wave; j < H; j += 4) {  // T -> Tbar (the padding columns hold zeros)
-    const float qj = 2.f * q[j];
-    for (int64_t i = lane; i < F1; i += 64) Tm[j * FP + i] *= qj * (i < F ? g0[j * F + i] : gb0[j]);
-  }
-}
+};
 
-// T[m][j][i] = sum_v P[n, v] mask[v, j] Ee[v, i], n = idx[m0 + m]; the row's entries are staged VCH at a time.  The same
-// workgroup then runs the sample's part above on its tile (one launch, the tile read back from L2 instead of HBM).
+// T[m][j][:] = sum_v P[n, v] mask[v, j] Ee[v, :], n = idx[m0 + m] -- and everything else of the sample, in one pass over the
+// tile: p, q (which needs the softmax and W_1 only) first; the row's entries staged VCH at a time, thread <-> 4 x 4 sub-tiles
+// in registers (two 16-byte LDS reads per 16 FMAs and staged entry); with the LAST group of entries a sub-tile leaves as
+// Tbar = 2 q g0e T and adds its share of r[j] = sum_i g0e T^2 (LDS atomics); then the last layer and the logits' adjoint.
 __global__ __launch_bounds__(256) void dadj_tile_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
                                                         int64_t m0, int64_t N, const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col, const float* __restrict__ val,
@@ -1247,20 +1166,45 @@ __global__ __launch_bounds__(256) void dadj_tile_kernel(const int64_t* __restric
                                                         const float* __restrict__ gamma, float loss_scale, float* __restrict__ T,
                                                         float* __restrict__ phibar, float* __restrict__ out_bar) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int64_t F1 = F + 1, FP = (F1 + 3) & ~int64_t(3), HP = (H + 3) & ~int64_t(3);
+  const int64_t F1 = F + 1, FP = (F1 + 3) & ~int64_t(3), HP = (H + 3) & ~int64_t(3), H1 = H + 1;
   float* __restrict__ mk = sm;                     // [VCH][HP]  w_u * mask rows, zero padded
   float* __restrict__ ev = mk + int64_t(VCH) * HP; // [VCH][FP]  rows of Ee, zero padded
-  const int64_t n = idx[m0 + blockIdx.x];
+  const DadjSample S(ev + int64_t(VCH) * FP, H, C);
+  const float* __restrict__ g0 = gamma;
+  const float* __restrict__ gb0 = g0 + H * F;
+  const float* __restrict__ g1 = gb0 + H;
+  const float* __restrict__ gb1 = g1 + C * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m = m0 + blockIdx.x;
+  const int64_t n = idx[m];
   float* __restrict__ Tm = T + int64_t(blockIdx.x) * H * FP;
-  const int tid = threadIdx.x;
-  const bool valid = n >= 0 && n < N;  // (an invalid id is flagged by the prologue)
-  const int32_t ps = valid ? rowptr[n] : 0, pe = valid ? rowptr[n + 1] : 0;
+  float* __restrict__ pbm = phibar + int64_t(blockIdx.x) * H1;
+  if (n < 0 || n >= N) {  // flagged by the prologue: contributes nothing
+    for (int64_t e = tid; e < H * FP; e += 256) Tm[e] = 0.f;
+    for (int64_t j = tid; j < H1; j += 256) pbm[j] = 0.f;
+    return;
+  }
+  for (int64_t c = tid; c < C; c += 256) S.p[c] = probs[m * C + c];
+  for (int64_t j = tid; j < H1; j += 256) S.phi[j] = j < H ? PH[n * ldp + j] : rowsum[n];
+  __syncthreads();
+  for (int64_t j = tid; j < H; j += 256) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t c = 0; c < C; ++c) {
+      const float w = W1[c * H + j];
+      s1 = fmaf(S.p[c], w, s1);
+      s2 = fmaf(S.p[c] * w, w, s2);
+    }
+    S.mv[j] = s1;
+    S.q[j] = s2 - s1 * s1;
+    S.r[j] = 0.f;
+  }
+  const int32_t ps = rowptr[n], pe = rowptr[n + 1];
   if (ps == pe)
     for (int64_t e = tid; e < H * FP; e += 256) Tm[e] = 0.f;
-  // thread <-> 4 x 4 sub-tiles (rows 4 jb .., columns 4 ib ..): two 16-byte LDS reads per 16 FMAs and staged entry
   const int nI = int(FP / 4), nSub = int(HP / 4) * nI;
   for (int32_t p0 = ps; p0 < pe; p0 += VCH) {
     const int un = min(VCH, pe - p0);
+    const bool last = p0 + VCH >= pe;
     __syncthreads();
     for (int64_t t = tid; t < int64_t(un) * (HP + FP); t += 256) {
       const int u = int(t / (HP + FP));
@@ -1275,29 +1219,75 @@ __global__ __launch_bounds__(256) void dadj_tile_kernel(const int64_t* __restric
     __syncthreads();
     for (int st = tid; st < nSub; st += 256) {
       const int jb = st / nI, ib = st - jb * nI;
-      float4 acc[4];
+      float acc[4][4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int64_t j = 4 * jb + rr;
-        acc[rr] = (p0 == ps || j >= H) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(Tm + j * FP + 4 * ib);
+        const float4 t4 = (p0 == ps || j >= H) ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                               : *reinterpret_cast<const float4*>(Tm + j * FP + 4 * ib);
+        acc[rr][0] = t4.x; acc[rr][1] = t4.y; acc[rr][2] = t4.z; acc[rr][3] = t4.w;
       }
       for (int u = 0; u < un; ++u) {
         const float4 m4 = *reinterpret_cast<const float4*>(mk + int64_t(u) * HP + 4 * jb);
         const float4 e4 = *reinterpret_cast<const float4*>(ev + int64_t(u) * FP + 4 * ib);
-        acc[0].x = fmaf(m4.x, e4.x, acc[0].x); acc[0].y = fmaf(m4.x, e4.y, acc[0].y); acc[0].z = fmaf(m4.x, e4.z, acc[0].z); acc[0].w = fmaf(m4.x, e4.w, acc[0].w);
-        acc[1].x = fmaf(m4.y, e4.x, acc[1].x); acc[1].y = fmaf(m4.y, e4.y, acc[1].y); acc[1].z = fmaf(m4.y, e4.z, acc[1].z); acc[1].w = fmaf(m4.y, e4.w, acc[1].w);
-        acc[2].x = fmaf(m4.z, e4.x, acc[2].x); acc[2].y = fmaf(m4.z, e4.y, acc[2].y); acc[2].z = fmaf(m4.z, e4.z, acc[2].z); acc[2].w = fmaf(m4.z, e4.w, acc[2].w);
-        acc[3].x = fmaf(m4.w, e4.x, acc[3].x); acc[3].y = fmaf(m4.w, e4.y, acc[3].y); acc[3].z = fmaf(m4.w, e4.z, acc[3].z); acc[3].w = fmaf(m4.w, e4.w, acc[3].w);
+        const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = fmaf(mm[rr], ee[cc], acc[rr][cc]);
       }
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int64_t j = 4 * jb + rr;
-        if (j < H) *reinterpret_cast<float4*>(Tm + j * FP + 4 * ib) = acc[rr];
+        if (j >= H) continue;
+        if (last) {  // T -> Tbar on the way out, r[j] from the unscaled entries
+          const float qj = 2.f * S.q[j];
+          float rs = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int64_t i = 4 * ib + cc;
+            const float g = i < F ? g0[j * F + i] : (i == F ? gb0[j] : 0.f);
+            const float t = acc[rr][cc];
+            rs = fmaf(g * t, t, rs);
+            acc[rr][cc] = qj * g * t;
+          }
+          atomicAdd(&S.r[j], rs);
+        }
+        *reinterpret_cast<float4*>(Tm + j * FP + 4 * ib) = make_float4(acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]);
       }
     }
   }
-  __syncthreads();  // the tile is complete (and visible to the workgroup); the staging buffers are free
-  dadj_sample_part(sm, idx, y, m0, N, probs, C, H, F, W1, PH, ldp, rowsum, gamma, loss_scale, T, phibar, out_bar);
+  __syncthreads();  // r is complete
+  for (int64_t c = wave; c < C; c += 4) {
+    float acc = 0.f;
+    for (int64_t j = lane; j < H1; j += 64) acc = fmaf((j < H ? g1[c * H + j] : gb1[c]) * S.phi[j], S.phi[j], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) S.a[c] = acc;
+  }
+  __syncthreads();
+  for (int64_t c = wave; c < C; c += 4) {
+    float acc = 0.f;
+    for (int64_t j = lane; j < H; j += 64) {
+      const float w = W1[c * H + j];
+      acc = fmaf(S.r[j], w * w - 2.f * w * S.mv[j], acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) S.pb[c] = (1.f - 2.f * S.p[c]) * S.a[c] + acc;
+  }
+  __syncthreads();
+  float part = 0.f;
+  for (int64_t c = tid; c < C; c += 256) part = fmaf(S.p[c], S.pb[c], part);
+  const float dot = block_sum_256(part, S.red);
+  const int64_t yc = y[m];
+  for (int64_t c = tid; c < C; c += 256)
+    atomicAdd(&out_bar[n * C + c], S.p[c] * (S.pb[c] - dot) + loss_scale * (S.p[c] - (c == yc ? 1.f : 0.f)));
+  for (int64_t j = tid; j < H1; j += 256) {
+    float lg = 0.f;
+    for (int64_t c = 0; c < C; ++c) lg = fmaf(S.p[c] * (1.f - S.p[c]), j < H ? g1[c * H + j] : gb1[c], lg);
+    pbm[j] = 2.f * S.phi[j] * lg;
+  }
 }
 
 // value of one (sample, column node v) pair: sum_j mask[v, j] <Tbar[j, :], Ee[v, :]> + <phibar, H1e[v]> (candidate pairs; the
@@ -1443,11 +1433,11 @@ int diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   const int64_t FP = (F1 + 3) & ~int64_t(3), HP = (H + 3) & ~int64_t(3);  // tile rows / staged rows padded to 16 bytes
   const int64_t per_sample = H * FP * 4;
   const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(M, h->ws_limit / per_sample));
-  const int vch = int(std::max<int64_t>(1, std::min<int64_t>(8, (60 * 1024 / 4) / (HP + FP))));
-  const size_t smem_t = size_t(vch) * (HP + FP) * 4;
-  LGNN_REQUIRE(smem_t <= 60 * 1024, "adjacency gradient, diagonal posterior: hidden + input width too large");
+  // tile kernel: staged entries (as many as fit, at most 8) + the per-sample arrays, within the 64 KiB of a default launch
   const size_t smem_s = size_t(3 * H + (H + 1) + 3 * C + 4) * 4;
-  LGNN_REQUIRE(smem_s <= 60 * 1024, "adjacency gradient, diagonal posterior: hidden width / classes too large");
+  LGNN_REQUIRE(smem_s + size_t(HP + FP) * 4 <= 62 * 1024, "adjacency gradient, diagonal posterior: hidden + input width too large");
+  const int vch = int(std::min<int64_t>(8, (62 * 1024 - int64_t(smem_s)) / ((HP + FP) * 4)));
+  const size_t smem_t = size_t(vch) * (HP + FP) * 4;
   const size_t smem_e = size_t(H * 8 + 4 * 8 + 8 + 8) * 4;  // (dadj_entry_kernel: EV = 8 mask rows; the candidates' kernel needs H + 4)
   LGNN_REQUIRE(smem_e <= 60 * 1024, "adjacency gradient, diagonal posterior: hidden width too large");
   const float* mask = h->fc.dact0.as<float>();
@@ -1460,7 +1450,7 @@ int diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   float* phibar = h->ws.misc.as<float>();
   for (int64_t m0 = 0; m0 < M; m0 += chunk) {
     const int64_t mc = std::min(chunk, M - m0);
-    hipLaunchKernelGGL(dadj_tile_kernel, dim3(unsigned(mc)), dim3(256), std::max(smem_t, smem_s), s, idx,
+    hipLaunchKernelGGL(dadj_tile_kernel, dim3(unsigned(mc)), dim3(256), smem_t + smem_s, s, idx,
                        static_cast<const int64_t*>(y), m0, N, h->P.rowptr, h->P.col, h->P.val, mask, H, PX, ldx, rowsum, F, vch,
                        h->ws.probs.as<float>(), C, h->W[1], h->fc.prop_in[1].as<float>(), h->fc.prop_ld[1], gamma, loss_scale, T,
                        phibar, out_bar);
