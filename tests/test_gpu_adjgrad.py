@@ -212,6 +212,13 @@ def test_diag_adjacency_gradient_midsize_vs_oracle(sym, F, H, C, limit):
     assert rel(grad.cpu().numpy(), og) < 1e-4
     _, gd = O.diag_marglik_adj_grad(om, idx.numpy(), y.numpy(), 128, 0.5, sym, dense=True)
     assert rel(gc.cpu().numpy(), gd[cand[0].numpy(), cand[1].numpy()]) < 1e-4
+    # a prior precision per layer (weight, bias, weight, bias): gamma_p = 1 / (2 (H_p + delta_p)) with the block's own delta
+    pp = torch.tensor([0.3, 2.0, 0.8, 5.0])
+    sizes = [H * F, H, C * H, C]
+    val_l, _, grad_l = la.neg_marglik_adj_grad(loader, prior_precision=pp.cuda())
+    oval_l, _, _, og_l = O.diag_marglik_adj_grad(om, idx.numpy(), y.numpy(), 128, np.repeat(pp.numpy().astype(np.float64), sizes), sym)
+    assert abs(float(val_l) - oval_l) <= 5e-6 * abs(oval_l) and rel(grad_l.cpu().numpy(), og_l) < 1e-4
+    assert rel(grad_l.cpu().numpy(), og) > 1e-2  # (a different gradient than under the scalar prior)
     model.engine.check_async_errors()
 
 
