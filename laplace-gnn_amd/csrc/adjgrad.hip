@@ -1313,9 +1313,12 @@ __device__ __forceinline__ float dadj_pair(const float* __restrict__ Tm, const f
   return block_sum_256(part, red);
 }
 
-// The entries of a sample's row, EV at a time: the tile is read once for the EV column nodes (their mask rows are staged j-major
-// in LDS, two 16-byte broadcasts per tile element), thread t owns columns i = t, t + 256, ... of the tile.
+// The entries of a sample's row, EV at a time: ca[u][i] = sum_j mask[v_u, j] Tbar[j, i] is an (EV x H) . (H x F1) product per
+// group.  Thread <-> (ib, jq): four columns of the tile (one 16-byte load per row) and every NJ-th row; the EV mask values of a
+// row are two 16-byte LDS broadcasts; 32 FMAs per row visited.  The row slices meet in LDS (cas [EV][ICH], float atomics when
+// NJ > 1), ICH columns at a time; the sums are then contracted with Ee[v_u, :] (gradP) and scattered (e_bar).
 constexpr int EV = 8;
+constexpr int ICH = 1024;  // columns of the tile per pass (cas: 32 KiB)
 __global__ __launch_bounds__(256) void dadj_entry_kernel(const int64_t* __restrict__ idx, int64_t m0, int64_t N,
                                                          const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                          const float* __restrict__ val, const float* __restrict__ mask, int64_t H,
@@ -1325,12 +1328,14 @@ __global__ __launch_bounds__(256) void dadj_entry_kernel(const int64_t* __restri
                                                          const float* __restrict__ phibar, float* __restrict__ gradP,
                                                          float* __restrict__ h1_bar, float* __restrict__ e_bar) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int64_t F1 = F + 1, FP = (F1 + 3) & ~int64_t(3);
+  const int icw = int(min<int64_t>(ICH, FP));   // columns per pass
   float* __restrict__ mk = sm;                   // [H][EV]
-  float* __restrict__ red = mk + H * EV;         // [4][EV]
+  float* __restrict__ cas = mk + H * EV;         // [EV][icw]
+  float* __restrict__ red = cas + EV * icw;      // [4][EV]
   float* __restrict__ wv = red + 4 * EV;         // [EV]
   int32_t* __restrict__ vid = reinterpret_cast<int32_t*>(wv + EV);  // [EV]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t F1 = F + 1, FP = (F1 + 3) & ~int64_t(3);
   const int64_t n = idx[m0 + blockIdx.x];
   if (n < 0 || n >= N) return;
   const float* __restrict__ Tm = T + int64_t(blockIdx.x) * H * FP;
@@ -1346,30 +1351,56 @@ __global__ __launch_bounds__(256) void dadj_entry_kernel(const int64_t* __restri
     __syncthreads();
     for (int64_t t = tid; t < H * EV; t += 256) {
       const int u = int(t % EV);
-      const int64_t j = t / EV;
-      mk[t] = u < un ? mask[int64_t(vid[u]) * H + j] : 0.f;
+      mk[t] = u < un ? mask[int64_t(vid[u]) * H + t / EV] : 0.f;
     }
-    __syncthreads();
     float part[EV];
 #pragma unroll
     for (int u = 0; u < EV; ++u) part[u] = 0.f;
-    for (int64_t i = tid; i < F1; i += 256) {
-      float ca[EV];
+    for (int64_t c0 = 0; c0 < FP; c0 += icw) {
+      const int cw = int(min<int64_t>(icw, FP - c0));  // a multiple of 4
+      const int nI = cw / 4;
+      const int NJ = nI >= 256 ? 1 : int(min<int64_t>(256 / nI, H));  // row slices
+      __syncthreads();  // mk staged / the previous pass's cas consumed
+      if (NJ > 1)
+        for (int t = tid; t < EV * cw; t += 256) cas[(t / cw) * icw + (t % cw)] = 0.f;
+      __syncthreads();
+      for (int st = tid; st < nI * NJ; st += 256) {
+        const int jq = st / nI, ib = st - jq * nI;
+        float ca[EV][4];
 #pragma unroll
-      for (int u = 0; u < EV; ++u) ca[u] = 0.f;
-      for (int64_t j = 0; j < H; ++j) {
-        const float t = Tm[j * FP + i];
-        const float4 m0v = *reinterpret_cast<const float4*>(mk + j * EV);
-        const float4 m1v = *reinterpret_cast<const float4*>(mk + j * EV + 4);
-        ca[0] = fmaf(m0v.x, t, ca[0]); ca[1] = fmaf(m0v.y, t, ca[1]); ca[2] = fmaf(m0v.z, t, ca[2]); ca[3] = fmaf(m0v.w, t, ca[3]);
-        ca[4] = fmaf(m1v.x, t, ca[4]); ca[5] = fmaf(m1v.y, t, ca[5]); ca[6] = fmaf(m1v.z, t, ca[6]); ca[7] = fmaf(m1v.w, t, ca[7]);
+        for (int u = 0; u < EV; ++u)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ca[u][c] = 0.f;
+        for (int64_t j = jq; j < H; j += NJ) {
+          const float4 t4 = *reinterpret_cast<const float4*>(Tm + j * FP + c0 + 4 * ib);
+          const float4 m0v = *reinterpret_cast<const float4*>(mk + j * EV);
+          const float4 m1v = *reinterpret_cast<const float4*>(mk + j * EV + 4);
+          const float mm[EV] = {m0v.x, m0v.y, m0v.z, m0v.w, m1v.x, m1v.y, m1v.z, m1v.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+          for (int u = 0; u < EV; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ca[u][c] = fmaf(mm[u], tt[c], ca[u][c]);
+        }
+#pragma unroll
+        for (int u = 0; u < EV; ++u)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (NJ > 1) atomicAdd(&cas[u * icw + 4 * ib + c], ca[u][c]);
+            else cas[u * icw + 4 * ib + c] = ca[u][c];
+          }
       }
+      __syncthreads();
 #pragma unroll
       for (int u = 0; u < EV; ++u)
         if (u < un) {
           const int64_t v = vid[u];
-          part[u] = fmaf(ca[u], i < F ? PX[v * ldx + i] : rowsum[v], part[u]);
-          if (ca[u] != 0.f) atomicAdd(&e_bar[v * F1 + i], wv[u] * ca[u]);
+          for (int i = tid; i < cw; i += 256) {
+            const int64_t gi = c0 + i;
+            if (gi >= F1) break;
+            const float c = cas[u * icw + i];
+            part[u] = fmaf(c, gi < F ? PX[v * ldx + gi] : rowsum[v], part[u]);
+            if (c != 0.f) atomicAdd(&e_bar[v * F1 + gi], wv[u] * c);
+          }
         }
     }
     for (int64_t j = tid; j < H; j += 256) {
@@ -1438,7 +1469,7 @@ int diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   LGNN_REQUIRE(smem_s + size_t(HP + FP) * 4 <= 62 * 1024, "adjacency gradient, diagonal posterior: hidden + input width too large");
   const int vch = int(std::min<int64_t>(8, (62 * 1024 - int64_t(smem_s)) / ((HP + FP) * 4)));
   const size_t smem_t = size_t(vch) * (HP + FP) * 4;
-  const size_t smem_e = size_t(H * 8 + 4 * 8 + 8 + 8) * 4;  // (dadj_entry_kernel: EV = 8 mask rows; the candidates' kernel needs H + 4)
+  const size_t smem_e = size_t(H * 8 + 8 * std::min<int64_t>(1024, FP) + 4 * 8 + 8 + 8) * 4;  // (dadj_entry_kernel: EV = 8 mask rows + the column sums of a pass; the candidates' kernel needs H + 4)
   LGNN_REQUIRE(smem_e <= 60 * 1024, "adjacency gradient, diagonal posterior: hidden width too large");
   const float* mask = h->fc.dact0.as<float>();
   const float* PX = h->fc.prop_in[0].as<float>();
@@ -1457,7 +1488,7 @@ int diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
     hipLaunchKernelGGL(dadj_entry_kernel, dim3(unsigned(mc)), dim3(256), smem_e, s, idx, m0, N, h->P.rowptr, h->P.col, h->P.val,
                        mask, H, PX, ldx, rowsum, F, h->fc.hact_p[0], h->fc.hact_ld[0], T, phibar, grad_P, h1_bar, e_bar);
     if (K > 0)
-      hipLaunchKernelGGL(dadj_cand_kernel, dim3(unsigned(std::min<int64_t>(K, 65535))), dim3(256), smem_e, s, cand_a, cand_b, K,
+      hipLaunchKernelGGL(dadj_cand_kernel, dim3(unsigned(std::min<int64_t>(K, 65535))), dim3(256), size_t(H + 4) * 4, s, cand_a, cand_b, K,
                          h->ws.pos.as<int32_t>(), h->ws.mult.as<int32_t>(), m0, mc, mask, H, PX, ldx, rowsum, F,
                          h->fc.hact_p[0], h->fc.hact_ld[0], T, phibar, grad_cand);
     LGNN_HIP_CHECK(hipGetLastError());
