@@ -319,8 +319,8 @@ LGNN_API int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float*
  *                d/d[P X | rowsum(P)] of the closed-form diagonal;  candidates as above;
  *   once      :  lgnn_diag_adjgrad_finish propagates out_bar, h1_bar and e_bar through the forward pass into grad_P and writes
  *                grad_adj [nnz] / grad_cand_adj exactly like lgnn_adjgrad_finish.
- * Workspace: [chunk][H][F + 1] floats for the first-layer tiles of a chunk of samples (0.5 GB for a Cora-shaped batch), under the
- * workspace limit.                                                                                                   */
+ * Workspace: [chunk][H][F + 1 rounded up to 4] floats for the first-layer tiles of a chunk of samples (0.5 GB for a Cora-shaped
+ * batch), under the workspace limit (lgnn_set_workspace_limit); no synchronisation, nothing allocated after the first call.  */
 LGNN_API int lgnn_diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, const float* gamma,
                             float loss_scale, float* grad_P, float* out_bar, float* h1_bar, float* e_bar,
                             const int32_t* cand_a, const int32_t* cand_b, int64_t num_cand, float* grad_cand, void* stream);
