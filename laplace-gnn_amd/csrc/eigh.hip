@@ -249,7 +249,8 @@ extern "C" int lgnn_symeig_batched(float* A, int64_t n, int64_t batch, float* W,
   if (!A || !W || !info) { set_error("null argument"); return 2; }
   LGNN_REQUIRE(n > 0 && n <= 32768 && batch > 0 && batch <= 65535, "symeig: bad shape");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!blas_handle(s)) { set_error("rocBLAS handle / stream setup failed"); return 3; }
+  // (neither branch touches the shared g_handle: the divide and conquer chains have handles of their own, g_bh, and the
+  //  library path g_eig_handle -- queued main-stream work that uses g_handle is never rebound to a side stream from here)
   if (n <= TN && n >= 2 && getenv("LGNN_EIGH_LIBRARY") == nullptr) {
     LGNN_CALL(g_e.reserve(size_t(batch) * n * 4));
     LGNN_CALL(g_v.reserve(size_t(batch) * n * TN * 4));

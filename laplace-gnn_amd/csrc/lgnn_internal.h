@@ -115,6 +115,7 @@ struct Workspace {
   // two-hop path route of the first layer's B (paths.hip): per-sample coefficient rows [M][3][64], the rows (u | p) [2 M][C]
   // and their products with W_1 [2 M][H]; R = P^T[:, batch] as CSR over v (counts / cursors, row pointers, sample, weight)
   DevBuf path_coef, path_up, path_bg, path_cnt, path_rptr, path_rm, path_rw, path_zeros;
+  DevBuf path_alpha;  // GraphSAGE: the samples' alpha coefficients, class major [M][64] (weights of the one-hot paths)
   DevBuf path_pcnt, path_pptr, path_pm, path_pv, path_pw;  // the batch's paths per destination node (CSR over n)
   DevBuf path_flags, path_nodes, path_nnodes;              // nodes of the launch's range that have a path: flags, list, count
   // (the list's capacity is max(4 nnz, 4 M entries); a batch whose list is longer takes the enumerating route on the device)

@@ -48,6 +48,10 @@ namespace {
 constexpr int kCoefStride = 64;  // classes per coefficient row (zero padded): two 32-row MFMA tiles
 constexpr int kCoefRow = 256;    // floats per sample in the coefficient table: (alpha | -beta | -gamma | pad) = 1 KiB, one LDS-DMA piece
 constexpr int kPathWindow = 128; // paths staged in LDS per accumulation window
+// Where class c of a call's class range [cb, cb + 64) sits inside the 64 slots of one coefficient kind: the four 16-class MFMA
+// tiles of a slot i side by side, so that a product-wave lane fetches its A operands of all tiles with one 16-byte load.
+__device__ __forceinline__ int coef_slot(int rel) { return ((rel & 15) << 2) | (rel >> 4); }
+__device__ __forceinline__ int slot_class(int slot) { return ((slot & 3) << 4) | (slot >> 2); }
 
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
@@ -56,10 +60,11 @@ __device__ __forceinline__ float wsum(float v) {
 }
 
 // One wave per batch sample (first occurrences only; a node listed t times carries t in its R weights).
-// mode: 0 upstream seeds, 1 fork exact, 2 regression (V = sqrt(2) I).
+// mode: 0 upstream seeds, 1 fork exact, 2 regression (V = sqrt(2) I).  The coefficient row holds the classes [cb, cb + 64) of the
+// call in slot order (coef_slot); slots of classes >= C are zero.
 __global__ __launch_bounds__(256) void path_tables_kernel(const float* __restrict__ probs, const float* __restrict__ logits,
                                                           const int64_t* __restrict__ idx, const int32_t* __restrict__ pos,
-                                                          int64_t M, int64_t N, int C, int mode, float* __restrict__ coef,
+                                                          int64_t M, int64_t N, int C, int cb, int mode, float* __restrict__ coef,
                                                           float* __restrict__ up) {
   const int lane = threadIdx.x & 63;
   const int64_t m = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -79,9 +84,14 @@ __global__ __launch_bounds__(256) void path_tables_kernel(const float* __restric
     else if (mode == 1) { al = sp * (1.f + 0.5f * t); be = sp; ga = 0.5f * sp * t; u = pk * (1.f + t); }
     else { al = sp; be = sp; u = pk; }
   }
-  cm[lane] = al;                       // lanes >= C write the zero padding
-  cm[kCoefStride + lane] = -be;
-  cm[2 * kCoefStride + lane] = -ga;
+  // slot `lane` of each kind holds class cb + slot_class(lane): fetched from the lane that computed it
+  const int c = cb + slot_class(lane);
+  const bool have = c < C;
+  const int src = have ? c : 0;
+  const float sal = __shfl(al, src), sbe = __shfl(be, src), sga = __shfl(ga, src);
+  cm[lane] = have ? sal : 0.f;
+  cm[kCoefStride + lane] = have ? -sbe : 0.f;
+  cm[2 * kCoefStride + lane] = have ? -sga : 0.f;
   cm[3 * kCoefStride + lane] = 0.f;
   if (lane < C) { um[lane] = u; pm[lane] = own ? pk : 0.f; }
 }
@@ -178,6 +188,9 @@ struct YArgs {
   const int32_t* list;      // optional: the nodes of that range that have a path (relative to n0), ...
   const int32_t* n_list;    // ... and how many (device side: no host round trip); null: every node of the range
   int H, c0, R;
+  int cb;                   // first class of the coefficient table's slots (the call's class range starts there)
+  int debug;                // LGNN_FUSED_DEBUG (timing experiments only, results are wrong with bits 0 / 1): 1 no Gram, 2 no
+                            // products, 4 product waves at priority 3, 8 Gram waves at priority 3, 16 all operand loads from sample 0 / node 0
   int no_bg;                // regression / nothing but the diagonal term: the beta / gamma products vanish
 };
 
@@ -196,8 +209,6 @@ struct YMeta {                  // the window's triples
   int32_t m[kWin], v[kWin];
   float w[kWin];
 };
-
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ void lds_dma16(const float* src, float* lds_dst) {
   __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
@@ -276,59 +287,6 @@ __device__ __forceinline__ void mfma_window(const YWin& win, const YMeta& mt, in
   }
 }
 
-// The second row tile (classes 32 .. 47 of the chunk) on v_mfma_f32_16x16x4_f32: a 16-class tile has no padding rows to multiply
-// (C = 40: a 32-row tile would spend three quarters of its work on rows 40 .. 63) and takes half the matrix-pipe time per path.
-// Lane l: A row i = l & 15 (class), B column = l & 15 (four 16-column tiles per wave), k = l >> 4 (four paths per step);
-// C / D: col = l & 15, row = 4 (l >> 4) + r.  Dependent MFMAs on one accumulator are four instructions apart (latency 40 > issue 32).
-using f32x4v = __attribute__((ext_vector_type(4))) float;
-struct YOps16 { float aa, ab, ag, mf[4], bb[4], gg[4]; };
-__device__ __forceinline__ void y_load_ops16(const YWin& win, const YMeta& mt, int kw, int ks, int lane, int cls16, int cg, int H,
-                                             YOps16& o) {
-  const int jr = 4 * ks + (lane >> 4);
-  const bool valid = jr < kw;
-  const int j = valid ? jr : 0;  // (a staged row: what sits past the window's end may not be finite)
-  const float wj = valid ? mt.w[j] : 0.f;
-  o.aa = wj * win.coef[j][cls16]; o.ab = wj * win.coef[j][kCoefStride + cls16]; o.ag = wj * win.coef[j][2 * kCoefStride + cls16];
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct) {
-    const int col = 64 * cg + 16 * ct + (lane & 15);
-    const int colc = col < H ? col : 0;
-    const uint32_t word = win.mask[j][colc >> 5];
-    o.mf[ct] = (valid && col < H && ((word >> (colc & 31)) & 1u)) ? 1.f : 0.f;
-    o.bb[ct] = o.mf[ct] * win.bg[j][0][colc];
-    o.gg[ct] = o.mf[ct] * win.bg[j][1][colc];
-  }
-}
-__device__ __forceinline__ void y_mfma_ops16(const YOps16& o, bool no_bg, f32x4v (&t1)[4], f32x4v (&y2)[4]) {
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct) t1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.aa, o.mf[ct], t1[ct], 0, 0, 0);
-  if (!no_bg) {
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) y2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.ab, o.bb[ct], y2[ct], 0, 0, 0);
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) y2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.ag, o.gg[ct], y2[ct], 0, 0, 0);
-  }
-}
-__device__ __forceinline__ void mfma_window16(const YWin& win, const YMeta& mt, int kw, int lane, int cls16, int cg, int H,
-                                              bool no_bg, f32x4v (&t1)[4], f32x4v (&y2)[4]) {
-  const int nks = (kw + 3) >> 2;
-  if (nks == 0) return;
-  YOps16 oa, ob;
-  y_load_ops16(win, mt, kw, 0, lane, cls16, cg, H, oa);
-  for (int ks = 0; ks < nks; ks += 2) {
-    y_load_ops16(win, mt, kw, ks + 1, lane, cls16, cg, H, ob);  // (past the end: zero weights on a staged row)
-    __builtin_amdgcn_sched_barrier(0);
-    y_mfma_ops16(oa, no_bg, t1, y2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (ks + 1 < nks) {
-      y_load_ops16(win, mt, kw, ks + 2, lane, cls16, cg, H, oa);
-      __builtin_amdgcn_sched_barrier(0);
-      y_mfma_ops16(ob, no_bg, t1, y2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
 // Role of a wave: (rt, cg) owns the 32-class row tile rt (classes c0 + 32 rt ...) and the columns [64 cg, 64 cg + 64) of
 // Y[n]: two 32 x 32 accumulator tiles for the alpha product and two for the beta / gamma products; waves w and w + 4 (the
 // two row tiles of one column group) share a SIMD.
@@ -337,17 +295,17 @@ struct YRole {
   int colv[2];
   bool col_ok[2];
 };
-__device__ __forceinline__ YRole y_role(const YArgs& a, bool fixed8 = false) {
+__device__ __forceinline__ YRole y_role(const YArgs& a) {
   YRole r;
   const int tid = threadIdx.x;
   r.lane = tid & 63; r.li = r.lane & 31; r.half = r.lane >> 5;
   r.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   r.nwaves = blockDim.x >> 6;
-  const int ncg = fixed8 ? 4 : (a.H + 63) >> 6;  // fused kernel: always 4 x 2 roles (waves w and w + 4 share a SIMD)
+  const int ncg = (a.H + 63) >> 6;
   r.cg = r.wave % ncg; r.rt = r.wave / ncg;
   // class of this lane's A-operand row (i = lane & 31), clamped into the zero-padded coefficient row; rows past the class
   // range are computed on whatever sits there and never stored
-  r.cls = min(a.c0 + 32 * r.rt + r.li, kCoefStride - 1);
+  r.cls = coef_slot(min(a.c0 - a.cb + 32 * r.rt + r.li, kCoefStride - 1));
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     r.colv[ct] = 64 * r.cg + 32 * ct + r.li;
@@ -355,147 +313,6 @@ __device__ __forceinline__ YRole y_role(const YArgs& a, bool fixed8 = false) {
     if (!r.col_ok[ct]) r.colv[ct] = 0;
   }
   return r;
-}
-
-// One node's products into the LDS tile `ytile` [rows][256]: the first window is in win[b] (meta slot ms), further windows
-// (hubs) are restaged in place -- every wave of the workgroup takes part in the barriers of that loop, whatever its role.
-// RT1 = false: the wave owns classes [0, 32) x 64 columns (32 x 32 x 2 MFMA); RT1 = true: classes [32, 48) x 64 columns
-// (16 x 16 x 4 MFMA).  W_1's slice of the wave stays in registers for the whole launch.
-#ifdef LGNN_DEV  // make DEV=1: per-wave cycle counts of the fused kernel's phases (s_memtime), printed by paths_phase_report()
-__device__ unsigned long long g_phase[8][8];
-struct Ph { unsigned long long t, acc[8]; };
-#define PH_ARG , Ph& ph
-#define PH_PASS , ph
-#define PH_MARK(k) do { const unsigned long long ph_n = __builtin_amdgcn_s_memtime(); ph.acc[k] += ph_n - ph.t; ph.t = ph_n; } while (0)
-#else
-#define PH_ARG
-#define PH_PASS
-#define PH_MARK(k)
-#endif
-
-template <bool RT1>
-struct YRegs {
-  float w1r[RT1 ? 4 : 2][RT1 ? 4 : 16];
-};
-template <bool RT1>
-__device__ __forceinline__ void y_load_w1(const YArgs& a, const YRole& ro, bool path_wave, YRegs<RT1>& g) {
-  const int H = a.H;
-  if constexpr (!RT1) {
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int colc = 64 * ro.cg + 32 * ct + ro.li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 4 * ro.half + (r & 3) + 8 * (r >> 2);
-        g.w1r[ct][r] = (path_wave && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * a.w1_ld + colc] : 0.f;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const int colc = 64 * ro.cg + 16 * ct + (ro.lane & 15);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 32 + 4 * (ro.lane >> 4) + r;
-        g.w1r[ct][r] = (path_wave && row < a.R && colc < H) ? a.W1[int64_t(a.c0 + row) * a.w1_ld + colc] : 0.f;
-      }
-    }
-  }
-}
-template <bool RT1>
-__device__ __forceinline__ void y_node_products(const YArgs& a, YWin (&win)[2], YMeta (&meta)[4], float (*ytile)[256],
-                                                const YRole& ro, bool path_wave, const YRegs<RT1>& g, int b, int ms, int kwc,
-                                                int32_t p0c, int32_t p1c PH_ARG) {
-  const int tid = threadIdx.x, H = a.H, lane = ro.lane;
-  const bool no_bg = a.no_bg != 0;
-  const int cls16 = min(a.c0 + 32 + (lane & 15), kCoefStride - 1);
-  f32x16 t1[2], y2[2];
-  f32x4v u1[4], u2[4];
-  if constexpr (!RT1) {
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { t1[ct][r] = 0.f; y2[ct][r] = 0.f; }
-    if (path_wave) mfma_window(win[b], meta[ms], kwc, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
-  } else {
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) { u1[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; u2[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
-    if (path_wave) mfma_window16(win[b], meta[ms], kwc, lane, cls16, ro.cg, H, no_bg, u1, u2);
-  }
-  PH_MARK(2);  // first window's products
-  for (int32_t wb = p0c + kWin; wb < p1c; wb += kWin) {  // hubs: further windows, restaged in place (not overlapped)
-    const int kw = min(kWin, p1c - wb);
-    lds_barrier();
-    if (tid < kw) { meta[3].m[tid] = a.pm[wb + tid]; meta[3].v[tid] = a.pv[wb + tid]; meta[3].w[tid] = a.pw[wb + tid]; }
-    lds_barrier();
-    stage_dma(a, win[b], meta[3], kw, ro.wave, 8, lane);
-    if (tid < 8 * kWin) win[b].mask[tid >> 3][tid & 7] = load_mask_word(a, meta[3], kw, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-    if (path_wave) {
-      if constexpr (!RT1) mfma_window(win[b], meta[3], kw, ro.cls, ro.colv, ro.col_ok, ro.half, no_bg, t1, y2);
-      else mfma_window16(win[b], meta[3], kw, lane, cls16, ro.cg, H, no_bg, u1, u2);
-    }
-  }
-  PH_MARK(3);  // further windows (restaged)
-  // Y[n] into the LDS tile (readers of the previous node's tile passed this node's first barrier)
-  if (path_wave) {
-    if constexpr (!RT1) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const int colc = 64 * ro.cg + 32 * ct + ro.li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 4 * ro.half + (r & 3) + 8 * (r >> 2);
-          if (colc < H && row < a.R) ytile[row][colc] = g.w1r[ct][r] * t1[ct][r] + y2[ct][r];
-        }
-      }
-    } else {
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const int colc = 64 * ro.cg + 16 * ct + (lane & 15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 32 + 4 * (lane >> 4) + r;
-          if (colc < H && row < a.R) ytile[row][colc] = g.w1r[ct][r] * u1[ct][r] + u2[ct][r];
-        }
-      }
-    }
-  }
-}
-
-// The part of the node loop both persistent kernels share: prologue (node 0's window in flight, node 1's triples in
-// registers) and, per node, the top of the iteration (wait, publish the next triples, barrier, start the next window).
-struct YPipe {
-  int32_t p0c, p1c, p0n, p1n, p0f, p1f, trm, trv;  // path ranges of the current node, the next one, and the one after (fetched early)
-  float trw;
-  int kwc, kwn;
-  uint32_t mwn;
-};
-template <bool LIST>
-__device__ __forceinline__ void y_range(const YArgs& a, int64_t cnt, int64_t i, int32_t& p0, int32_t& p1) {
-  p0 = p1 = 0;
-  if (i < cnt) {
-    const int64_t k = blockIdx.x + i * int64_t(gridDim.x);
-    const int64_t n = a.n0 + (LIST ? int64_t(a.list[k]) : k);
-    p0 = a.pptr[n]; p1 = a.pptr[n + 1];
-  }
-}
-template <bool LIST>
-__device__ __forceinline__ void y_pipe_prologue(const YArgs& a, YWin (&win)[2], YMeta (&meta)[4], const YRole& ro, int64_t cnt,
-                                                YPipe& pp) {
-  const int tid = threadIdx.x;
-  y_range<LIST>(a, cnt, 0, pp.p0c, pp.p1c);
-  pp.kwc = min(kWin, pp.p1c - pp.p0c);
-  if (tid < pp.kwc) { meta[0].m[tid] = a.pm[pp.p0c + tid]; meta[0].v[tid] = a.pv[pp.p0c + tid]; meta[0].w[tid] = a.pw[pp.p0c + tid]; }
-  __syncthreads();
-  stage_dma(a, win[0], meta[0], pp.kwc, ro.wave, 8, ro.lane);
-  if (tid < 8 * kWin) win[0].mask[tid >> 3][tid & 7] = load_mask_word(a, meta[0], pp.kwc, tid);
-  y_range<LIST>(a, cnt, 1, pp.p0n, pp.p1n);
-  pp.kwn = min(kWin, pp.p1n - pp.p0n);
-  pp.trm = 0; pp.trv = 0; pp.trw = 0.f;
-  if (tid < pp.kwn) { pp.trm = a.pm[pp.p0n + tid]; pp.trv = a.pv[pp.p0n + tid]; pp.trw = a.pw[pp.p0n + tid]; }
-  y_range<LIST>(a, cnt, 2, pp.p0f, pp.p1f);
 }
 
 // The fallback when the batch's path list does not fit its buffer (very large batches on hub-heavy graphs): a grid-stride loop
@@ -617,135 +434,425 @@ __device__ __forceinline__ void part_mfma(const float (&x)[8], f32x16 (&acc)[HI 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// The headline route, everything of a node on one CU: ONE persistent 512-thread workgroup per CU walks its nodes; per node
-//   (1) the window of <= 16 paths (rows b_m, g_m, coefficient rows: 1 KiB LDS-DMA pieces) is already in LDS -- it was put in
-//       flight one node earlier, its triples loaded one node earlier still -- and the three path products run on the matrix
-//       pipes (wave (rt, cg): 32 classes x 64 columns, v_mfma_f32_32x32x2_f32);
-//   (2) Y[n] = W_1 (.) T1 + Y2 goes to an LDS tile [rows][256] (never to HBM);
-//   (3) all eight waves contract it into the register-resident upper-triangular 256 x 256 accumulators (36 sub-tiles, 5 + 4 per
-//       SIMD pair), S += Y[n]^T Y[n].
-// Two barriers per node, no exposed memory latency; nodes with more than 16 paths (hubs) restage further windows in place.
-constexpr int kYRows = 40;  // classes per launch (LDS: 2 x 55.6 KiB windows + 40 KiB tile = 152 KiB)
+// The headline route (round 4): everything of a node on one CU, ONE persistent 512-thread workgroup per CU whose eight waves
+// have two ROLES.  The hardware deals a workgroup's waves round-robin to the CU's four SIMDs, so hardware waves g and g + 4
+// share a SIMD -- and its one matrix pipe:
+//   waves 4 .. 7, the PRODUCT waves (one per SIMD): wave 4 + cg owns the columns [64 cg, 64 cg + 64) of Y[n] for all <= 48
+//       classes of the launch.  Per step of FOUR paths: three 16-byte loads of the paths' coefficient rows (A operands: lane
+//       (i, k) = class slot i of path k, the four class tiles of a slot side by side in the table row), two 16-byte loads of
+//       the table rows b_m, g_m (B operands: lane (i, k) = columns 64 cg + 4 i .. + 3 of path k -- the four 16-column MFMA
+//       tiles of the wave interleave the columns, so one load feeds all four), one mask word; 36 v_mfma_f32_16x16x4_f32
+//       (3 class tiles x 4 column tiles x (alpha, beta, gamma)).  No LDS staging, no window, no restaging of hubs: the
+//       operands of step s + 1 are in flight while the MFMAs of step s issue, across node boundaries (a node's triples
+//       (m, v, w) arrive with ONE coalesced load a node ahead and are handed to the lanes with ds_bpermute).
+//       Y[n] = W_1 (.) T1 + Y2 goes to one of TWO LDS tiles [40][256] with 16-byte stores.
+//   waves 0 .. 3, the GRAM waves: S += Y[n - 1]^T Y[n - 1] from the other tile into register-resident upper-triangular
+//       accumulators (the 36 sub-tiles of gram256.h, 9 per wave, 144 accumulator registers), nothing else.
+// ONE barrier per node.  The product wave of a SIMD needs the matrix pipe for ~4 400 of a node's ~16 000 cycles and sleeps on
+// memory the rest of the time; the Gram wave is a dense MFMA stream that takes every slot the product wave leaves: the two
+// phases that round 3 ran back to back in every wave (7.7 ms per arxiv batch, matrix pipes 57 % busy) now overlap.
+constexpr int kYRows = 48;  // classes per launch: three 16-class MFMA tiles (LDS: two 48 KiB tiles + W_1's 48 rows)
 
-struct FusedShared {
-  YWin win[2];
-  YMeta meta[4];
-  float y[kYRows][256];
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+
+struct alignas(16) FusedShared {
+  float y[2][kYRows][256];  // the node tiles (double buffered)
+  float w1[kYRows][256];    // W_1's rows of the launch (zero past R / H)
+  // hand-off counters (one writer each): ready[p] = nodes whose tile columns product wave p has published, done[g] = nodes
+  // Gram wave g has contracted
+  int ready[4], done[4];
 };
 
-template <int W, int LO, int HI, bool LIST>
-__device__ __forceinline__ void fused_wave(const YArgs& a, FusedShared& sh, float* __restrict__ scratch) {
-  constexpr int NT = HI - LO;
-  constexpr bool RT1 = LO != 0;  // hardware waves 4 .. 7: the second class tile, the second half of the SIMD pair's sub-tiles
-  const YRole ro = y_role(a, true);
-  const int tid = threadIdx.x, H = a.H, lane = ro.lane;
-  const int rtiles = a.R > 32 ? 2 : 1, ncg = (H + 63) >> 6;
-  const bool path_wave = ro.rt < rtiles && ro.cg < ncg;  // (H <= 192 or R <= 32: some waves only stage and contract)
-  const int r2 = (a.R + 1) & ~1;                          // rows the Gram reads (an odd class count: one zero row)
-  f32x16 acc[NT];
+// min over the four counters of a hand-off array (one 16-byte LDS read; wave uniform)
+__device__ __forceinline__ int lds_min4(const int* c) {
+  int4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(uint32_t(reinterpret_cast<uintptr_t>(c))) : "memory");
+  return __builtin_amdgcn_readfirstlane(min(min(v.x, v.y), min(v.z, v.w)));
+}
+// publish a counter after this wave's earlier LDS traffic has completed
+__device__ __forceinline__ void lds_publish(int* c, int value, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) *reinterpret_cast<volatile int*>(c) = value;
+}
+
+#ifdef LGNN_DEV  // make DEV=1: per-wave cycle counts of the fused kernel's phases (s_memtime), printed by paths_phase_report()
+__device__ unsigned long long g_phase[8][8];
+struct Ph { unsigned long long t, acc[8]; };
+#define PH_DECL Ph ph; ph.t = __builtin_amdgcn_s_memtime(); for (int k_ = 0; k_ < 8; ++k_) ph.acc[k_] = 0
+#define PH_MARK(k) do { const unsigned long long ph_n = __builtin_amdgcn_s_memtime(); ph.acc[k] += ph_n - ph.t; ph.t = ph_n; } while (0)
+#define PH_FLUSH(wave, lane) do { if ((lane) == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_phase[wave][k_], ph.acc[k_]); } while (0)
+#else
+#define PH_DECL
+#define PH_MARK(k)
+#define PH_FLUSH(wave, lane)
+#endif
+
+// path range [p0, p1) of the i-th node of this workgroup (entry blockIdx.x + i * gridDim.x of the list of nodes with paths,
+// or of the whole range).  Wave uniform.  `pptr` / `list` are kernel parameters of their own (__restrict__): read through the
+// argument struct hipcc cannot prove them read-only and loads them with VECTOR loads followed by vmcnt(0) -- a drain of
+// every load in flight once per node; as restrict parameters they are scalar loads.
+template <bool LIST>
+__device__ __forceinline__ void node_range(const int32_t* __restrict__ pptr, const int32_t* __restrict__ list, int64_t n0,
+                                           int64_t cnt, int64_t i, int32_t& p0, int32_t& p1) {
+  p0 = p1 = 0;
+  if (i < cnt) {
+    const int64_t k = blockIdx.x + i * int64_t(gridDim.x);
+    const int64_t n = n0 + (LIST ? int64_t(list[k]) : k);
+    p0 = pptr[n]; p1 = pptr[n + 1];
+  }
+}
+
+// ---- loads of the product waves: inline assembly with hand-placed wait counts.  hipcc's own counts are exact only along one
+// path; at the loop headers of this kernel it merges the paths pessimistically (measured: the wait for a step's operands also
+// waited for half of the NEXT step's, i.e. one step of prefetch distance instead of two), and any load it tracks itself would
+// make it wait for vmcnt(0) -- it does not see the assembly loads queued behind.  So every vector load of the role's loop is
+// issued here and waited for with a counted s_waitcnt whose "+v" operands tie the loaded registers to the wait (uses cannot
+// move above it).  vmcnt counts in order: waiting until at most n operations are outstanding retires everything older than
+// the n youngest.
+__device__ __forceinline__ void gload4(f32x4v& d, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void gload1(uint32_t& d, const void* p) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+
+// The triples of (up to) 64 paths starting at p0: lane l holds path p0 + l.  Unconditional loads from a clamped index; lanes
+// past the range get (sample 0, node 0, weight 0) in meta_finish: every address formed from them is valid, every product with
+// them is zero.
+struct PMeta { uint32_t m, v, w; };  // (w: the bits of a float)
+__device__ __forceinline__ void meta_issue(const YArgs& a, int32_t p0, int32_t p1, int lane, PMeta& t) {
+  const int32_t q = max(min(p0 + lane, p1 - 1), 0);
+  gload1(t.m, a.pm + q);
+  gload1(t.v, a.pv + q);
+  gload1(t.w, a.pw + q);
+}
+template <int YOUNGER>  // vector-memory operations issued after the triples' loads that may still be in flight
+__device__ __forceinline__ void meta_finish(int32_t p0, int32_t p1, int lane, PMeta& t) {
+  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(t.m), "+v"(t.v), "+v"(t.w) : "n"(YOUNGER) : "memory");
+  const bool in = p0 + lane < p1;
+  t.m = in ? t.m : 0u; t.v = in ? t.v : 0u; t.w = in ? t.w : 0u;
+}
+
+struct PLane {       // what a product-wave lane is: class slot / column slot i, path k of a step
+  int i, kq;
+  int colc;          // 64 cg + 4 i (0 when past H: a valid address, the result is dropped)
+  bool col_ok;
+  int mword, mshift; // mask word and bit of column colc
+};
+
+struct POps {        // the loaded operands of one step (22 registers)
+  f32x4v ca[3];      // coefficient rows (alpha | -beta | -gamma), class slots (i, t = 0 .. 3)
+  f32x4v b4, g4;     // rows b_m, g_m at columns colc .. colc + 3
+  uint32_t mw;       // mask word of the path's middle node
+  float w;           // path weight (0 past the node's last path)
+};
+
+// Issue the loads of step s (paths 4 s .. 4 s + 3 of the chunk whose triples `mt` holds): kStepLoads<NOBG> instructions,
+// nothing conditional.
+template <bool NOBG> constexpr int kStepLoads = NOBG ? 2 : 6;
+template <bool NOBG>
+__device__ __forceinline__ void p_load(const YArgs& a, const PMeta& mt, int s, const PLane& pl, POps& o) {
+  const int src = 4 * s + pl.kq;  // the lane that holds this lane's path (s < 16)
+  int32_t m = __shfl(int(mt.m), src), v = __shfl(int(mt.v), src);
+  if (a.debug & 16) { m = 0; v = 0; }  // (timing experiment: every operand load hits the same cache lines)
+  o.w = __uint_as_float(uint32_t(__shfl(int(mt.w), src)));
+  const float* __restrict__ cr = a.coef + int64_t(m) * kCoefRow + 4 * pl.i;
+  gload4(o.ca[0], cr);
+  if constexpr (!NOBG) {
+    gload4(o.ca[1], cr + kCoefStride);
+    gload4(o.ca[2], cr + 2 * kCoefStride);
+    gload4(o.b4, a.bg + int64_t(m) * a.H + pl.colc);
+    gload4(o.g4, a.bg + (a.M + int64_t(m)) * a.H + pl.colc);
+  }
+  gload1(o.mw, a.mask + int64_t(v) * a.mask_words + pl.mword);
+}
+// the step's loads have landed once at most YOUNGER younger vector-memory operations are outstanding
+template <bool NOBG, int YOUNGER>
+__device__ __forceinline__ void p_wait(POps& o) {
+  if constexpr (NOBG)
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(o.ca[0]), "+v"(o.mw) : "n"(YOUNGER) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(o.ca[0]), "+v"(o.ca[1]), "+v"(o.ca[2]), "+v"(o.b4), "+v"(o.g4), "+v"(o.mw)
+                 : "n"(YOUNGER) : "memory");
+}
+
+// A step's MFMA operands: lane (i, k): A[row i][k] = weighted coefficient of class 16 t + i, B[k][col i] = mask bit / masked
+// table value of column 64 cg + 4 i + ct.
+struct PCur { float a0[3], a1[3], a2[3], mf[4], bb[4], gg[4]; };
+template <bool NOBG>
+__device__ __forceinline__ void p_xform(const POps& o, const PLane& pl, bool hi, PCur& c) {
+  // hi (a second launch of a call with more than 48 classes): the launch's only tile is the fourth of the slot
+  const float wl = hi ? 0.f : o.w, wh = hi ? o.w : 0.f;
 #pragma unroll
-  for (int s = 0; s < NT; ++s)
+  for (int t = 0; t < 3; ++t) {
+    c.a0[t] = wl * o.ca[0][t];
+    if constexpr (!NOBG) { c.a1[t] = wl * o.ca[1][t]; c.a2[t] = wl * o.ca[2][t]; }
+  }
+  c.a0[0] = fmaf(wh, o.ca[0][3], c.a0[0]);
+  if constexpr (!NOBG) { c.a1[0] = fmaf(wh, o.ca[1][3], c.a1[0]); c.a2[0] = fmaf(wh, o.ca[2][3], c.a2[0]); }
+  const uint32_t bits = pl.col_ok ? (o.mw >> pl.mshift) : 0u;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    c.mf[ct] = ((bits >> ct) & 1u) ? 1.f : 0.f;
+    if constexpr (!NOBG) { c.bb[ct] = c.mf[ct] * o.b4[ct]; c.gg[ct] = c.mf[ct] * o.g4[ct]; }
+  }
+}
+// the 36 (NOBG: 12) MFMAs of one step;  D: col = i, row = 4 k + r
+template <bool NOBG>
+__device__ __forceinline__ void p_mfma(const PCur& c, f32x4v (&t1)[3][4], f32x4v (&y2)[3][4]) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) t1[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a0[t], c.mf[ct], t1[t][ct], 0, 0, 0);
+  if constexpr (!NOBG) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) y2[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a1[t], c.bb[ct], y2[t][ct], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) y2[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.a2[t], c.gg[ct], y2[t][ct], 0, 0, 0);
+  }
+}
+
+// The product wave's work as a stream of CHUNKS: at most 64 paths of one node (one register of triples); a node is one chunk
+// (a hub: several), a node without paths one empty chunk.  Wave-uniform scalar state; the range of the node after the one
+// being cut is fetched a node ahead.
+template <bool LIST>
+struct ChunkGen {
+  int64_t gi;            // node being cut into chunks (index into this workgroup's nodes; nodes >= cnt are empty)
+  int32_t gp, gend;      // its remaining paths
+  int32_t pa0, pa1;      // the path range of node gi + 1
+  const int32_t* __restrict__ pptr;
+  const int32_t* __restrict__ list;
+  int64_t n0;
+  __device__ __forceinline__ void init(const int32_t* __restrict__ pptr_, const int32_t* __restrict__ list_, int64_t n0_, int64_t cnt) {
+    pptr = pptr_; list = list_; n0 = n0_;
+    gi = 0;
+    node_range<LIST>(pptr, list, n0, cnt, 0, gp, gend);
+    node_range<LIST>(pptr, list, n0, cnt, 1, pa0, pa1);
+  }
+  // the next chunk [q0, q1) and whether it is its node's last
+  __device__ __forceinline__ void next(int64_t cnt, int32_t& q0, int32_t& q1, bool& last) {
+    q0 = gp; q1 = min(gp + 64, gend);
+    last = q1 >= gend;
+    if (last) {
+      ++gi;
+      gp = pa0; gend = pa1;
+      node_range<LIST>(pptr, list, n0, cnt, gi + 1, pa0, pa1);
+    } else {
+      gp = q1;
+    }
+  }
+};
+
+// The product wave of SIMD cg.  Steps come in PAIRS (8 paths): buffer A holds the loaded operands of the pair's first step, B
+// of its second; each is refilled for the NEXT pair -- this chunk's, or the next chunk's first (usually the next node's) --
+// right after its values were turned into MFMA operands, so two steps' loads (12 instructions) are in flight behind the 36
+// MFMAs being issued.  Everything hipcc's wait counts depend on is kept static: the loads are unconditional and in one fixed
+// order, the pair loop's body is straight-line code, and A / B are written nowhere else inside the loop (with a branch in the
+// body, or a second definition on a side path -- hubs, empty nodes --, hipcc resolves the loop phis with register copies of
+// loads still in flight, i.e. drains them: measured as the whole latency exposed once per pair resp. once per node).  Hence
+// the chunk stream: hubs and empty nodes take the same path as everything else; a step past the chunk's last path multiplies
+// zero weights (load_meta), an empty chunk is one such pair.
+template <bool LIST, bool NOBG>
+__device__ __forceinline__ void product_role(const YArgs& a, const int32_t* __restrict__ pptr, const int32_t* __restrict__ list,
+                                             FusedShared& sh, int64_t cnt, int cg) {
+  const int lane = threadIdx.x & 63;
+  const int H = a.H, R = a.R;
+  PLane pl;
+  pl.i = lane & 15; pl.kq = lane >> 4;
+  const int col = 64 * cg + 4 * pl.i;
+  pl.col_ok = col < H;  // (H % 4 == 0: the lane's four columns are in or out together)
+  pl.colc = pl.col_ok ? col : 0;
+  pl.mword = pl.colc >> 5; pl.mshift = pl.colc & 31;
+  const bool path_wave = 64 * cg < H;  // (H <= 192: the last product wave only keeps the barriers)
+  const bool hi = a.c0 != a.cb;        // classes cb + 48 ..: the fourth tile of the coefficient slots
+  PH_DECL;
+  if (a.debug & 4) __builtin_amdgcn_s_setprio(3);
+  if (!path_wave) return;  // (its ready counter was set to "everything" at the kernel's top)
+  if (a.debug & 2) {       // (timing experiment: no products)
+    lds_publish(&sh.ready[cg], INT32_MAX, lane);
+    return;
+  }
+  constexpr int NL = kStepLoads<NOBG>;
+  ChunkGen<LIST> gen;
+  gen.init(pptr, list, a.n0, cnt);
+  int32_t q0c, q1c, q0n, q1n;
+  bool lastc, lastn;
+  gen.next(cnt, q0c, q1c, lastc);
+  gen.next(cnt, q0n, q1n, lastn);
+  PMeta mc, mn;
+  meta_issue(a, q0c, q1c, lane, mc);
+  meta_issue(a, q0n, q1n, lane, mn);
+  meta_finish<0>(q0c, q1c, lane, mc);
+  meta_finish<0>(q0n, q1n, lane, mn);
+  POps A, B;
+  p_load<NOBG>(a, mc, 0, pl, A);
+  p_load<NOBG>(a, mc, 1, pl, B);
+  f32x4v t1[3][4], y2[3][4];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { t1[t][ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; y2[t][ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+  bool node_has = false;  // the node being built has a path so far
+  for (int64_t i = 0; i < cnt;) {  // node i's tile is built while the Gram waves contract node i - 1's (or i - 2's)
+    // the chunk after the next: its range now, its triples a whole chunk before they are used.  In flight from here
+    // (oldest first): A, B (issued by the previous chunk's last pair), these three loads
+    int32_t q0f, q1f;
+    bool lastf;
+    gen.next(cnt, q0f, q1f, lastf);
+    PMeta mf2;
+    meta_issue(a, q0f, q1f, lane, mf2);
+    const int kch = q1c - q0c, np = max((kch + 7) >> 3, 1);
+    node_has = node_has || kch > 0;
+    for (int j = 0; j < np; ++j) {
+      // the pair after this one: this chunk's, else the next chunk's first
+      const bool more = j + 1 < np;
+      PMeta mx;
+      mx.m = more ? mc.m : mn.m; mx.v = more ? mc.v : mn.v; mx.w = more ? mc.w : mn.w;
+      const int sx = more ? 2 * (j + 1) : 0;
+      PCur c;
+      // A's loads: the NL youngest outstanding may be B's (the first pair of a chunk: B's and the three triple loads --
+      // there the count also waits for B's first half, issued a whole pair earlier)
+      p_wait<NOBG, NL>(A);
+      PH_MARK(4);
+      p_xform<NOBG>(A, pl, hi, c);
+      PH_MARK(0);
+      __builtin_amdgcn_sched_barrier(0);
+      p_load<NOBG>(a, mx, sx, pl, A);
+      __builtin_amdgcn_sched_barrier(0);
+      p_mfma<NOBG>(c, t1, y2);
+      PH_MARK(1);
+      __builtin_amdgcn_sched_barrier(0);
+      p_wait<NOBG, NL>(B);  // (younger: A's refill)
+      PH_MARK(4);
+      p_xform<NOBG>(B, pl, hi, c);
+      PH_MARK(0);
+      __builtin_amdgcn_sched_barrier(0);
+      p_load<NOBG>(a, mx, sx + 1, pl, B);
+      __builtin_amdgcn_sched_barrier(0);
+      p_mfma<NOBG>(c, t1, y2);
+      PH_MARK(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lastc) {
+      // tile i & 1 was last read by the Gram of node i - 2: every Gram wave must have counted i - 1 nodes
+      if (i >= 2)
+        while (lds_min4(sh.done) < int(i) - 1) __builtin_amdgcn_s_sleep(2);
+      PH_MARK(3);
+      if (node_has && pl.col_ok) {
+        // Y[n] = W_1 (.) T1 + Y2; rows past the launch's classes are written as the zeros they already are (one branch
+        // around twelve unconditional 16-byte stores instead of twelve branches)
+        float (*ytile)[256] = sh.y[i & 1];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + 4 * pl.kq + r;
+            const float keep = row < R ? 1.f : 0.f;
+            const f32x4v w1 = *reinterpret_cast<const f32x4v*>(&sh.w1[row][col]);
+            f32x4v o;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) o[ct] = keep * (w1[ct] * t1[t][ct][r] + y2[t][ct][r]);
+            *reinterpret_cast<f32x4v*>(&ytile[row][col]) = o;
+          }
+      }
+      ++i;
+      lds_publish(&sh.ready[cg], int(i), lane);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { t1[t][ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; y2[t][ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+      node_has = false;
+      PH_MARK(2);
+    }
+    // rotate the chunk stream (the triples issued at the top are older than the 2 NL loads of the last pair's refills)
+    meta_finish<2 * NL>(q0f, q1f, lane, mf2);
+    q0c = q0n; q1c = q1n; lastc = lastn; mc = mn;
+    q0n = q0f; q1n = q1f; lastn = lastf; mn = mf2;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the refills past the last chunk
+  PH_FLUSH(4 + cg, lane);
+}
+
+template <int W, bool LIST>
+__device__ __forceinline__ void gram_role(const YArgs& a, const int32_t* __restrict__ pptr, const int32_t* __restrict__ list,
+                                          FusedShared& sh, int64_t cnt, float* __restrict__ scratch) {
+  const int lane = threadIdx.x & 63;
+  f32x16 acc[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-  YRegs<RT1> g;
-  y_load_w1<RT1>(a, ro, path_wave, g);
-  // the tile is zero where nobody writes: columns >= H, the odd row out
-  for (int q = tid; q < kYRows * 256; q += 512) (&sh.y[0][0])[q] = 0.f;
-  const int64_t stride = gridDim.x;
-  // nodes of this launch: entry blockIdx.x + i * stride of the list of nodes with paths (or of the whole range)
-  const int64_t nn = LIST ? int64_t(__builtin_amdgcn_readfirstlane(*a.n_list)) : a.n1 - a.n0;
-  const int64_t cnt = nn > int64_t(blockIdx.x) ? (nn - blockIdx.x + stride - 1) / stride : 0;
-  YPipe pp;
-  y_pipe_prologue<LIST>(a, sh.win, sh.meta, ro, cnt, pp);
-#ifdef LGNN_DEV
-  Ph ph;
-  ph.t = __builtin_amdgcn_s_memtime();
-  for (int k = 0; k < 8; ++k) ph.acc[k] = 0;
-#endif
+  const int nk = (a.R + 1) >> 1;  // rows two at a time (an odd class count: one zero row)
+  int32_t p0, p1;
+  node_range<LIST>(pptr, list, a.n0, cnt, 0, p0, p1);
+  PH_DECL;
+  if (a.debug & 8) __builtin_amdgcn_s_setprio(3);
+  const bool gwork = !(a.debug & 1);
   for (int64_t i = 0; i < cnt; ++i) {
-    const int b = int(i & 1), ms = int(i % 3), msn = int((i + 1) % 3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // node i's window has landed; node i + 1's triples are in registers
-    PH_MARK(7);  // waiting for the window's copies
-    if (tid < pp.kwn) { sh.meta[msn].m[tid] = pp.trm; sh.meta[msn].v[tid] = pp.trv; sh.meta[msn].w[tid] = pp.trw; }
-    lds_barrier();  // window i visible to all waves; everybody is done with node i - 1 (its Gram, the other window buffer;
-                    // meta slot msn's previous tenant is three nodes back)
-    PH_MARK(0);  // first barrier
-    // ---- asynchronous, behind this node's work: node i + 1's window, its mask words, node i + 2's triples
-    stage_dma(a, sh.win[b ^ 1], sh.meta[msn], pp.kwn, ro.wave, 8, lane);
-    pp.mwn = 0;
-    if (tid < 8 * kWin) pp.mwn = load_mask_word(a, sh.meta[msn], pp.kwn, tid);
-    // (node i + 2's range was fetched one node ago: its triples' addresses do not wait for a pointer load -- measured with
-    //  the DEV build's phase counters: 10.6 % of the kernel sat in that dependent load; node i + 3's range starts now)
-    const int32_t p0nn = pp.p0f, p1nn = pp.p1f;
-    y_range<LIST>(a, cnt, i + 3, pp.p0f, pp.p1f);
-    const int kwnn = min(kWin, p1nn - p0nn);
-    pp.trm = 0; pp.trv = 0; pp.trw = 0.f;
-    if (tid < kwnn) { pp.trm = a.pm[p0nn + tid]; pp.trv = a.pv[p0nn + tid]; pp.trw = a.pw[p0nn + tid]; }
-    // ---- (1) + (2): the path products of node i, Y[n] into the LDS tile.  A node without paths (GraphSAGE: neither in the
-    // batch nor next to it; a short last batch) has Y[n] = 0: no products, no Gram, only its share of the pipeline
-    const bool has_paths = pp.p1c > pp.p0c;  // (workgroup uniform)
-    PH_MARK(1);  // staging issue, prefetches
-    if (has_paths) y_node_products<RT1>(a, sh.win, sh.meta, sh.y, ro, path_wave, g, b, ms, pp.kwc, pp.p0c, pp.p1c PH_PASS);
-    PH_MARK(4);  // Y tile write
-    if (tid < 8 * kWin) sh.win[b ^ 1].mask[tid >> 3][tid & 7] = pp.mwn;  // (readers of that buffer passed this node's barrier)
-    lds_barrier();  // raw: a __syncthreads() here would drain the copies in flight for node i + 1
-    PH_MARK(5);  // second barrier
-    // ---- (3) S += Y[n]^T Y[n], rows two at a time (operands of step k + 1 read before the MFMAs of step k)
-    if (has_paths) {
-      const float* __restrict__ base = &sh.y[0][0] + (lane >> 5) * 256 + (lane & 31);
-      const int nk = r2 >> 1;
+    int32_t q0, q1;
+    node_range<LIST>(pptr, list, a.n0, cnt, i + 1, q0, q1);
+    // node i's tile: every product wave must have published i + 1 nodes
+    while (lds_min4(sh.ready) < int(i) + 1) __builtin_amdgcn_s_sleep(2);
+    PH_MARK(6);
+    if (p1 > p0 && gwork) {
+      const float* __restrict__ base = &sh.y[i & 1][0][0] + (lane >> 5) * 256 + (lane & 31);
       float xa[8], xb[8];
-      part_load<W, LO, HI>(base, xa);
+      gram256_load<W>(base, xa);
       for (int kk = 0; kk < nk; kk += 2) {
-        if (kk + 1 < nk) part_load<W, LO, HI>(base + (kk + 1) * 512, xb);
+        if (kk + 1 < nk) gram256_load<W>(base + (kk + 1) * 512, xb);
         __builtin_amdgcn_sched_barrier(0);
-        part_mfma<W, LO, HI>(xa, acc);
+        gram256_mfma9<W>(xa, acc);
         __builtin_amdgcn_sched_barrier(0);
         if (kk + 1 < nk) {
-          if (kk + 2 < nk) part_load<W, LO, HI>(base + (kk + 2) * 512, xa);
+          if (kk + 2 < nk) gram256_load<W>(base + (kk + 2) * 512, xa);
           __builtin_amdgcn_sched_barrier(0);
-          part_mfma<W, LO, HI>(xb, acc);
+          gram256_mfma9<W>(xb, acc);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
-    PH_MARK(6);  // Gram
-    pp.p0c = pp.p0n; pp.p1c = pp.p1n; pp.kwc = pp.kwn;
-    pp.p0n = p0nn; pp.p1n = p1nn; pp.kwn = kwnn;
+    lds_publish(&sh.done[W], int(i) + 1, lane);  // (the tile's reads have returned: the MFMAs above consumed them)
+    PH_MARK(5);
+    p0 = q0; p1 = q1;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef LGNN_DEV
-  if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_phase[ro.wave][k], ph.acc[k]);
-#endif
-  const int l31 = lane & 31, lhi = lane >> 5;
-  const int64_t D = H;
-#pragma unroll
-  for (int s = LO; s < HI; ++s) {
-    const int64_t j = Tiles256<W>::sj[s] * 32 + l31;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t ii = Tiles256<W>::si[s] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      if (ii < D && j < D) atomicAdd(&scratch[ii * D + j], acc[s - LO][r]);
-    }
-  }
+  PH_FLUSH(W, lane);
+  gram256_flush<W>(scratch, a.H, lane, acc);
 }
 
-// LIST: the node loop runs over a device-side list of the nodes that have a path (a separate instance: the indirection
-// costs the full-batch GCN launch, where every node has paths, 0.14 ms)
+// LIST: the node loop runs over a device-side list of the nodes that have a path
 template <bool LIST>
-__global__ __launch_bounds__(512, 2) void paths_fused_kernel(YArgs a, float* __restrict__ scratch) {
-  __shared__ FusedShared sh;  // ONE LDS object (a second one makes hipcc drain vmcnt before its reads)
-  if (int64_t(a.pptr[a.N]) > a.cap) return;  // the path list overflowed its buffer: the enumerating route takes over
+__global__ __launch_bounds__(512, 2) void paths_fused_kernel(YArgs a, const int32_t* __restrict__ pptr,
+                                                             const int32_t* __restrict__ list, float* __restrict__ scratch) {
+  __shared__ FusedShared sh;  // ONE LDS object
+  if (int64_t(pptr[a.N]) > a.cap) return;  // the path list overflowed its buffer: the enumerating route takes over
+  // the tiles are zero where nobody writes: columns >= H, the odd row out
+  for (int q = threadIdx.x; q < 2 * kYRows * 256; q += 512) (&sh.y[0][0][0])[q] = 0.f;
+  for (int q = threadIdx.x; q < kYRows * 256; q += 512) {
+    const int row = q >> 8, colq = q & 255;
+    sh.w1[row][colq] = (row < a.R && colq < a.H) ? a.W1[int64_t(a.c0 + row) * a.w1_ld + colq] : 0.f;
+  }
+  if (threadIdx.x < 4) {
+    sh.ready[threadIdx.x] = 64 * int(threadIdx.x) < a.H ? 0 : INT32_MAX;  // (H <= 192: the last product wave has no columns)
+    sh.done[threadIdx.x] = 0;
+  }
+  __syncthreads();
   const int hw = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
-  switch (hw) {  // hardware waves g and g + 4 share a SIMD: 5 + 4 of the group's 9 sub-tiles
-    case 0: fused_wave<0, 0, 5, LIST>(a, sh, scratch); break;
-    case 4: fused_wave<0, 5, 9, LIST>(a, sh, scratch); break;
-    case 1: fused_wave<1, 0, 5, LIST>(a, sh, scratch); break;
-    case 5: fused_wave<1, 5, 9, LIST>(a, sh, scratch); break;
-    case 2: fused_wave<2, 0, 5, LIST>(a, sh, scratch); break;
-    case 6: fused_wave<2, 5, 9, LIST>(a, sh, scratch); break;
-    case 3: fused_wave<3, 0, 5, LIST>(a, sh, scratch); break;
-    default: fused_wave<3, 5, 9, LIST>(a, sh, scratch); break;
+  const int64_t stride = gridDim.x;
+  const int64_t nn = LIST ? int64_t(__builtin_amdgcn_readfirstlane(*a.n_list)) : a.n1 - a.n0;
+  const int64_t cnt = nn > int64_t(blockIdx.x) ? (nn - blockIdx.x + stride - 1) / stride : 0;
+  switch (hw) {
+    case 0: gram_role<0, LIST>(a, pptr, list, sh, cnt, scratch); break;
+    case 1: gram_role<1, LIST>(a, pptr, list, sh, cnt, scratch); break;
+    case 2: gram_role<2, LIST>(a, pptr, list, sh, cnt, scratch); break;
+    case 3: gram_role<3, LIST>(a, pptr, list, sh, cnt, scratch); break;
+    default:
+      if (a.no_bg) product_role<LIST, true>(a, pptr, list, sh, cnt, hw - 4);
+      else product_role<LIST, false>(a, pptr, list, sh, cnt, hw - 4);
+      break;
   }
 }
 
@@ -864,14 +971,17 @@ namespace {
 // (u^T [W_1s | W_1n] is one GEMM whose [M][2H] output IS the [2M][H] table in that order).  paths_fused_kernel runs unchanged.
 __global__ __launch_bounds__(256) void sage_path_tables_kernel(const float* __restrict__ probs, const float* __restrict__ logits,
                                                                const int64_t* __restrict__ idx, const int32_t* __restrict__ pos,
-                                                               int64_t M, int64_t N, int C, int mode, float* __restrict__ coef,
-                                                               float* __restrict__ up) {
+                                                               int64_t M, int64_t N, int C, int cb, int mode,
+                                                               float* __restrict__ coef, float* __restrict__ up,
+                                                               float* __restrict__ alpha) {
   const int lane = threadIdx.x & 63;
   const int64_t m = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (m >= M + C) return;
+  const int c = cb + slot_class(lane);  // the class of slot `lane` (coef_slot order, see path_tables_kernel)
+  const bool have = c < C;
   if (m >= M) {  // the one-hot rows
     float* __restrict__ cm = coef + (2 * M + (m - M)) * kCoefRow;
-    cm[lane] = 0.f; cm[kCoefStride + lane] = lane == int(m - M) ? 1.f : 0.f; cm[2 * kCoefStride + lane] = 0.f; cm[3 * kCoefStride + lane] = 0.f;
+    cm[lane] = 0.f; cm[kCoefStride + lane] = (have && c == int(m - M)) ? 1.f : 0.f; cm[2 * kCoefStride + lane] = 0.f; cm[3 * kCoefStride + lane] = 0.f;
     return;
   }
   const int64_t n = idx[m];
@@ -886,10 +996,14 @@ __global__ __launch_bounds__(256) void sage_path_tables_kernel(const float* __re
     else if (mode == 1) { al = sp * (1.f + 0.5f * t); be = sp; ga = 0.5f * sp * t; u = pk * (1.f + t); }
     else { al = sp; be = sp; u = pk; }
   }
+  const int src = have ? c : 0;
+  float sal = __shfl(al, src), sbe = __shfl(be, src), sga = __shfl(ga, src);  // (unconditional: every lane takes part)
+  if (!have) { sal = 0.f; sbe = 0.f; sga = 0.f; }
   float* __restrict__ cs = coef + (2 * m) * kCoefRow;      // the node's own beta / gamma terms
   float* __restrict__ cn = coef + (2 * m + 1) * kCoefRow;  // a neighbour path from sample m
-  cs[lane] = 0.f; cs[kCoefStride + lane] = -be; cs[2 * kCoefStride + lane] = -ga; cs[3 * kCoefStride + lane] = 0.f;
-  cn[lane] = al;  cn[kCoefStride + lane] = -be; cn[2 * kCoefStride + lane] = -ga; cn[3 * kCoefStride + lane] = 0.f;
+  cs[lane] = 0.f; cs[kCoefStride + lane] = -sbe; cs[2 * kCoefStride + lane] = -sga; cs[3 * kCoefStride + lane] = 0.f;
+  cn[lane] = sal; cn[kCoefStride + lane] = -sbe; cn[2 * kCoefStride + lane] = -sga; cn[3 * kCoefStride + lane] = 0.f;
+  alpha[m * kCoefStride + lane] = al;  // class major: the weights of the one-hot alpha paths (sage_path_list_kernel)
   if (lane < C) { up[m * C + lane] = u; up[(M + m) * C + lane] = own ? pk : 0.f; }
 }
 
@@ -898,7 +1012,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void sage_path_list_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                              const float* __restrict__ val, int64_t N, int64_t M, int C,
                                                              const int32_t* __restrict__ pos, const int32_t* __restrict__ mult,
-                                                             const float* __restrict__ coef, int32_t* __restrict__ pcnt,
+                                                             const float* __restrict__ alpha, int32_t* __restrict__ pcnt,
                                                              const int32_t* __restrict__ pptr, int32_t* __restrict__ pm,
                                                              int32_t* __restrict__ pv, float* __restrict__ pw) {
   const int lane = threadIdx.x & 63;
@@ -927,7 +1041,7 @@ __global__ __launch_bounds__(256) void sage_path_list_kernel(const int32_t* __re
       if (lane == 0) { pm[run] = 2 * ms; pv[run] = int32_t(n); pw[run] = tm; }
       if (lane < C) {
         pm[run + 1 + lane] = int32_t(2 * M) + lane; pv[run + 1 + lane] = int32_t(n);
-        pw[run + 1 + lane] = tm * coef[(2 * int64_t(ms) + 1) * kCoefRow + lane];
+        pw[run + 1 + lane] = tm * alpha[int64_t(ms) * kCoefStride + lane];
       }
     }
     run += 1 + C;
@@ -1010,7 +1124,7 @@ int launch_gram256_stream(const float* Y, int64_t ld, int64_t rows, int64_t widt
 void paths_phase_report() {
   unsigned long long host[8][8];
   if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase), sizeof(host)) != hipSuccess) return;
-  static const char* names[8] = {"barrier 1", "stage issue", "products w1", "products w2+", "Y write", "barrier 2", "Gram", "window wait"};
+  static const char* names[8] = {"P: operand prep", "P: loads + MFMA issue", "P: Y write + publish", "P: drain + wait for tile buffer", "P: operand wait", "G: Gram + publish", "G: wait for tile", "-"};
   fprintf(stderr, "paths_fused_kernel phase cycles (s_memtime ticks, summed over workgroups and launches)\n");
   for (int k = 0; k < 8; ++k) {
     fprintf(stderr, "  %-14s", names[k]);
@@ -1036,6 +1150,10 @@ static int path_node_list(lgnn_ctx* h, int64_t nb, int64_t ne, hipStream_t s) {
   return compact_flags(ws.path_flags.as<uint8_t>(), n, ws.path_nodes.as<int32_t>(), ws.path_nnodes.as<int32_t>(), ws.select_tmp, s);
 }
 
+static int fused_debug() {  // timing experiments (see YArgs::debug); read per call
+  const char* e = getenv("LGNN_FUSED_DEBUG");
+  return e ? atoi(e) : 0;
+}
 // persistent workgroups of paths_fused_kernel: one per CU (149 KB of LDS each); LGNN_FUSED_WGS (dev) leaves CUs to other streams
 static int64_t fused_workgroups() {
   static const int64_t n = getenv("LGNN_FUSED_WGS") ? std::max<int64_t>(1, atoll(getenv("LGNN_FUSED_WGS"))) : 256;
@@ -1057,8 +1175,8 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
   LGNN_CALL(ws.path_up.reserve(size_t(2 * M) * C * 4));
   LGNN_CALL(ws.path_bg.reserve(size_t(2 * M) * H * 4));
   hipLaunchKernelGGL(path_tables_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, ws.probs.as<float>(),
-                     h->fc.out.as<float>(), idx, ws.pos.as<int32_t>(), M, N, int(C), seed_mode, ws.path_coef.as<float>(),
-                     ws.path_up.as<float>());
+                     h->fc.out.as<float>(), idx, ws.pos.as<int32_t>(), M, N, int(C), int(cb), seed_mode,
+                     ws.path_coef.as<float>(), ws.path_up.as<float>());
   LGNN_HIP_CHECK(hipGetLastError());
   const bool no_bg = seed_mode == 2;
   if (!no_bg) {
@@ -1126,10 +1244,10 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>(); y.zeros = ws.path_zeros.as<float>();
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
     y.W1 = h->W[1]; y.w1_ld = int(H); y.Y = nullptr; y.N = N; y.n0 = nb; y.n1 = ne; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
-    y.no_bg = no_bg ? 1 : 0;
+    y.cb = int(cb); y.no_bg = no_bg ? 1 : 0; y.debug = fused_debug();
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel(s) of the KFAC path (bench.py roofline)
-    if (y.list) hipLaunchKernelGGL(paths_fused_kernel<true>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, scratch);
-    else hipLaunchKernelGGL(paths_fused_kernel<false>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, scratch);
+    if (y.list) hipLaunchKernelGGL(paths_fused_kernel<true>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, y.pptr, y.list, scratch);
+    else hipLaunchKernelGGL(paths_fused_kernel<false>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, y.pptr, y.list, scratch);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }
@@ -1149,7 +1267,7 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>(); y.zeros = ws.path_zeros.as<float>();
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
     y.W1 = h->W[1]; y.w1_ld = int(H); y.Y = ws.planes_a.as<float>(); y.N = N; y.n0 = nb; y.n1 = ne; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
-    y.no_bg = no_bg ? 1 : 0;
+    y.cb = int(cb); y.no_bg = no_bg ? 1 : 0;
     const unsigned threads = unsigned(64 * cdiv(H, 64) * cdiv(R, 32));  // (column groups) x (32-class row tiles) waves
     hipLaunchKernelGGL(ybuild_kernel, dim3(unsigned(std::min<int64_t>(ne - nb, 1024))), dim3(threads), 0, s, y);
     LGNN_HIP_CHECK(hipGetLastError());
@@ -1173,9 +1291,10 @@ int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int 
   LGNN_CALL(ws.path_coef.reserve(size_t(T) * kCoefRow * 4));
   LGNN_CALL(ws.path_up.reserve(size_t(2 * M) * C * 4));
   LGNN_CALL(ws.path_bg.reserve(size_t(2 * T) * H * 4));
+  LGNN_CALL(ws.path_alpha.reserve(size_t(M) * kCoefStride * 4));
   hipLaunchKernelGGL(sage_path_tables_kernel, dim3(unsigned(cdiv(M + C, 4))), dim3(256), 0, s, ws.probs.as<float>(),
-                     h->fc.out.as<float>(), idx, ws.pos.as<int32_t>(), M, N, int(C), seed_mode, ws.path_coef.as<float>(),
-                     ws.path_up.as<float>());
+                     h->fc.out.as<float>(), idx, ws.pos.as<int32_t>(), M, N, int(C), int(cb), seed_mode,
+                     ws.path_coef.as<float>(), ws.path_up.as<float>(), ws.path_alpha.as<float>());
   LGNN_HIP_CHECK(hipGetLastError());
   // b rows [0, T): u^T [W_1s | W_1n] as rows (2 m, 2 m + 1), then W_1s[c', :]; g rows [T, 2 T): p^T [W_1s | W_1n], then zeros
   float* bg = ws.path_bg.as<float>();
@@ -1201,12 +1320,12 @@ int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int 
   LGNN_HIP_CHECK(hipMemsetAsync(ws.path_pcnt.as<int32_t>() + N, 0, 4, s));
   const dim3 pgrid{unsigned(cdiv(N, 4))};
   hipLaunchKernelGGL(sage_path_list_kernel<false>, pgrid, dim3(256), 0, s, h->PT.rowptr, h->PT.col, h->PT.val, N, M, int(C),
-                     ws.pos.as<int32_t>(), ws.mult.as<int32_t>(), ws.path_coef.as<float>(), ws.path_pcnt.as<int32_t>(),
+                     ws.pos.as<int32_t>(), ws.mult.as<int32_t>(), ws.path_alpha.as<float>(), ws.path_pcnt.as<int32_t>(),
                      static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
                      static_cast<float*>(nullptr));
   LGNN_CALL(exclusive_scan_i32(ws.path_pcnt.as<int32_t>(), ws.path_pptr.as<int32_t>(), N + 1, ws.select_tmp, s));
   hipLaunchKernelGGL(sage_path_list_kernel<true>, pgrid, dim3(256), 0, s, h->PT.rowptr, h->PT.col, h->PT.val, N, M, int(C),
-                     ws.pos.as<int32_t>(), ws.mult.as<int32_t>(), ws.path_coef.as<float>(), ws.path_pcnt.as<int32_t>(),
+                     ws.pos.as<int32_t>(), ws.mult.as<int32_t>(), ws.path_alpha.as<float>(), ws.path_pcnt.as<int32_t>(),
                      ws.path_pptr.as<int32_t>(), ws.path_pm.as<int32_t>(), ws.path_pv.as<int32_t>(), ws.path_pw.as<float>());
   LGNN_HIP_CHECK(hipGetLastError());
   LGNN_REQUIRE(N < (int64_t(1) << 31), "too many nodes for one launch");
@@ -1222,10 +1341,11 @@ int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int 
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
     y.W1 = h->W[1] + H; y.w1_ld = int(2 * H);  // the neighbour half: the alpha term of the neighbour paths
     y.Y = nullptr; y.N = N; y.n0 = nb; y.n1 = ne; y.M = T; y.H = int(H); y.c0 = int(c0); y.R = int(R);
-    y.no_bg = 0;  // (the one-hot alpha paths go through the beta product: never skipped)
+    y.cb = int(cb); y.no_bg = 0;  // (the one-hot alpha paths go through the beta product: never skipped)
+    y.debug = fused_debug();
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the KFAC path (bench.py roofline)
-    if (y.list) hipLaunchKernelGGL(paths_fused_kernel<true>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, scratch);
-    else hipLaunchKernelGGL(paths_fused_kernel<false>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, scratch);
+    if (y.list) hipLaunchKernelGGL(paths_fused_kernel<true>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, y.pptr, y.list, scratch);
+    else hipLaunchKernelGGL(paths_fused_kernel<false>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, y.pptr, y.list, scratch);
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }

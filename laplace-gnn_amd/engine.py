@@ -249,9 +249,11 @@ class GraphEngine:
 
     def feature_token(self):
         """Exact identity of the bound feature tensor for callers that cache what depends on X only: the tensor object itself
-        (holding it keeps its storage from being recycled under the token) and its version counter."""
+        (holding it keeps its storage from being recycled under the token), its version counter and the engine's own
+        ``rebind`` count.  Writes through ``X.data`` (``X.data.mul_()``, ``X.data.copy_()``) bump no version counter: after
+        them call ``rebind()`` -- the same contract as for parameters written through ``p.data`` (``invalidate()``)."""
         X = self._bound[0]
-        return (_IdentityKey(X), X._version, tuple(X.shape))
+        return (_IdentityKey(X), X._version, tuple(X.shape), getattr(self, "_rebinds", 0))
 
     def _param_versions(self):
         _, ws, bs = self._bound
@@ -261,7 +263,19 @@ class GraphEngine:
         return [(X.data_ptr(), X._version)] + [(t.data_ptr(), t._version) for t in (*ws, *bs, *extra)]
 
     def invalidate(self):
+        """Drop the cached forward / input Grams.  Needed by hand only after writes the version counters cannot see
+        (``p.data.add_()`` and friends); optimizer steps, ``p.add_()`` under ``no_grad`` and storage swaps are detected."""
         _lib.check(self.lib.lgnn_invalidate(self._h), "lgnn_invalidate")
+
+    def rebind(self):
+        """Bind the same tensors again: drops everything derived from X too (padded copy, P X, X^T X and the callers'
+        caches keyed by ``feature_token``).  For feature writes through ``X.data``, which no version counter records."""
+        if self._bound is None:
+            raise _lib.HipLibraryError("no model bound")
+        X, ws, bs = self._bound
+        self._rebinds = getattr(self, "_rebinds", 0) + 1
+        self.bind(X, ws, bs, *self._bind_opts, **self._extras)
+        self.invalidate()
 
     def _sync_versions(self):
         """In-place updates of the bound parameters (optimizer steps) invalidate the cached forward."""

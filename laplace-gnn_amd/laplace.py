@@ -171,13 +171,10 @@ class ParametricLaplace(BaseLaplace):
             self.n_data = 0
         if self.model.training:
             self.model.eval()
-        # the flattened parameters (laplace/baselaplace.py:800): one concatenation kernel -- skipped when no parameter tensor
-        # has been replaced or written in place since the last fit (storage pointers + version counters), e.g. refits
-        # after adjacency steps of the structure-learning loop, where a Cora-shaped fit is nine launches in all
-        mean_key = tuple((p.data_ptr(), p._version) for p in self.params)
-        if getattr(self, "_mean_key", None) != mean_key or not torch.is_tensor(getattr(self, "mean", None)):
-            self.mean = parameters_to_vector(self.params).detach()
-            self._mean_key = mean_key
+        # the flattened parameters, recomputed on every fit exactly as laplace/baselaplace.py:800 does (one concatenation
+        # kernel).  Version counters cannot stand in for it: ``p.data.add_()`` / ``p.data.copy_()`` do not bump
+        # ``p._version``, and ``load_state_dict`` / ``la.mean = ...`` replace the vector behind any key
+        self.mean = parameters_to_vector(self.params).detach()
         dev = self._device
         # the reference finds the output width with a forward pass of one sample (laplace/baselaplace.py:806-816); a model
         # that states it (laplace_gnn_amd.models.BaseGNN.n_outputs) saves that pass' launches -- a Cora-shaped fit is

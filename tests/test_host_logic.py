@@ -610,22 +610,36 @@ def test_model_constructor_validation():
         lg.GraphSAGE(4, 5, 3, 2, X, adj, 5)
 
 
-def test_the_flattened_mean_is_reused_only_while_no_parameter_changed():
-    """fit() flattens the parameters into ``mean`` (laplace/baselaplace.py:800); the concatenation is skipped when neither a
-    parameter's storage nor its version counter moved since the last fit -- and only then."""
+def test_the_flattened_mean_follows_every_kind_of_parameter_write():
+    """fit() flattens the parameters into ``mean`` on EVERY call (laplace/baselaplace.py:800): writes through ``p.data``
+    bump no version counter, and ``load_state_dict`` / ``la.mean = ...`` replace the vector -- none of them may leave a
+    stale or foreign posterior mean behind."""
     g = np.load(os.path.join(GOLDEN, "gcn_small_3batch_s1.npz"))
     model = _cpu_model(g)
     loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"]), int(g["batch_size"]))
     la = lg.Laplace(model, "classification", "all", "diag", backend=OracleBackend)
+    flat = lambda: torch.nn.utils.parameters_to_vector(la.params).detach()  # noqa: E731
     la.fit(loader)
-    m0 = la.mean
+    assert torch.equal(la.mean, flat())
+    v0 = [p._version for p in la.params]
+    for p in la.params:
+        p.data.add_(1.0)  # invisible to the version counters
+    assert [p._version for p in la.params] == v0
     la.fit(loader)
-    assert la.mean is m0  # nothing changed: the same tensor
+    assert torch.equal(la.mean, flat())
     with torch.no_grad():
         model.convs[0].lin.bias.add_(0.25)  # in place: the version counter moves
     la.fit(loader)
-    assert la.mean is not m0 and torch.equal(la.mean, torch.nn.utils.parameters_to_vector(la.params).detach())
+    assert torch.equal(la.mean, flat())
     m1 = la.mean
     torch.nn.utils.vector_to_parameters(m1.clone() * 0.5, la.params)  # storage replaced
     la.fit(loader)
-    assert la.mean is not m1 and torch.equal(la.mean, m1 * 0.5)
+    assert torch.equal(la.mean, m1 * 0.5)
+    la.mean = torch.zeros_like(la.mean)  # a foreign vector
+    la.fit(loader)
+    assert torch.equal(la.mean, flat())
+    sd = la.state_dict()
+    sd["mean"] = sd["mean"] + 3.0
+    la.load_state_dict(sd)
+    la.fit(loader)
+    assert torch.equal(la.mean, flat())
