@@ -41,6 +41,10 @@
 #include "gram256.h"
 #include "lgnn_internal.h"
 
+#ifndef LGNN_PABL
+#define LGNN_PABL 0
+#endif
+
 namespace lgnn {
 
 namespace {
@@ -61,11 +65,11 @@ __device__ __forceinline__ float wsum(float v) {
 
 // One wave per batch sample (first occurrences only; a node listed t times carries t in its R weights).
 // mode: 0 upstream seeds, 1 fork exact, 2 regression (V = sqrt(2) I).  The coefficient row holds the classes [cb, cb + 64) of the
-// call in slot order (coef_slot); slots of classes >= C are zero.
+// call in slot order (coef_slot); slots of classes >= ce are zero.
 __global__ __launch_bounds__(256) void path_tables_kernel(const float* __restrict__ probs, const float* __restrict__ logits,
                                                           const int64_t* __restrict__ idx, const int32_t* __restrict__ pos,
-                                                          int64_t M, int64_t N, int C, int cb, int mode, float* __restrict__ coef,
-                                                          float* __restrict__ up) {
+                                                          int64_t M, int64_t N, int C, int cb, int ce, int mode,
+                                                          float* __restrict__ coef, float* __restrict__ up) {
   const int lane = threadIdx.x & 63;
   const int64_t m = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -84,9 +88,10 @@ __global__ __launch_bounds__(256) void path_tables_kernel(const float* __restric
     else if (mode == 1) { al = sp * (1.f + 0.5f * t); be = sp; ga = 0.5f * sp * t; u = pk * (1.f + t); }
     else { al = sp; be = sp; u = pk; }
   }
-  // slot `lane` of each kind holds class cb + slot_class(lane): fetched from the lane that computed it
+  // slot `lane` of each kind holds class cb + slot_class(lane): fetched from the lane that computed it.  Classes outside the
+  // call's range [cb, ce) get zero coefficients: their rows of Y come out as exact zeros, the fused kernel stores them unasked
   const int c = cb + slot_class(lane);
-  const bool have = c < C;
+  const bool have = c < ce;
   const int src = have ? c : 0;
   const float sal = __shfl(al, src), sbe = __shfl(be, src), sga = __shfl(ga, src);
   cm[lane] = have ? sal : 0.f;
@@ -189,6 +194,7 @@ struct YArgs {
   const int32_t* n_list;    // ... and how many (device side: no host round trip); null: every node of the range
   int H, c0, R;
   int cb;                   // first class of the coefficient table's slots (the call's class range starts there)
+  int64_t n_coef;           // rows of the coefficient table
   int debug;                // LGNN_FUSED_DEBUG (timing experiments only, results are wrong with bits 0 / 1): 1 no Gram, 2 no
                             // products, 4 product waves at priority 3, 8 Gram waves at priority 3, 16 all operand loads from sample 0 / node 0
   int no_bg;                // regression / nothing but the diagonal term: the beta / gamma products vanish
@@ -455,8 +461,10 @@ constexpr int kYRows = 48;  // classes per launch: three 16-class MFMA tiles (LD
 
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 
+constexpr int kYStride = 272;  // floats per tile row: 256 + 16, so that the four rows of a Gram operand read (lanes 16 k ..
+                               // 16 k + 15 read row k0 + k) fall on disjoint banks
 struct alignas(16) FusedShared {
-  float y[2][kYRows][256];  // the node tiles (double buffered)
+  float y[2][kYRows][kYStride];  // the node tiles (double buffered)
   float w1[kYRows][256];    // W_1's rows of the launch (zero past R / H)
   // hand-off counters (one writer each): ready[p] = nodes whose tile columns product wave p has published, done[g] = nodes
   // Gram wave g has contracted
@@ -509,62 +517,82 @@ __device__ __forceinline__ void node_range(const int32_t* __restrict__ pptr, con
 // issued here and waited for with a counted s_waitcnt whose "+v" operands tie the loaded registers to the wait (uses cannot
 // move above it).  vmcnt counts in order: waiting until at most n operations are outstanding retires everything older than
 // the n youngest.
-__device__ __forceinline__ void gload4(f32x4v& d, const float* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+// BUFFER loads (descriptor in SGPRs + one 32-bit byte offset per lane): on this chip the fp32 MFMAs run on the SIMD's vector
+// ALUs, so every VALU instruction of either wave of a SIMD is matrix-pipe time lost, not work hidden behind the MFMAs
+// (measured: the product wave's MFMA time and the time of its other instructions add up, with or without the Gram wave) --
+// 64-bit address arithmetic per load was a quarter of this wave's instructions.  An offset past the table's end reads zeros.
+using i32x4 = int __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, uint64_t bytes) {
+  const uint64_t u = reinterpret_cast<uint64_t>(p);
+  return i32x4{int(uint32_t(u)), int(uint32_t(u >> 32) & 0xffffu), int(uint32_t(bytes > 0xffffffffull ? 0xffffffffull : bytes)),
+               0x00020000};
 }
-__device__ __forceinline__ void gload1(uint32_t& d, const void* p) {
-  asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+template <int OFF>
+__device__ __forceinline__ void bload4(f32x4v& d, uint32_t voff, const i32x4& rsrc) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(d) : "v"(voff), "s"(rsrc), "n"(OFF) : "memory");
 }
+__device__ __forceinline__ void bload1(uint32_t& d, uint32_t voff, const i32x4& rsrc) {
+  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(d) : "v"(voff), "s"(rsrc) : "memory");
+}
+struct PTables {  // descriptors of what the role reads
+  i32x4 coef, b, g, mask, pm, pv, pw;
+};
 
-// The triples of (up to) 64 paths starting at p0: lane l holds path p0 + l.  Unconditional loads from a clamped index; lanes
-// past the range get (sample 0, node 0, weight 0) in meta_finish: every address formed from them is valid, every product with
-// them is zero.
-struct PMeta { uint32_t m, v, w; };  // (w: the bits of a float)
-__device__ __forceinline__ void meta_issue(const YArgs& a, int32_t p0, int32_t p1, int lane, PMeta& t) {
-  const int32_t q = max(min(p0 + lane, p1 - 1), 0);
-  gload1(t.m, a.pm + q);
-  gload1(t.v, a.pv + q);
-  gload1(t.w, a.pw + q);
+// The paths of a chunk (up to 64): lane l holds path p0 + l as the BYTE OFFSETS of its sample's rows in the coefficient table
+// (oc) and the b / g tables (ob), of its middle node's mask words (om), and its weight.  Unconditional loads from a clamped
+// index; lanes past the range get offsets 0 and weight 0 in meta_finish: every load formed from them is valid, every product
+// with them is zero.
+struct PMeta { uint32_t oc, ob, om, w; };  // (w: the bits of a float)
+__device__ __forceinline__ void meta_issue(const PTables& tb, int32_t p0, int32_t p1, int lane, PMeta& t) {
+  const uint32_t q = uint32_t(max(min(p0 + lane, p1 - 1), 0)) * 4u;
+  bload1(t.oc, q, tb.pm);  // (sample m, node v: turned into offsets in meta_finish)
+  bload1(t.om, q, tb.pv);
+  bload1(t.w, q, tb.pw);
 }
 template <int YOUNGER>  // vector-memory operations issued after the triples' loads that may still be in flight
-__device__ __forceinline__ void meta_finish(int32_t p0, int32_t p1, int lane, PMeta& t) {
-  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(t.m), "+v"(t.v), "+v"(t.w) : "n"(YOUNGER) : "memory");
+__device__ __forceinline__ void meta_finish(int32_t p0, int32_t p1, int lane, uint32_t row_bytes, uint32_t mask_bytes, PMeta& t) {
+  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(t.oc), "+v"(t.om), "+v"(t.w) : "n"(YOUNGER) : "memory");
   const bool in = p0 + lane < p1;
-  t.m = in ? t.m : 0u; t.v = in ? t.v : 0u; t.w = in ? t.w : 0u;
+  const uint32_t m = in ? t.oc : 0u, v = in ? t.om : 0u;
+  t.oc = m * uint32_t(kCoefRow * 4); t.ob = m * row_bytes; t.om = v * mask_bytes;
+  t.w = in ? t.w : 0u;
 }
 
-struct PLane {       // what a product-wave lane is: class slot / column slot i, path k of a step
-  int i, kq;
-  int colc;          // 64 cg + 4 i (0 when past H: a valid address, the result is dropped)
-  bool col_ok;
-  int mword, mshift; // mask word and bit of column colc
+struct PLane {        // what a product-wave lane is: class slot / column slot i, path k of a step
+  int kq;
+  uint32_t oc, ob, om;  // the lane's byte offsets inside a coefficient row (16 i), a table row (4 (64 cg + 4 i)) and a node's
+                        // mask words; past H: the row's start resp. an offset outside the mask (reads zero: no bit set)
+  int mshift;           // bit of the lane's first column inside its mask word
 };
 
 struct POps {        // the loaded operands of one step (22 registers)
   f32x4v ca[3];      // coefficient rows (alpha | -beta | -gamma), class slots (i, t = 0 .. 3)
-  f32x4v b4, g4;     // rows b_m, g_m at columns colc .. colc + 3
+  f32x4v b4, g4;     // rows b_m, g_m at the lane's four columns
   uint32_t mw;       // mask word of the path's middle node
-  float w;           // path weight (0 past the node's last path)
+  float w;           // path weight (0 past the chunk's last path)
 };
 
-// Issue the loads of step s (paths 4 s .. 4 s + 3 of the chunk whose triples `mt` holds): kStepLoads<NOBG> instructions,
-// nothing conditional.
+// Issue the loads of step s (paths 4 s .. 4 s + 3 of the chunk `mt`): kStepLoads<NOBG> instructions, nothing conditional.
 template <bool NOBG> constexpr int kStepLoads = NOBG ? 2 : 6;
 template <bool NOBG>
-__device__ __forceinline__ void p_load(const YArgs& a, const PMeta& mt, int s, const PLane& pl, POps& o) {
+__device__ __forceinline__ void p_load(const PTables& tb, const PMeta& mt, int s, const PLane& pl, POps& o) {
   const int src = 4 * s + pl.kq;  // the lane that holds this lane's path (s < 16)
-  int32_t m = __shfl(int(mt.m), src), v = __shfl(int(mt.v), src);
-  if (a.debug & 16) { m = 0; v = 0; }  // (timing experiment: every operand load hits the same cache lines)
+  const uint32_t oc = uint32_t(__shfl(int(mt.oc), src)) + pl.oc;
+  const uint32_t om = uint32_t(__shfl(int(mt.om), src)) + pl.om;
   o.w = __uint_as_float(uint32_t(__shfl(int(mt.w), src)));
-  const float* __restrict__ cr = a.coef + int64_t(m) * kCoefRow + 4 * pl.i;
-  gload4(o.ca[0], cr);
+#if LGNN_PABL == 2  // (timing experiment: no operand loads)
+  asm volatile("" :: "v"(oc), "v"(om));
+  return;
+#endif
+  bload4<0>(o.ca[0], oc, tb.coef);
   if constexpr (!NOBG) {
-    gload4(o.ca[1], cr + kCoefStride);
-    gload4(o.ca[2], cr + 2 * kCoefStride);
-    gload4(o.b4, a.bg + int64_t(m) * a.H + pl.colc);
-    gload4(o.g4, a.bg + (a.M + int64_t(m)) * a.H + pl.colc);
+    const uint32_t ob = uint32_t(__shfl(int(mt.ob), src)) + pl.ob;
+    bload4<kCoefStride * 4>(o.ca[1], oc, tb.coef);
+    bload4<2 * kCoefStride * 4>(o.ca[2], oc, tb.coef);
+    bload4<0>(o.b4, ob, tb.b);
+    bload4<0>(o.g4, ob, tb.g);
   }
-  gload1(o.mw, a.mask + int64_t(v) * a.mask_words + pl.mword);
+  bload1(o.mw, om, tb.mask);
 }
 // the step's loads have landed once at most YOUNGER younger vector-memory operations are outstanding
 template <bool NOBG, int YOUNGER>
@@ -577,29 +605,45 @@ __device__ __forceinline__ void p_wait(POps& o) {
 }
 
 // A step's MFMA operands: lane (i, k): A[row i][k] = weighted coefficient of class 16 t + i, B[k][col i] = mask bit / masked
-// table value of column 64 cg + 4 i + ct.
+// table value of the lane's column ct.  HI (a second launch of a call with more than 48 classes): the launch's only class
+// tile is the fourth of the slot.  26 vector instructions (each costs the SIMD's matrix pipe its issue cycles, see above):
+// bit ct of the mask word as 0 / -1 with one v_bfe_i32, ANDed with 1.0f.
 struct PCur { float a0[3], a1[3], a2[3], mf[4], bb[4], gg[4]; };
-template <bool NOBG>
-__device__ __forceinline__ void p_xform(const POps& o, const PLane& pl, bool hi, PCur& c) {
-  // hi (a second launch of a call with more than 48 classes): the launch's only tile is the fourth of the slot
-  const float wl = hi ? 0.f : o.w, wh = hi ? o.w : 0.f;
+template <bool NOBG, bool HI>
+__device__ __forceinline__ void p_xform(const POps& o, const PLane& pl, PCur& c) {
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
-    c.a0[t] = wl * o.ca[0][t];
-    if constexpr (!NOBG) { c.a1[t] = wl * o.ca[1][t]; c.a2[t] = wl * o.ca[2][t]; }
+    const int tt = HI ? 3 : t;
+    c.a0[t] = (HI && t > 0) ? 0.f : o.w * o.ca[0][tt];
+    if constexpr (!NOBG) {
+      c.a1[t] = (HI && t > 0) ? 0.f : o.w * o.ca[1][tt];
+      c.a2[t] = (HI && t > 0) ? 0.f : o.w * o.ca[2][tt];
+    }
   }
-  c.a0[0] = fmaf(wh, o.ca[0][3], c.a0[0]);
-  if constexpr (!NOBG) { c.a1[0] = fmaf(wh, o.ca[1][3], c.a1[0]); c.a2[0] = fmaf(wh, o.ca[2][3], c.a2[0]); }
-  const uint32_t bits = pl.col_ok ? (o.mw >> pl.mshift) : 0u;
+  const int bits = int(o.mw >> pl.mshift);
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
-    c.mf[ct] = ((bits >> ct) & 1u) ? 1.f : 0.f;
+    const int on = __builtin_amdgcn_sbfe(bits, ct, 1);  // 0 or -1
+    c.mf[ct] = __int_as_float(on & 0x3f800000);
     if constexpr (!NOBG) { c.bb[ct] = c.mf[ct] * o.b4[ct]; c.gg[ct] = c.mf[ct] * o.g4[ct]; }
+  }
+}
+// an empty statement that reads every register of `c`: keeps the set alive (and out of the other set's registers) up to here
+template <bool NOBG>
+__device__ __forceinline__ void p_keep(const PCur& c) {
+  asm volatile("" :: "v"(c.a0[0]), "v"(c.a0[1]), "v"(c.a0[2]), "v"(c.mf[0]), "v"(c.mf[1]), "v"(c.mf[2]), "v"(c.mf[3]));
+  if constexpr (!NOBG) {
+    asm volatile("" :: "v"(c.a1[0]), "v"(c.a1[1]), "v"(c.a1[2]), "v"(c.a2[0]), "v"(c.a2[1]), "v"(c.a2[2]));
+    asm volatile("" :: "v"(c.bb[0]), "v"(c.bb[1]), "v"(c.bb[2]), "v"(c.bb[3]), "v"(c.gg[0]), "v"(c.gg[1]), "v"(c.gg[2]), "v"(c.gg[3]));
   }
 }
 // the 36 (NOBG: 12) MFMAs of one step;  D: col = i, row = 4 k + r
 template <bool NOBG>
 __device__ __forceinline__ void p_mfma(const PCur& c, f32x4v (&t1)[3][4], f32x4v (&y2)[3][4]) {
+#if LGNN_PABL == 1  // (timing experiment: the step's MFMAs are not issued)
+  p_keep<NOBG>(c);
+  return;
+#endif
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -650,25 +694,18 @@ struct ChunkGen {
 // The product wave of SIMD cg.  Steps come in PAIRS (8 paths): buffer A holds the loaded operands of the pair's first step, B
 // of its second; each is refilled for the NEXT pair -- this chunk's, or the next chunk's first (usually the next node's) --
 // right after its values were turned into MFMA operands, so two steps' loads (12 instructions) are in flight behind the 36
-// MFMAs being issued.  Everything hipcc's wait counts depend on is kept static: the loads are unconditional and in one fixed
-// order, the pair loop's body is straight-line code, and A / B are written nowhere else inside the loop (with a branch in the
-// body, or a second definition on a side path -- hubs, empty nodes --, hipcc resolves the loop phis with register copies of
-// loads still in flight, i.e. drains them: measured as the whole latency exposed once per pair resp. once per node).  Hence
-// the chunk stream: hubs and empty nodes take the same path as everything else; a step past the chunk's last path multiplies
-// zero weights (load_meta), an empty chunk is one such pair.
-template <bool LIST, bool NOBG>
+// MFMAs being issued.  The loads are unconditional and in one fixed order, the hand-counted waits rely on it; A / B are written
+// nowhere else inside the loop.  Hence the chunk stream: hubs and empty nodes take the same path as everything else; a step past
+// the chunk's last path multiplies zero weights (meta_finish), an empty chunk is one such pair.  The loop body is straight-line
+// code on purpose: skipping the MFMAs of a pair's empty second step with a branch gave wrong tiles now and then (the MFMA ->
+// VALU wait states hipcc inserts are counted along straight-line code; the tile write behind the loop read accumulators an
+// MFMA inside the branch had not finished writing).
+template <bool LIST, bool NOBG, bool HI>
 __device__ __forceinline__ void product_role(const YArgs& a, const int32_t* __restrict__ pptr, const int32_t* __restrict__ list,
                                              FusedShared& sh, int64_t cnt, int cg) {
   const int lane = threadIdx.x & 63;
-  const int H = a.H, R = a.R;
-  PLane pl;
-  pl.i = lane & 15; pl.kq = lane >> 4;
-  const int col = 64 * cg + 4 * pl.i;
-  pl.col_ok = col < H;  // (H % 4 == 0: the lane's four columns are in or out together)
-  pl.colc = pl.col_ok ? col : 0;
-  pl.mword = pl.colc >> 5; pl.mshift = pl.colc & 31;
-  const bool path_wave = 64 * cg < H;  // (H <= 192: the last product wave only keeps the barriers)
-  const bool hi = a.c0 != a.cb;        // classes cb + 48 ..: the fourth tile of the coefficient slots
+  const int H = a.H;
+  const bool path_wave = 64 * cg < H;  // (H <= 192: the last product wave has no columns)
   PH_DECL;
   if (a.debug & 4) __builtin_amdgcn_s_setprio(3);
   if (!path_wave) return;  // (its ready counter was set to "everything" at the kernel's top)
@@ -676,6 +713,24 @@ __device__ __forceinline__ void product_role(const YArgs& a, const int32_t* __re
     lds_publish(&sh.ready[cg], INT32_MAX, lane);
     return;
   }
+  PLane pl;
+  const int li = lane & 15;
+  pl.kq = lane >> 4;
+  const int col = 64 * cg + 4 * li;
+  const bool col_ok = col < H;  // (H % 4 == 0: the lane's four columns are in or out together)
+  pl.oc = 16u * uint32_t(li);
+  pl.ob = col_ok ? 4u * uint32_t(col) : 0u;
+  pl.om = col_ok ? 4u * uint32_t(col >> 5) : 0x7ffffff0u;  // (past H: outside the mask, the load returns zero bits)
+  pl.mshift = col & 31;
+  const uint32_t row_bytes = uint32_t(H) * 4u, mask_bytes = uint32_t(a.mask_words) * 4u;
+  PTables tb;
+  tb.coef = make_rsrc(a.coef, uint64_t(a.n_coef) * kCoefRow * 4);
+  tb.b = make_rsrc(a.bg, uint64_t(a.M) * row_bytes);
+  tb.g = make_rsrc(a.bg + a.M * int64_t(H), uint64_t(a.M) * row_bytes);
+  tb.mask = make_rsrc(a.mask, uint64_t(a.N) * mask_bytes);
+  tb.pm = make_rsrc(a.pm, uint64_t(a.cap) * 4);
+  tb.pv = make_rsrc(a.pv, uint64_t(a.cap) * 4);
+  tb.pw = make_rsrc(a.pw, uint64_t(a.cap) * 4);
   constexpr int NL = kStepLoads<NOBG>;
   ChunkGen<LIST> gen;
   gen.init(pptr, list, a.n0, cnt);
@@ -684,78 +739,79 @@ __device__ __forceinline__ void product_role(const YArgs& a, const int32_t* __re
   gen.next(cnt, q0c, q1c, lastc);
   gen.next(cnt, q0n, q1n, lastn);
   PMeta mc, mn;
-  meta_issue(a, q0c, q1c, lane, mc);
-  meta_issue(a, q0n, q1n, lane, mn);
-  meta_finish<0>(q0c, q1c, lane, mc);
-  meta_finish<0>(q0n, q1n, lane, mn);
+  meta_issue(tb, q0c, q1c, lane, mc);
+  meta_issue(tb, q0n, q1n, lane, mn);
+  meta_finish<0>(q0c, q1c, lane, row_bytes, mask_bytes, mc);
+  meta_finish<0>(q0n, q1n, lane, row_bytes, mask_bytes, mn);
   POps A, B;
-  p_load<NOBG>(a, mc, 0, pl, A);
-  p_load<NOBG>(a, mc, 1, pl, B);
+  p_load<NOBG>(tb, mc, 0, pl, A);
+  p_load<NOBG>(tb, mc, 1, pl, B);
   f32x4v t1[3][4], y2[3][4];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) { t1[t][ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; y2[t][ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+  // Two sets of prepared MFMA operands, alternating (p_keep pins them to registers of their own): the next step is prepared
+  // while the MFMAs of the previous one may still be reading theirs.
+  PCur cA = {}, cB = {};
   bool node_has = false;  // the node being built has a path so far
   for (int64_t i = 0; i < cnt;) {  // node i's tile is built while the Gram waves contract node i - 1's (or i - 2's)
-    // the chunk after the next: its range now, its triples a whole chunk before they are used.  In flight from here
+    // the chunk after the next: its range now, its paths a whole chunk before they are used.  In flight from here
     // (oldest first): A, B (issued by the previous chunk's last pair), these three loads
     int32_t q0f, q1f;
     bool lastf;
     gen.next(cnt, q0f, q1f, lastf);
     PMeta mf2;
-    meta_issue(a, q0f, q1f, lane, mf2);
+    meta_issue(tb, q0f, q1f, lane, mf2);
     const int kch = q1c - q0c, np = max((kch + 7) >> 3, 1);
     node_has = node_has || kch > 0;
     for (int j = 0; j < np; ++j) {
       // the pair after this one: this chunk's, else the next chunk's first
       const bool more = j + 1 < np;
       PMeta mx;
-      mx.m = more ? mc.m : mn.m; mx.v = more ? mc.v : mn.v; mx.w = more ? mc.w : mn.w;
+      mx.oc = more ? mc.oc : mn.oc; mx.ob = more ? mc.ob : mn.ob; mx.om = more ? mc.om : mn.om; mx.w = more ? mc.w : mn.w;
       const int sx = more ? 2 * (j + 1) : 0;
-      PCur c;
-      // A's loads: the NL youngest outstanding may be B's (the first pair of a chunk: B's and the three triple loads --
-      // there the count also waits for B's first half, issued a whole pair earlier)
+      // A's loads: the NL youngest outstanding may be B's (the first pair of a chunk: B's and the three path loads -- there
+      // the count also waits for B's first half, issued a whole pair earlier)
       p_wait<NOBG, NL>(A);
       PH_MARK(4);
-      p_xform<NOBG>(A, pl, hi, c);
+      p_xform<NOBG, HI>(A, pl, cA);
+      p_keep<NOBG>(cB);  // (cB's MFMAs may still be queued: cA must not be prepared into their operand registers)
       PH_MARK(0);
-      __builtin_amdgcn_sched_barrier(0);
-      p_load<NOBG>(a, mx, sx, pl, A);
-      __builtin_amdgcn_sched_barrier(0);
-      p_mfma<NOBG>(c, t1, y2);
+      p_load<NOBG>(tb, mx, sx, pl, A);
+      p_mfma<NOBG>(cA, t1, y2);
       PH_MARK(1);
-      __builtin_amdgcn_sched_barrier(0);
       p_wait<NOBG, NL>(B);  // (younger: A's refill)
       PH_MARK(4);
-      p_xform<NOBG>(B, pl, hi, c);
+      p_xform<NOBG, HI>(B, pl, cB);
+      p_keep<NOBG>(cA);  // (likewise)
       PH_MARK(0);
-      __builtin_amdgcn_sched_barrier(0);
-      p_load<NOBG>(a, mx, sx + 1, pl, B);
-      __builtin_amdgcn_sched_barrier(0);
-      p_mfma<NOBG>(c, t1, y2);
+      p_load<NOBG>(tb, mx, sx + 1, pl, B);
+      p_mfma<NOBG>(cB, t1, y2);  // (unconditional: see the role's header)
       PH_MARK(1);
-      __builtin_amdgcn_sched_barrier(0);
     }
     if (lastc) {
       // tile i & 1 was last read by the Gram of node i - 2: every Gram wave must have counted i - 1 nodes
       if (i >= 2)
         while (lds_min4(sh.done) < int(i) - 1) __builtin_amdgcn_s_sleep(2);
       PH_MARK(3);
-      if (node_has && pl.col_ok) {
-        // Y[n] = W_1 (.) T1 + Y2; rows past the launch's classes are written as the zeros they already are (one branch
-        // around twelve unconditional 16-byte stores instead of twelve branches)
-        float (*ytile)[256] = sh.y[i & 1];
+#if LGNN_PABL == 3  // (timing experiment: no tile write)
+      if (false) {
+#else
+      if (node_has && col_ok) {
+#endif
+        // Y[n] = W_1 (.) T1 + Y2.  Rows past the launch's classes come out as the zeros they already are (their coefficients
+        // and their rows of W_1 are zero): one branch around twelve unconditional 16-byte stores.
+        float (*ytile)[kYStride] = sh.y[i & 1];
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * t + 4 * pl.kq + r;
-            const float keep = row < R ? 1.f : 0.f;
             const f32x4v w1 = *reinterpret_cast<const f32x4v*>(&sh.w1[row][col]);
             f32x4v o;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) o[ct] = keep * (w1[ct] * t1[t][ct][r] + y2[t][ct][r]);
+            for (int ct = 0; ct < 4; ++ct) o[ct] = w1[ct] * t1[t][ct][r] + y2[t][ct][r];
             *reinterpret_cast<f32x4v*>(&ytile[row][col]) = o;
           }
       }
@@ -768,25 +824,54 @@ __device__ __forceinline__ void product_role(const YArgs& a, const int32_t* __re
       node_has = false;
       PH_MARK(2);
     }
-    // rotate the chunk stream (the triples issued at the top are older than the 2 NL loads of the last pair's refills)
-    meta_finish<2 * NL>(q0f, q1f, lane, mf2);
+    // rotate the chunk stream (the paths issued at the top are older than the 2 NL loads of the last pair's refills)
+    meta_finish<2 * NL>(q0f, q1f, lane, row_bytes, mask_bytes, mf2);
     q0c = q0n; q1c = q1n; lastc = lastn; mc = mn;
     q0n = q0f; q1n = q1f; lastn = lastf; mn = mf2;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the refills past the last chunk
-  PH_FLUSH(4 + cg, lane);
+  PH_FLUSH(cg, lane);
 }
 
+// The Gram wave W: its 9 upper 32 x 32 sub-tiles of gram256.h, each as 2 x 2 tiles of v_mfma_f32_16x16x4_f32 (the lower tile
+// of a diagonal sub-tile is never read by the symmetrising pass and is skipped: 34 MFMAs per four tile rows).  The SAME
+// instruction shape as the product wave's on purpose: the two waves of a SIMD take turns on its matrix pipe instruction by
+// instruction, so with 64-cycle 32x32x2 instructions here every one of the product wave's 32-cycle instructions waited 64
+// cycles and that wave -- a third of the pipe's time for a third of the work plus its serial sections -- was the critical path
+// (measured: its node time = time alone + 155 x 64 cycles; Gram waves idle 30 %).
+// Operand of a k step (4 tile rows) for the 16 columns 32 b + 16 h: lane l holds Y[k0 + (l >> 4)][32 b + 16 h + (l & 15)] -- as
+// A operand (row l & 15, k = l >> 4) and as B operand (k = l >> 4, column l & 15) alike.
+template <int W>
+__device__ __forceinline__ void gram16_load(const float* __restrict__ p, float (&x)[8][2]) {
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    x[b][0] = tiles256_uses<W>(b) ? p[b * 32] : 0.f;
+    x[b][1] = tiles256_uses<W>(b) ? p[b * 32 + 16] : 0.f;
+  }
+}
+template <int W>
+__device__ __forceinline__ void gram16_mfma(const float (&x)[8][2], f32x4v (&acc)[9][2][2]) {
+#pragma unroll
+  for (int s = 0; s < 9; ++s)
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+      for (int hj = 0; hj < 2; ++hj) {
+        if (Tiles256<W>::si[s] == Tiles256<W>::sj[s] && hi > hj) continue;  // (below the diagonal)
+        acc[s][hi][hj] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[Tiles256<W>::si[s]][hi], x[Tiles256<W>::sj[s]][hj],
+                                                              acc[s][hi][hj], 0, 0, 0);
+      }
+}
 template <int W, bool LIST>
 __device__ __forceinline__ void gram_role(const YArgs& a, const int32_t* __restrict__ pptr, const int32_t* __restrict__ list,
                                           FusedShared& sh, int64_t cnt, float* __restrict__ scratch) {
   const int lane = threadIdx.x & 63;
-  f32x16 acc[9];
+  f32x4v acc[9][2][2];
 #pragma unroll
   for (int s = 0; s < 9; ++s)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
-  const int nk = (a.R + 1) >> 1;  // rows two at a time (an odd class count: one zero row)
+    for (int q = 0; q < 4; ++q) acc[s][q >> 1][q & 1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  const int nk = (a.R + 3) >> 2;  // tile rows four at a time (rows past R are zero)
   int32_t p0, p1;
   node_range<LIST>(pptr, list, a.n0, cnt, 0, p0, p1);
   PH_DECL;
@@ -799,18 +884,18 @@ __device__ __forceinline__ void gram_role(const YArgs& a, const int32_t* __restr
     while (lds_min4(sh.ready) < int(i) + 1) __builtin_amdgcn_s_sleep(2);
     PH_MARK(6);
     if (p1 > p0 && gwork) {
-      const float* __restrict__ base = &sh.y[i & 1][0][0] + (lane >> 5) * 256 + (lane & 31);
-      float xa[8], xb[8];
-      gram256_load<W>(base, xa);
+      const float* __restrict__ base = &sh.y[i & 1][0][0] + (lane >> 4) * kYStride + (lane & 15);
+      float xa[8][2], xb[8][2];
+      gram16_load<W>(base, xa);
       for (int kk = 0; kk < nk; kk += 2) {
-        if (kk + 1 < nk) gram256_load<W>(base + (kk + 1) * 512, xb);
+        if (kk + 1 < nk) gram16_load<W>(base + (kk + 1) * 4 * kYStride, xb);
         __builtin_amdgcn_sched_barrier(0);
-        gram256_mfma9<W>(xa, acc);
+        gram16_mfma<W>(xa, acc);
         __builtin_amdgcn_sched_barrier(0);
         if (kk + 1 < nk) {
-          if (kk + 2 < nk) gram256_load<W>(base + (kk + 2) * 512, xa);
+          if (kk + 2 < nk) gram16_load<W>(base + (kk + 2) * 4 * kYStride, xa);
           __builtin_amdgcn_sched_barrier(0);
-          gram256_mfma9<W>(xb, acc);
+          gram16_mfma<W>(xb, acc);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -819,8 +904,24 @@ __device__ __forceinline__ void gram_role(const YArgs& a, const int32_t* __restr
     PH_MARK(5);
     p0 = q0; p1 = q1;
   }
-  PH_FLUSH(W, lane);
-  gram256_flush<W>(scratch, a.H, lane, acc);
+  PH_FLUSH(4 + W, lane);
+  // accumulator layout of 16x16x4: column l & 15, rows 4 (l >> 4) + r
+  const int64_t D = a.H;
+  const int li = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 9; ++s)
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+      for (int hj = 0; hj < 2; ++hj) {
+        if (Tiles256<W>::si[s] == Tiles256<W>::sj[s] && hi > hj) continue;
+        const int64_t jj = Tiles256<W>::sj[s] * 32 + 16 * hj + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t ii = Tiles256<W>::si[s] * 32 + 16 * hi + 4 * lq + r;
+          if (ii < D && jj < D) atomicAdd(&scratch[ii * D + jj], acc[s][hi][hj][r]);
+        }
+      }
 }
 
 // LIST: the node loop runs over a device-side list of the nodes that have a path
@@ -830,7 +931,7 @@ __global__ __launch_bounds__(512, 2) void paths_fused_kernel(YArgs a, const int3
   __shared__ FusedShared sh;  // ONE LDS object
   if (int64_t(pptr[a.N]) > a.cap) return;  // the path list overflowed its buffer: the enumerating route takes over
   // the tiles are zero where nobody writes: columns >= H, the odd row out
-  for (int q = threadIdx.x; q < 2 * kYRows * 256; q += 512) (&sh.y[0][0][0])[q] = 0.f;
+  for (int q = threadIdx.x; q < 2 * kYRows * kYStride; q += 512) (&sh.y[0][0][0])[q] = 0.f;
   for (int q = threadIdx.x; q < kYRows * 256; q += 512) {
     const int row = q >> 8, colq = q & 255;
     sh.w1[row][colq] = (row < a.R && colq < a.H) ? a.W1[int64_t(a.c0 + row) * a.w1_ld + colq] : 0.f;
@@ -844,14 +945,21 @@ __global__ __launch_bounds__(512, 2) void paths_fused_kernel(YArgs a, const int3
   const int64_t stride = gridDim.x;
   const int64_t nn = LIST ? int64_t(__builtin_amdgcn_readfirstlane(*a.n_list)) : a.n1 - a.n0;
   const int64_t cnt = nn > int64_t(blockIdx.x) ? (nn - blockIdx.x + stride - 1) / stride : 0;
-  switch (hw) {
-    case 0: gram_role<0, LIST>(a, pptr, list, sh, cnt, scratch); break;
-    case 1: gram_role<1, LIST>(a, pptr, list, sh, cnt, scratch); break;
-    case 2: gram_role<2, LIST>(a, pptr, list, sh, cnt, scratch); break;
-    case 3: gram_role<3, LIST>(a, pptr, list, sh, cnt, scratch); break;
+  // (which half is which matters: see the kernel's header -- LGNN_FUSED_DEBUG bit 5 swaps them for the A/B run)
+  const int role = (a.debug & 32) ? (hw ^ 4) : hw;
+  switch (role) {
+    case 4: gram_role<0, LIST>(a, pptr, list, sh, cnt, scratch); break;
+    case 5: gram_role<1, LIST>(a, pptr, list, sh, cnt, scratch); break;
+    case 6: gram_role<2, LIST>(a, pptr, list, sh, cnt, scratch); break;
+    case 7: gram_role<3, LIST>(a, pptr, list, sh, cnt, scratch); break;
     default:
-      if (a.no_bg) product_role<LIST, true>(a, pptr, list, sh, cnt, hw - 4);
-      else product_role<LIST, false>(a, pptr, list, sh, cnt, hw - 4);
+      if (a.c0 != a.cb) {  // classes cb + 48 ..: the fourth tile of the coefficient slots
+        if (a.no_bg) product_role<LIST, true, true>(a, pptr, list, sh, cnt, role);
+        else product_role<LIST, false, true>(a, pptr, list, sh, cnt, role);
+      } else {
+        if (a.no_bg) product_role<LIST, true, false>(a, pptr, list, sh, cnt, role);
+        else product_role<LIST, false, false>(a, pptr, list, sh, cnt, role);
+      }
       break;
   }
 }
@@ -971,14 +1079,14 @@ namespace {
 // (u^T [W_1s | W_1n] is one GEMM whose [M][2H] output IS the [2M][H] table in that order).  paths_fused_kernel runs unchanged.
 __global__ __launch_bounds__(256) void sage_path_tables_kernel(const float* __restrict__ probs, const float* __restrict__ logits,
                                                                const int64_t* __restrict__ idx, const int32_t* __restrict__ pos,
-                                                               int64_t M, int64_t N, int C, int cb, int mode,
+                                                               int64_t M, int64_t N, int C, int cb, int ce, int mode,
                                                                float* __restrict__ coef, float* __restrict__ up,
                                                                float* __restrict__ alpha) {
   const int lane = threadIdx.x & 63;
   const int64_t m = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (m >= M + C) return;
   const int c = cb + slot_class(lane);  // the class of slot `lane` (coef_slot order, see path_tables_kernel)
-  const bool have = c < C;
+  const bool have = c < ce;             // (classes outside the call's range: zero coefficients)
   if (m >= M) {  // the one-hot rows
     float* __restrict__ cm = coef + (2 * M + (m - M)) * kCoefRow;
     cm[lane] = 0.f; cm[kCoefStride + lane] = (have && c == int(m - M)) ? 1.f : 0.f; cm[2 * kCoefStride + lane] = 0.f; cm[3 * kCoefStride + lane] = 0.f;
@@ -1175,7 +1283,7 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
   LGNN_CALL(ws.path_up.reserve(size_t(2 * M) * C * 4));
   LGNN_CALL(ws.path_bg.reserve(size_t(2 * M) * H * 4));
   hipLaunchKernelGGL(path_tables_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, ws.probs.as<float>(),
-                     h->fc.out.as<float>(), idx, ws.pos.as<int32_t>(), M, N, int(C), int(cb), seed_mode,
+                     h->fc.out.as<float>(), idx, ws.pos.as<int32_t>(), M, N, int(C), int(cb), int(ce), seed_mode,
                      ws.path_coef.as<float>(), ws.path_up.as<float>());
   LGNN_HIP_CHECK(hipGetLastError());
   const bool no_bg = seed_mode == 2;
@@ -1244,7 +1352,7 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>(); y.zeros = ws.path_zeros.as<float>();
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
     y.W1 = h->W[1]; y.w1_ld = int(H); y.Y = nullptr; y.N = N; y.n0 = nb; y.n1 = ne; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
-    y.cb = int(cb); y.no_bg = no_bg ? 1 : 0; y.debug = fused_debug();
+    y.cb = int(cb); y.n_coef = M; y.no_bg = no_bg ? 1 : 0; y.debug = fused_debug();
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel(s) of the KFAC path (bench.py roofline)
     if (y.list) hipLaunchKernelGGL(paths_fused_kernel<true>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, y.pptr, y.list, scratch);
     else hipLaunchKernelGGL(paths_fused_kernel<false>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, y.pptr, y.list, scratch);
@@ -1267,7 +1375,7 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     y.coef = ws.path_coef.as<float>(); y.bg = ws.path_bg.as<float>(); y.zeros = ws.path_zeros.as<float>();
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
     y.W1 = h->W[1]; y.w1_ld = int(H); y.Y = ws.planes_a.as<float>(); y.N = N; y.n0 = nb; y.n1 = ne; y.M = M; y.H = int(H); y.c0 = int(c0); y.R = int(R);
-    y.cb = int(cb); y.no_bg = no_bg ? 1 : 0;
+    y.cb = int(cb); y.n_coef = M; y.no_bg = no_bg ? 1 : 0;
     const unsigned threads = unsigned(64 * cdiv(H, 64) * cdiv(R, 32));  // (column groups) x (32-class row tiles) waves
     hipLaunchKernelGGL(ybuild_kernel, dim3(unsigned(std::min<int64_t>(ne - nb, 1024))), dim3(threads), 0, s, y);
     LGNN_HIP_CHECK(hipGetLastError());
@@ -1293,7 +1401,7 @@ int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int 
   LGNN_CALL(ws.path_bg.reserve(size_t(2 * T) * H * 4));
   LGNN_CALL(ws.path_alpha.reserve(size_t(M) * kCoefStride * 4));
   hipLaunchKernelGGL(sage_path_tables_kernel, dim3(unsigned(cdiv(M + C, 4))), dim3(256), 0, s, ws.probs.as<float>(),
-                     h->fc.out.as<float>(), idx, ws.pos.as<int32_t>(), M, N, int(C), int(cb), seed_mode,
+                     h->fc.out.as<float>(), idx, ws.pos.as<int32_t>(), M, N, int(C), int(cb), int(ce), seed_mode,
                      ws.path_coef.as<float>(), ws.path_up.as<float>(), ws.path_alpha.as<float>());
   LGNN_HIP_CHECK(hipGetLastError());
   // b rows [0, T): u^T [W_1s | W_1n] as rows (2 m, 2 m + 1), then W_1s[c', :]; g rows [T, 2 T): p^T [W_1s | W_1n], then zeros
@@ -1341,7 +1449,7 @@ int kfac_paths_first_layer_sage(lgnn_ctx* h, const int64_t* idx, int64_t M, int 
     y.mask = h->fc.mask_bits[0].as<uint32_t>(); y.mask_words = int(cdiv(H, 32));
     y.W1 = h->W[1] + H; y.w1_ld = int(2 * H);  // the neighbour half: the alpha term of the neighbour paths
     y.Y = nullptr; y.N = N; y.n0 = nb; y.n1 = ne; y.M = T; y.H = int(H); y.c0 = int(c0); y.R = int(R);
-    y.cb = int(cb); y.no_bg = 0;  // (the one-hot alpha paths go through the beta product: never skipped)
+    y.cb = int(cb); y.n_coef = T; y.no_bg = 0;  // (the one-hot alpha paths go through the beta product: never skipped)
     y.debug = fused_debug();
     if (h->timing) LGNN_CALL(record_event(h, s));  // dominant kernel of the KFAC path (bench.py roofline)
     if (y.list) hipLaunchKernelGGL(paths_fused_kernel<true>, dim3(unsigned(std::min<int64_t>(ne - nb, fused_workgroups()))), dim3(512), 0, s, y, y.pptr, y.list, scratch);
