@@ -767,43 +767,74 @@ class KronLaplace(ParametricLaplace):
             raise ValueError("Prior precision for Kron either scalar or per-layer.")
         return self.H * self._H_factor + pp
 
-    # ---- 8(f)-4: what the GNN driver differentiates (gnn/marglik_training.py:197-216) ------------------------------
-    _FP64_EIG_MAX = 512  # factors up to this size are re-decomposed in fp64 for the adjacency gradient
+    # ---- fp64 eigenpairs of the fitted factors: what divides by (eigenvalue products + prior precision) reads these -----
+    _FP64_EIG_MAX = 512  # factors up to this size are re-decomposed in fp64 (larger ones keep the fit's own eigenpairs)
 
+    def _eigh64(self, block: int, k: int):
+        """(eigenvalues, eigenvectors) in fp64 of factor ``k`` of block ``block`` of the fitted (fp32) factors, cached per fit.
+        The fit's own decomposition is fp32 (hand-written tridiagonalisation + divide and conquer): its eigenvalues carry an
+        ABSOLUTE error of ~1e-6 of the factor's largest one, i.e. the small ones -- which dominate ``1 / (f lB_i lA_j + delta)``
+        -- have no correct digit, and the float atomics of the accumulation make that error differ from run to run.  An fp64
+        decomposition of the same fp32 factor has none of it: what remains is the factors' own last-bit noise (~1e-7).
+        Factors of up to 128 rows on a host core (numpy: 0.1 ms; the device needs 2 ms of launches for a 64 x 64 matrix, and
+        torch's CPU eigh spins up the whole intra-op pool), up to ``_FP64_EIG_MAX`` rows on the device, larger ones (Cora's
+        1 433 x 1 433 X^T X: 40 ms in fp64) keep the fit's pairs."""
+        store = self.__dict__.setdefault("_eig64", {})
+        if store.get("for") is not self.H:  # a new fit / load_state_dict made a new decomposition object
+            store.clear()
+            store["for"] = self.H
+        t = self.H_facs.kfacs[block][k]
+        key = (t.data_ptr(), tuple(t.shape))
+        if key not in store:
+            n = t.shape[0]
+            if n <= 128:
+                import numpy as np
+                lam, Q = np.linalg.eigh(t.double().cpu().numpy())
+                pair = (torch.from_numpy(lam).to(t.device), torch.from_numpy(Q).to(t.device))
+            elif n <= self._FP64_EIG_MAX:
+                pair = torch.linalg.eigh(t.double())
+            else:
+                pair = (self.H.eigenvalues[block][k].double(), self.H.eigenvectors[block][k].double())
+            store[key] = (pair[0].clamp(min=0.0), pair[1])  # (symeig's clamp, laplace/utils/utils.py:193-226)
+        return store[key]
+
+    def _refined_decomposition(self) -> KronDecomposed:
+        """The fit's ``KronDecomposed`` with every factor's eigenpairs replaced by the fp64 ones (rounded to fp32: each
+        eigenvalue then has a RELATIVE error of 6e-8).  What the predictive and the samples invert; the marginal likelihood
+        -- the per-epoch quantity -- keeps the fit's own pairs (its logdet is insensitive: 3.7e-7 measured)."""
+        H = self.H
+        if not isinstance(H, KronDecomposed):
+            return H
+        store = self.__dict__.setdefault("_eig64", {})
+        if store.get("for") is H and "refined" in store:
+            return store["refined"]
+        vals, vecs = [], []
+        for i, ls in enumerate(H.eigenvalues):
+            pairs = [self._eigh64(i, k) for k in range(len(ls))]
+            vals.append([lam.float() for lam, _ in pairs])
+            vecs.append([Q.float() for _, Q in pairs])
+        store["refined"] = KronDecomposed(vecs, vals, H.deltas, H.damping)
+        return store["refined"]
+
+    @property
+    def posterior_precision_refined(self) -> KronDecomposed:
+        pp = torch.as_tensor(self.prior_precision, dtype=torch.float32, device=self._device).reshape(-1)
+        if pp.numel() not in (1, self.n_layers):
+            raise ValueError("Prior precision for Kron either scalar or per-layer.")
+        return self._refined_decomposition() * self._H_factor + pp
+
+    # ---- 8(f)-4: what the GNN driver differentiates (gnn/marglik_training.py:197-216) ------------------------------
     def _logdet_factor_gradients(self):
         """``d logdet(P) / d B_l`` and ``/ d A_l`` per layer (laplace/utils/matrix.py:371-394: ``sum log(f lB_i lA_j + delta)``
         per weight block, ``sum log(f lB_i + delta)`` per bias block, f = H_factor): ``Q diag(.) Q^T`` in the factor's own
-        eigenbasis.  Formed in fp64 from an fp64 eigendecomposition of the fitted (fp32) factors: with the fit's fp32
-        eigenpairs these matrices are off by up to 3e-3 -- the coefficients divide by f lB_i lA_j + delta, where the small
-        eigenvalues carry all of fp32's absolute error -- and that was the adjacency gradient's whole device error (3.3e-4
-        at a GraphSAGE with 256 hidden units, 4.4e-6 with this; tools/adjgrad_attribution.py,
-        profiles/r03_adjgrad_attribution.log).  Once per gradient, on factors of a few hundred rows: not a hot path."""
+        eigenbasis, formed in fp64 from the fp64 eigenpairs (``_eigh64``): with the fit's fp32 pairs these matrices are off
+        by up to 3e-3, and that was the adjacency gradient's whole device error (3.3e-4 at a GraphSAGE with 256 hidden units,
+        4.4e-6 with this; tools/adjgrad_attribution.py, profiles/r03_adjgrad_attribution.log)."""
         f = float(self._H_factor)
         pp = torch.as_tensor(self.prior_precision, dtype=torch.float64, device=self._device).reshape(-1)
         deltas = pp.expand(self.n_layers) if pp.numel() == 1 else pp
         kf = self.H_facs.kfacs
-        eig = {}  # the bias block's factor is its weight block's B: decompose it once
-
-        def eigh64(block, k):
-            t = kf[block][k]
-            key = (t.data_ptr(), tuple(t.shape))
-            if key not in eig:
-                if t.shape[0] <= 128:
-                    # small factors on the host: an fp64 eigh of a 64 x 64 matrix is ~2 ms of launches on the device and
-                    # ~0.1 ms on a core (the Cora-shaped gradient is a 1 ms call)
-                    # (numpy: torch's CPU eigh spins up the whole intra-op thread pool -- 100 ms on a 128-core host)
-                    import numpy as np
-                    lam, Q = np.linalg.eigh(t.double().cpu().numpy())
-                    eig[key] = (torch.from_numpy(lam).to(t.device), torch.from_numpy(Q).to(t.device))
-                elif t.shape[0] <= self._FP64_EIG_MAX:
-                    eig[key] = torch.linalg.eigh(t.double())
-                else:
-                    # a large input covariance (Cora's 1 433 x 1 433 X^T X: 40 ms in fp64 on a 1 ms call): the fit's own
-                    # eigenpairs.  Its eigenvalues enter the other factors' coefficients only through f lA_j / (f lB_i lA_j
-                    # + delta), which is insensitive to the small ones; its own gradient matrix is read by the GraphSAGE
-                    # adjoint only (a GCN's first input covariance does not depend on the adjacency)
-                    eig[key] = (self.H.eigenvalues[block][k].double(), self.H.eigenvectors[block][k].double())
-            return eig[key]
+        eigh64 = self._eigh64
 
         gB, gA = [], []
         for l in range(len(kf) // 2):
@@ -835,7 +866,7 @@ class KronLaplace(ParametricLaplace):
         if self.likelihood != "classification":
             raise NotImplementedError("adjacency gradient: classification likelihood")
         eng = self.backend.engine
-        value = -self.log_marginal_likelihood()
+        value = -self._log_marginal_likelihood64()
         gB, gA = self._logdet_factor_gradients()
         gB = [0.5 * g for g in gB]  # neg marglik = H_factor * loss + 1/2 (logdet P - logdet P_0 + scatter)
         gA = [0.5 * g for g in gA]
@@ -866,8 +897,31 @@ class KronLaplace(ParametricLaplace):
     def log_det_posterior_precision(self) -> torch.Tensor:
         return self.posterior_precision.logdet()
 
+    def _log_marginal_likelihood64(self) -> torch.Tensor:
+        """``log_marginal_likelihood()`` with the log determinant summed in fp64 over the fp64 eigenvalues (the structure-
+        learning step needs them for its gradient anyway): fp32 value within 1e-6 of the fp64 oracle where the fit's own
+        pairs left 5.7e-5 on one configuration of 420 (seed 346 of tools/stress_adjgrad.py, H = 256: a near-singular B_0
+        whose ~200 smallest eigenvalues each carried the fp32 decomposition's absolute error into log(f lB lA + delta))."""
+        if self.damping:
+            return self.log_marginal_likelihood()
+        f = float(self._H_factor)
+        pp = torch.as_tensor(self.prior_precision, dtype=torch.float64, device=self._device).reshape(-1)
+        deltas = pp.expand(self.n_layers) if pp.numel() == 1 else pp
+        ld = torch.zeros((), dtype=torch.float64, device=self._device)
+        for i, F in enumerate(self.H_facs.kfacs):
+            l0 = self._eigh64(i, 0)[0]
+            if len(F) == 1:
+                ld = ld + torch.log(f * l0 + deltas[i]).sum()
+            else:
+                ld = ld + torch.log(f * torch.outer(l0, self._eigh64(i, 1)[0]) + deltas[i]).sum()
+        ld_prior = self.prior_precision_diag.double().log().sum()
+        mean = self.mean.double()
+        delta = mean - torch.as_tensor(self.prior_mean, device=mean.device, dtype=mean.dtype)
+        scatter = (delta * self.prior_precision_diag.double()) @ delta
+        return (self.log_likelihood - 0.5 * (ld - ld_prior + scatter)).float()
+
     def _matrix_free_operands(self, out_map=None):
-        H = self.H
+        H = self._refined_decomposition()
         if not isinstance(H, KronDecomposed) or H.damping or len(H.eigenvalues) != 4:
             return None
         (lB0, lA0), (QB0, QA0) = H.eigenvalues[0], H.eigenvectors[0]
@@ -888,10 +942,10 @@ class KronLaplace(ParametricLaplace):
         return dict(S0=S0, S1=S1, kappa=kappa, QA0=QA0, QB0=QB0, QA1=QA1, QB1sq=QB1 * QB1)
 
     def _scale_samples(self, eps):  # laplace/baselaplace.py:1646-1655
-        return self.posterior_precision.bmm(eps, exponent=-0.5).reshape(eps.shape[0], self.n_params)
+        return self.posterior_precision_refined.bmm(eps, exponent=-0.5).reshape(eps.shape[0], self.n_params)
 
-    def functional_variance(self, Js):  # laplace/baselaplace.py:1635-1636
-        return self.posterior_precision.inv_square_form(Js)
+    def functional_variance(self, Js):  # laplace/baselaplace.py:1635-1636 (fp64 eigenpairs: see _eigh64)
+        return self.posterior_precision_refined.inv_square_form(Js)
 
 
 class DiagLaplace(ParametricLaplace):
@@ -1086,7 +1140,7 @@ class FullLLLaplace(ParametricLaplace):
         return self.posterior_precision.logdet()
 
     def functional_variance(self, Js):  # laplace/lllaplace.py via FullLaplace.functional_variance (baselaplace.py:1488-1489)
-        cov = torch.linalg.inv(self.posterior_precision)
+        cov = torch.linalg.inv(self.posterior_precision.double()).float()  # (fp64 inverse: see FullLaplace.posterior_scale)
         return torch.einsum("ncp,pq,nkq->nck", Js, cov, Js)
 
 
@@ -1112,9 +1166,10 @@ class FullLaplace(ParametricLaplace):
 
     @property
     def posterior_scale(self) -> torch.Tensor:
-        """``P^-1/2`` as a lower-triangular factor (laplace/utils/utils.py:118-129)."""
+        """``P^-1/2`` as a lower-triangular factor (laplace/utils/utils.py:118-129).  Factorised in fp64 (P x P of a small
+        model): the fp32 Cholesky of a GGN with near-zero directions lost three digits of the functional variance."""
         from torch.distributions.multivariate_normal import _precision_to_scale_tril
-        return _precision_to_scale_tril(self.posterior_precision)
+        return _precision_to_scale_tril(self.posterior_precision.double()).float()
 
     @property
     def posterior_covariance(self) -> torch.Tensor:

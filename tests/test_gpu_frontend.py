@@ -166,9 +166,12 @@ def test_jacobians_and_glm_predictive(path):
         la.fit(loader)
         f_mu, f_var = la._glm_predictive_distribution(idx)
         assert rel(f_mu.cpu().numpy(), g[structure + "_glm_fmu"]) < RTOL
-        # (J P^-1 J^T amplifies the factors' run-to-run last-bit differences -- float atomics -- through the small eigenvalues:
-        #  8e-7 ... 2e-4 observed over repeated runs of the same fixture)
-        assert rel(f_var.cpu().numpy(), g[structure + "_glm_fvar"]) < 5e-4
+        # (J P^-1 J^T divides by eigenvalue products + prior precision: inverted from fp64 eigenpairs of the fitted factors,
+        #  KronLaplace._eigh64 -- with the fit's fp32 pairs the small eigenvalues' absolute error, different from run to run
+        #  through the accumulation's float atomics, gave 8e-7 ... 2e-4 on the same fixture; now 3e-7 ... 2.4e-5 over 24 refits of
+        #  the worst fixture, <= 4e-6 on every other one (profiles/r04_tolerance_survey.log).  What is left is the problem's own
+        #  conditioning: the factors' last bits, ~1e-7 of their norm, times ||P^-1|| ||H|| ~ 2e2 at that fixture.)
+        assert rel(f_var.cpu().numpy(), g[structure + "_glm_fvar"]) < 1e-4
         assert np.abs(la(idx).cpu().numpy() - g[structure + "_glm_probit"]).max() < 5e-5
         for link in ("bridge", "bridge_norm"):
             got = la(idx, pred_type="glm", link_approx=link).cpu().numpy()
@@ -204,7 +207,7 @@ def test_full_laplace_all_weights(name):
     eps, idx = torch.from_numpy(g["pred_eps"]).cuda(), torch.from_numpy(g["pred_idx"]).cuda()
     assert rel(la.sample(eps=eps).cpu().numpy(), g["fullla_samples"]) < 1e-4
     _, f_var = la._glm_predictive_distribution(idx)
-    assert rel(f_var.cpu().numpy(), g["fullla_glm_fvar"]) < 5e-4
+    assert rel(f_var.cpu().numpy(), g["fullla_glm_fvar"]) < 1e-4
     assert np.abs(la(idx).cpu().numpy() - g["fullla_glm_probit"]).max() < 1e-4
     la3 = lg.FullLaplace(model, "classification")
     la3.fit(lg.TensorBatchLoader(idx_all, y_all, batch_size=max(1, len(idx_all) // 3 + 1)))
@@ -230,7 +233,7 @@ def test_regression_likelihood(name):
     assert abs(float(la.loss) - float(g["reg_kron_loss"])) < RTOL * float(g["reg_kron_loss"])
     assert abs(float(la.log_marginal_likelihood()) - float(g["reg_kron_marglik"])) < 3e-4 * abs(float(g["reg_kron_marglik"]))
     f_mu, f_var = la(torch.from_numpy(g["pred_idx"]).cuda(), pred_type="glm")
-    assert rel(f_mu.cpu().numpy(), g["reg_kron_glm_fmu"]) < RTOL and rel(f_var.cpu().numpy(), g["reg_kron_glm_fvar"]) < 5e-4
+    assert rel(f_mu.cpu().numpy(), g["reg_kron_glm_fmu"]) < RTOL and rel(f_var.cpu().numpy(), g["reg_kron_glm_fvar"]) < 5e-5
     # unfused kernels and a three-batch fit give the same factors
     be = lg.HipGGN(model, "regression")
     _, views, loss = be.engine.new_kfac_buffers()
@@ -573,10 +576,10 @@ def test_full_predictive_covariance_without_jacobians(name, monkeypatch):
         la.fit(loader)
         f_mu, f_var = la._glm_covariance_matrix_free(x, budget_floats=20_000)  # a few evaluation nodes per chunk
         assert rel(f_mu.cpu().numpy(), g[key + "_glm_fmu"]) < 1e-5
-        # against this fit's own Jacobian route (same factors) and the reference's golden (whose distance also holds the factors'
-        # run-to-run last bits amplified through the small eigenvalues: 5e-4 as in test_frontend_golden)
+        # against this fit's own Jacobian route (same factors) and the reference's golden (polarised off-diagonals carry the
+        # rounding of three variances: 1e-4)
         assert rel(f_var.cpu().numpy(), la._glm_predictive_distribution(x)[1].cpu().numpy()) < 1e-4, key
-        assert rel(f_var.cpu().numpy(), g[key + "_glm_fvar"]) < 5e-4, key
+        assert rel(f_var.cpu().numpy(), g[key + "_glm_fvar"]) < 1e-4, key
         assert float((f_var - f_var.transpose(1, 2)).abs().max()) == 0.0
         monkeypatch.setattr(type(la), "_JACOBIAN_BYTES_MAX", 0)  # every call counts as "too large for Jacobians"
         mc = la(x, link_approx="mc", n_samples=eps.shape[1], eps=eps)

@@ -51,7 +51,9 @@ for seed in range(first, last):
         e_c = rel(gc.cpu().numpy()[keep], ref_c) if keep.any() else 0.0
         e_g = rel(np.concatenate([grad.cpu().numpy(), gc.cpu().numpy()[keep]]), np.concatenate([og, ref_c]))
         model.engine.check_async_errors()
-        if not (e_val < 1e-4 and e_g < 2e-4 and e_c < 2e-4):  # fp32 value (log determinants of H x F terms): up to 5.7e-5 seen at H = 256
+        # (the value: log determinant summed in fp64 over fp64 eigenvalues since round 4 -- KronLaplace._log_marginal_likelihood64;
+        #  with the fit's fp32 pairs seed 346 had 5.7e-5)
+        if not (e_val < 1e-5 and e_g < 2e-4 and e_c < 2e-4):
             bad.append((seed, kind, N, F, H, C, E, M, bs, sym, fe, e_val, e_g, e_c))
             print("MISMATCH", bad[-1], flush=True)
         if kind == "gcn":  # the diagonal posterior's gradient (lgnn_diag_adjgrad_batch / _finish)
