@@ -690,11 +690,205 @@ __global__ __launch_bounds__(256) void diag_first_layer_mfma_kernel(
     }
 }
 
+// ---- GCN, wide inputs (Cora: F = 1 433): the same per-sample outer products, output tiles owned ------------------------------
+// Round 3's kernel above cut the samples into 42 slabs and every workgroup flushed its [64 x 256] partial tile with float
+// atomics: 35.9 MB through the fabric for a 0.37 MB result (97 x), E re-fetched by whichever XCD a workgroup landed on, and a
+// per-workgroup latency chain (32 samples) that left the matrix pipes 12 % busy.  Here
+//   * a workgroup (4 waves, one per SIMD) owns 192 columns x 64 hidden units for a LONG slab of samples (Cora: 8 column blocks x
+//     32 slabs of 41 samples); wave (jh, ch) holds a 32 x 96 tile of T and of the running sum (3 + 3 accumulator tiles: one
+//     A operand read feeds three MFMAs);
+//   * blockIdx.x = column block + ncb * slab: with 8 column blocks the workgroups of a column block share an XCD (blocks are
+//     dealt round-robin: speed only), so an XCD's L2 holds exactly its 192-column slice of E (2 MB) -- E crosses the fabric once;
+//   * ONE 16-byte-per-lane LDS-DMA copy stages an entry: lanes 0 .. 47 its 192 columns of E, lanes 48 .. 63 the 64 act' values;
+//   * sqrt(q) rides on the A operand (q = w^T Lambda w >= 0), so folding a finished sample is one FMA per accumulator register,
+//     acc += T'^2 -- the fp32 MFMAs and the VALU share the SIMD's ALUs, every saved vector instruction is matrix time;
+//   * the slab's partial tile goes to a workspace with PLAIN stores, every element written exactly once;
+//     diag_tile_reduce_kernel adds the slabs up in a fixed order: no atomics, deterministic, 16 x 0.37 MB written.
+constexpr int kTileCols = 192;
+constexpr int kTileDch = 12;    // entries per ring chunk (two copies per wave)
+constexpr int kTileNbuf = 4;
+constexpr int kTileSlabMax = 96;
+constexpr int kTileMaxE = 768;  // entries resolved per pass
+
+__global__ __launch_bounds__(256) void diag_first_layer_tile_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    const int64_t* __restrict__ idx, int64_t M, int64_t slab, int ncb, const float* __restrict__ E, int64_t ldE, int64_t F,
+    int64_t N, const float* __restrict__ dact, int64_t H, const float* __restrict__ q, float* __restrict__ part,
+    int64_t part_ld) {
+  constexpr int DCH = kTileDch, NBUF = kTileNbuf, ROW = 256, BUF = DCH * ROW, NI = DCH / 4, NP = DCH / 2, MAXE = kTileMaxE;
+  constexpr int SM = kTileSlabMax;
+  static_assert((NBUF - 2) * NI <= 63 && DCH % 4 == 0 && MAXE % DCH == 0, "ring");
+  // ONE LDS object: ring | sqrt(q) rows of the slab [SM][64] | entries {column, weight, pair record} | slab tables
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF + SM * 64 + 3 * MAXE + (SM + 1) + 3 * SM];
+  float* __restrict__ ring = smem;
+  float* __restrict__ sq = smem + NBUF * BUF;
+  int32_t* __restrict__ sv = reinterpret_cast<int32_t*>(sq + SM * 64);
+  float* __restrict__ sa = sq + SM * 64 + MAXE;
+  // record of the K step that starts at an even entry: sample | 256 (first step of its sample) | 512 (last); -1 past the end
+  int32_t* __restrict__ sflag = reinterpret_cast<int32_t*>(sa + MAXE);
+  int32_t* __restrict__ soff = sflag + MAXE;  // padded (even) entry offsets of the samples
+  int32_t* __restrict__ snode = soff + SM + 1;
+  int32_t* __restrict__ sbase = snode + SM;
+  int32_t* __restrict__ slen = sbase + SM;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jh = wave >> 1, ch = wave & 1;  // hidden half, column half (96 columns = three 32-column MFMA tiles)
+  const int cb = int(blockIdx.x) % ncb, slab_i = int(blockIdx.x) / ncb;
+  const int64_t cblk = int64_t(cb) * kTileCols;
+  const int64_t j0 = int64_t(blockIdx.y) * 64;
+  const int64_t m_begin = int64_t(slab_i) * slab, m_end = min(M, m_begin + slab);
+  const int ns = int(m_end - m_begin);  // <= SM
+  if (tid < 64) {  // exclusive prefix sums of the padded row lengths, two samples per lane (SM <= 128)
+    int32_t len2[2], incl = 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int sidx = 2 * tid + u;
+      int32_t len = 0, node = -1, base = 0;
+      if (sidx < ns) {
+        const int64_t n = idx[m_begin + sidx];
+        if (n >= 0 && n < N) { node = int32_t(n); base = rowptr[n]; len = rowptr[n + 1] - base; }
+      }
+      if (sidx < SM) { snode[sidx] = node; sbase[sidx] = base; slen[sidx] = len; }
+      len2[u] = (len + 1) & ~1;
+      incl += len2[u];
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (2 * tid + 1 <= SM) soff[2 * tid + 1] = incl - len2[1];
+    if (2 * tid + 2 <= SM) soff[2 * tid + 2] = incl;
+    if (tid == 0) soff[0] = 0;
+  }
+  for (int f = tid; f < SM * 64; f += 256) {  // sqrt(q) rows of the slab's samples (zero past the slab / past H)
+    const int sidx = f >> 6, j = f & 63;
+    sq[f] = (sidx < ns && j0 + j < H) ? sqrtf(fmaxf(q[(m_begin + sidx) * H + j0 + j], 0.f)) : 0.f;
+  }
+  __syncthreads();
+  const int32_t etot = soff[min(ns, SM)];
+  f32x16 T[3], acc[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { T[b][r] = 0.f; acc[b][r] = 0.f; }
+  // DMA source of this lane: lanes 0 .. 47 four columns of E, lanes 48 .. 63 four hidden units of act'
+  const bool is_e = lane < 48;
+  const int64_t ecol = cblk + 4 * lane, dcol = j0 + 4 * (lane - 48);
+  const bool src_ok = is_e ? ecol < ldE : dcol < H;
+  const float* __restrict__ src0 = is_e ? E + ecol : dact + dcol;
+  const int64_t src_ld = is_e ? ldE : H;
+
+  for (int32_t sb0 = 0; sb0 < etot; sb0 += MAXE) {
+    const int ne = min(MAXE, int(etot - sb0));  // even
+    const int nch = (ne + DCH - 1) / DCH;
+    for (int e = tid; e < nch * DCH; e += 256) {  // every entry of this pass: sample by bisection, then column / value
+      const int32_t g = sb0 + e;
+      int32_t v = 0, fl = -1;
+      float a = 0.f;
+      if (e < ne) {
+        int lo = 0, hi = ns;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (soff[mid] <= g) lo = mid; else hi = mid; }
+        const int32_t r = g - soff[lo], len = slen[lo];
+        v = max(snode[lo], 0);  // (the padding entry of an odd row: weight 0)
+        if (r < len) { const int32_t p = sbase[lo] + r; v = col[p]; a = val[p]; }
+        fl = lo | (r == 0 ? 256 : 0) | (r + 2 >= len ? 512 : 0);
+      }
+      sv[e] = v; sa[e] = a; sflag[e] = fl;
+    }
+    __syncthreads();
+    auto issue = [&](int c) {  // chunk c -> ring slot c % NBUF; wave w copies the rows of entries w, w + 4, w + 8
+      float* __restrict__ slot = ring + (c % NBUF) * BUF;
+#pragma unroll
+      for (int k = 0; k < DCH / 4; ++k) {
+        const int el = wave + 4 * k, e = c * DCH + el;
+        const int64_t v = sv[e];
+        lds_dma16((e < ne && src_ok) ? src0 + v * src_ld : g_diag_zero16, slot + el * ROW);
+      }
+    };
+    for (int c = 0; c < NBUF - 1 && c < nch; ++c) issue(c);
+    for (int c = 0; c < nch; ++c) {
+      wait_chunks<NI, NBUF - 2>(min(NBUF - 2, nch - 1 - c));  // chunks after c whose copies are in flight
+      asm volatile("s_barrier" ::: "memory");  // chunk c has landed for all waves; chunk c - 1 is consumed
+      if (c + NBUF - 1 < nch) issue(c + NBUF - 1);
+      const float* __restrict__ slot = ring + (c % NBUF) * BUF + lhi * ROW;  // this lane's K index: entry 2 p + lhi
+      float A[NP], B0[NP], B1[NP], B2[NP];
+      int fl[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const float* __restrict__ row = slot + 2 * p * ROW;
+        fl[p] = __builtin_amdgcn_readfirstlane(sflag[c * DCH + 2 * p]);
+        const float sqv = sq[(max(fl[p], 0) & 255) * 64 + 32 * jh + l31];
+        A[p] = sa[c * DCH + 2 * p + lhi] * sqv * row[kTileCols + 32 * jh + l31];
+        B0[p] = row[ch * 96 + l31]; B1[p] = row[ch * 96 + 32 + l31]; B2[p] = row[ch * 96 + 64 + l31];
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        // (steps past the last entry carry weight 0: they add nothing and need no branch)
+        T[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[p], B0[p], T[0], 0, 0, 0);
+        T[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[p], B1[p], T[1], 0, 0, 0);
+        T[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[p], B2[p], T[2], 0, 0, 0);
+        if (fl[p] >= 0 && (fl[p] & 512)) {  // the sample is complete: acc += (sqrt(q_j) T[j, i])^2, T = 0 for the next one
+          // A REAL branch (the empty statement keeps hipcc from if-converting it): left to itself it folds on EVERY K step
+          // behind 32 v_cndmask and picks the first step's zero accumulator with 32 more -- ~100 vector instructions per
+          // K step on the ALUs the fp32 MFMAs run on, which is what round 3's kernel spent its 67 us on.
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[b][r] = fmaf(T[b][r], T[b][r], acc[b][r]); T[b][r] = 0.f; }
+        }
+      }
+    }
+    __syncthreads();  // the next pass overwrites the entry table and the ring
+  }
+  // the slab's partial tile: accumulator register r of tile b is (hidden j0 + 32 jh + 8 (r >> 2) + 4 lhi + (r & 3), column + 32 b + l31)
+  float* __restrict__ pt = part + int64_t(slab_i) * H * part_ld;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const int64_t i = cblk + ch * 96 + b * 32 + l31;
+    if (i > F) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t j = j0 + 32 * jh + 8 * (r >> 2) + 4 * lhi + (r & 3);
+      if (j < H) pt[j * part_ld + i] = acc[b][r];
+    }
+  }
+}
+// diag(W_0)[j, i] += sum_slabs part[slab][j][i] (i < F), diag(b_0)[j] += ... (i == F): a fixed summation order.  Thread t of
+// linear block `blk` owns four consecutive columns of one hidden unit (part_ld % 4 == 0: 16-byte reads).  Runs as extra
+// z-slices of the last-layer launch (TileReduce below): no launch of its own, and it overlaps that latency-bound kernel.
+struct TileReduce {
+  const float* part; int64_t part_ld; int nslab; int64_t H, F; float* diag_w; float* diag_b;
+  int z0;  // first z-slice of the launch that reduces (z0 < 0: nothing to reduce)
+};
+__device__ __forceinline__ void diag_tile_reduce(const TileReduce& a, int64_t blk) {
+  const int64_t q4 = (a.F + 4) / 4;  // groups of four columns covering 0 .. F
+  const int64_t t = blk * 256 + threadIdx.x;
+  if (t >= a.H * q4) return;
+  const int64_t j = t / q4, i = 4 * (t - j * q4);
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < a.nslab; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(a.part + (int64_t(s) * a.H + j) * a.part_ld + i);
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  }
+  const float e[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (i + u < a.F) a.diag_w[j * a.F + i + u] += e[u];
+    else if (i + u == a.F) a.diag_b[j] += e[u];
+  }
+}
+
 // grid (i-chunks of 256, C, slabs): diag(W)[k,i] += sum_n wgt[n,k] phi[n,i]^2 ; bias with s_n.
 // wgt = p_k (1 - p_k) from the probabilities (GGN), or the caller's [M, C] array (empirical Fisher: scale * r_k^2)
 __global__ void diag_last_layer_kernel(const float* __restrict__ probs, const int64_t* __restrict__ idx, int64_t M,
                                        int64_t C, int64_t slab, FeatView Phi, float* __restrict__ diag_w,
-                                       float* __restrict__ diag_b, const float* __restrict__ wgt = nullptr) {
+                                       float* __restrict__ diag_b, const float* __restrict__ wgt, TileReduce red) {
+  if (red.z0 >= 0 && int(blockIdx.z) >= red.z0) {  // the first layer's partial tiles (diag_first_layer_tile_kernel)
+    diag_tile_reduce(red, blockIdx.x + int64_t(gridDim.x) * (blockIdx.y + int64_t(gridDim.y) * (blockIdx.z - red.z0)));
+    return;
+  }
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t k = blockIdx.y;
   if (i > Phi.width) return;
@@ -950,6 +1144,7 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
   const unsigned nslab = unsigned(cdiv(M, slab));
 
   int64_t off = 0;
+  TileReduce red{nullptr, 0, 0, 0, 0, nullptr, nullptr, -1};
   {
     const int64_t H = L == 2 ? h->dims[1] : 0, in0 = h->in_dim[0];
     const int has_self = h->kind == LGNN_KIND_SAGE ? 1 : 0;
@@ -988,8 +1183,28 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
           hipLaunchKernelGGL((diag_first_layer_dma_kernel<0, 16, 4>), grid, dim3(256), 0, s, h->P.rowptr, h->P.col, h->P.val,
                              idx, M, slab, E, h->fc.dact0.as<float>(), H, q, diag_out, diag_out + H * in0);
       } else {
-        // GCN: the matrix-core kernel; E = [P X | rowsum(P) | 0] is one padded matrix (context.hip build_px)
+        // GCN: the matrix-core kernels; E = [P X | rowsum(P) | 0] is one padded matrix (context.hip build_px)
         LGNN_REQUIRE(E.ld >= E.width + 1 && E.ld % 4 == 0, "internal: P X without its bias column");
+        const int64_t ncb = cdiv(E.width + 1, kTileCols);
+        if (ncb >= 4 && H % 4 == 0 && getenv("LGNN_DIAG_ATOMIC") == nullptr) {
+          // wide inputs: owned output tiles, long slabs, plain-store partials + a fixed-order reduction (no atomics)
+          const int64_t gyt = cdiv(H, 64);
+          int64_t nsl = std::max<int64_t>(1, std::min<int64_t>(cdiv(256, ncb * gyt), cdiv(M, 16)));  // ~ one workgroup per CU
+          int64_t sl = std::min<int64_t>(kTileSlabMax, cdiv(M, nsl));
+          if (const char* e = getenv("LGNN_DIAG_SLAB")) sl = std::max<int64_t>(1, std::min<int64_t>(kTileSlabMax, atoll(e)));
+          nsl = cdiv(M, sl);
+          const int64_t part_ld = ncb * kTileCols;
+          LGNN_CALL(h->ws.jac.reserve(size_t(nsl) * H * part_ld * 4));
+          float* part = h->ws.jac.as<float>();
+          hipLaunchKernelGGL(diag_first_layer_tile_kernel, dim3(unsigned(ncb * nsl), unsigned(gyt)), dim3(256), 0, s,
+                             h->P.rowptr, h->P.col, h->P.val, idx, M, sl, int(ncb), E.base, E.ld, E.width, h->N,
+                             h->fc.dact0.as<float>(), H, q, part, part_ld);
+          LGNN_HIP_CHECK(hipGetLastError());
+          if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += M; }
+          red = TileReduce{part, part_ld, int(nsl), H, E.width, diag_out, diag_out + H * in0, 0};
+          off = H * in0 + H;
+          goto first_layer_done;
+        }
         const unsigned gx = unsigned(cdiv(E.width + 1, 256)), gy = unsigned(cdiv(H, 64));
         int64_t sl = std::max<int64_t>(4, std::min<int64_t>(64, cdiv(M * gx * gy, 512)));
         if (const char* e = getenv("LGNN_DIAG_SLAB")) sl = std::max<int64_t>(1, std::min<int64_t>(64, atoll(e)));
@@ -1002,11 +1217,17 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
       off = H * in0 + H;
     }
   }
+first_layer_done:
   {
     FeatView Phi;
     feat_views(h, L - 1, Phi);
     const int64_t slab_last = slab;
-    const dim3 grid{unsigned(cdiv(Phi.width + 1, 256)), unsigned(C), unsigned(cdiv(M, slab_last))};
+    dim3 grid{unsigned(cdiv(Phi.width + 1, 256)), unsigned(C), unsigned(cdiv(M, slab_last))};
+    if (red.z0 >= 0) {  // the tile kernel's partials are added up by extra z-slices of this launch
+      red.z0 = int(grid.z);
+      const int64_t blocks = cdiv(red.H * ((red.F + 4) / 4), 256);
+      grid.z += unsigned(cdiv(blocks, int64_t(grid.x) * grid.y));
+    }
     const float* wgt = nullptr;
     if (regression) {
       const int64_t Hq = L == 2 ? h->dims[1] : 0;
@@ -1016,7 +1237,7 @@ int diag_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, u
       wgt = ones;
     }
     hipLaunchKernelGGL(diag_last_layer_kernel, grid, dim3(256), 0, s, h->ws.probs.as<float>(), idx, M, C, slab_last, Phi,
-                       diag_out + off, diag_out + off + C * Phi.width, wgt);
+                       diag_out + off, diag_out + off + C * Phi.width, wgt, red);
     LGNN_HIP_CHECK(hipGetLastError());
   }
   if (!light) LGNN_CALL(batch_epilogue(h, idx, M, s));
@@ -1118,7 +1339,8 @@ int ef_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y_seed, const voi
     FeatView Phi;
     feat_views(h, L - 1, Phi);
     hipLaunchKernelGGL(diag_last_layer_kernel, dim3(unsigned(cdiv(Phi.width + 1, 256)), unsigned(C), nslab), dim3(256), 0, s,
-                       h->ws.probs.as<float>(), idx, M, C, slab, Phi, diag_out + off, diag_out + off + C * Phi.width, wl);
+                       h->ws.probs.as<float>(), idx, M, C, slab, Phi, diag_out + off, diag_out + off + C * Phi.width, wl,
+                       TileReduce{nullptr, 0, 0, 0, 0, nullptr, nullptr, -1});
     LGNN_HIP_CHECK(hipGetLastError());
     LGNN_CALL(batch_epilogue(h, idx, M, s));
     return 0;
