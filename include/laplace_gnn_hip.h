@@ -113,6 +113,17 @@ LGNN_API int lgnn_export_adj(const lgnn_ctx* h, int64_t* rows, int64_t* cols, vo
 /* gnn/utils.py:333-336 adj_to_edge_index: diagonal dropped, row-major, int64 [2,E'].
  * Call with edge_index_out = NULL to get E' in *num_out (host); then again with a buffer. */
 LGNN_API int lgnn_adj_to_edge_index(const lgnn_ctx* h, int64_t* edge_index_out, int64_t* num_out, void* stream);
+/* Apply a structure-learning step to the stored 0/1 adjacency in place: `num_flips` pairs (rows[k], cols[k]) (device, int64)
+ * and the state each shall have afterwards (device uint8: 1 = stored, 0 = absent).  What the reference does by writing its
+ * dense `adj` parameter (`adj_optimizer.step()`, gnn/marglik_training.py:211-221) and re-thresholding it on the next forward
+ * (`BinarizeSTE` + `fill_diagonal_(1)` + `normalize_adj`, gnn/models/models.py:103-116, gnn/models/utils.py:42-112): here the
+ * caller (laplace_gnn_amd.models.STEGCN) thresholds its continuous values and hands over the entries that changed side.
+ * Diagonal pairs are ignored (a GCN's self loops are overwritten ones, GraphSAGE's zeros); a pair listed twice or an id out of
+ * range is an error.  No re-ingest: the flips are sorted and merged into both CSRs, degrees and the values of the propagation
+ * matrices are recomputed, everything cached from the graph (forward pass, P X, long-row lists) is dropped; what depends on
+ * the features only survives.  Synchronises the stream (the new entry count has to reach the host).                       */
+LGNN_API int lgnn_update_adjacency(lgnn_ctx* h, const int64_t* rows, const int64_t* cols, const uint8_t* state,
+                                   int64_t num_flips, void* stream);
 /* Export the propagation matrix the convs multiply with (A_hat or A_bar) as COO in row-major
  * order: rows,cols int64 [nnz], vals fp32 [nnz].                                            */
 LGNN_API int lgnn_export_propagation(const lgnn_ctx* h, int64_t* rows, int64_t* cols, float* vals, void* stream);

@@ -12,8 +12,8 @@ from .engine import GraphEngine  # noqa: F401
 from .laplace import (BaseLaplace, DiagLaplace, FullLaplace, FullLLLaplace, KronLaplace, Laplace,  # noqa: F401
                       ParametricLaplace, all_reduce_flat_)
 from .matrix import Kron, KronDecomposed, symeig  # noqa: F401
-from .models import GCN, GraphSAGE  # noqa: F401
+from .models import GCN, STEGCN, GraphSAGE  # noqa: F401
 
 __all__ = ["GraphEngine", "HipGGN", "HipEF", "HipCurvatureInterface", "Laplace", "BaseLaplace", "ParametricLaplace",
-           "KronLaplace", "DiagLaplace", "FullLaplace", "FullLLLaplace", "Kron", "KronDecomposed", "symeig", "GCN", "GraphSAGE",
+           "KronLaplace", "DiagLaplace", "FullLaplace", "FullLLLaplace", "Kron", "KronDecomposed", "symeig", "GCN", "STEGCN", "GraphSAGE",
            "TensorBatchLoader", "batches_of_rank", "units_of_rank", "all_reduce_flat_"]

@@ -31,6 +31,7 @@ SIGNATURES = {
     "lgnn_num_long_rows": (_i64, [_vp]),
     "lgnn_kfac_last_route": (_i32, [_vp]),
     "lgnn_export_adj": (_i32, [_vp, _vp, _vp, _vp]),
+    "lgnn_update_adjacency": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "lgnn_adj_to_edge_index": (_i32, [_vp, _vp, C.POINTER(_i64), _vp]),
     "lgnn_export_propagation": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "lgnn_bind_model": (_i32, [_vp, _i32, C.POINTER(_i64), _pp, _pp, _vp, _i32, _i32]),

@@ -263,6 +263,8 @@ int exclusive_scan_i32(int32_t* in, int32_t* out, int64_t n, DevBuf& tmp, hipStr
 
 // ---- graph.hip -----------------------------------------------------------------------
 int graph_build(lgnn_ctx* h, const int64_t* edge_index, int64_t E, hipStream_t s);
+int graph_values(lgnn_ctx* h, bool same, hipStream_t s);
+int graph_update(lgnn_ctx* h, const int64_t* fi, const int64_t* fj, const uint8_t* st, int64_t K, hipStream_t s);
 
 // ---- kernels (launchers) -------------------------------------------------------------
 // out[r, 0:width) = sum_j val[j] * in[col[j], 0:width)   for r in [0, nrows)

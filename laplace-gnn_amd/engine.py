@@ -143,6 +143,22 @@ class GraphEngine:
                        "lgnn_adj_to_edge_index")
         return out
 
+    def update_adjacency(self, rows: torch.Tensor, cols: torch.Tensor, state: torch.Tensor):
+        """Edit the stored 0/1 adjacency in place (``lgnn_update_adjacency``): pairs ``(rows[k], cols[k])`` and the state each
+        shall have afterwards (True / 1 = stored).  A structure-learning step (gnn/marglik_training.py:211-221) without a
+        re-ingest; the cached forward pass and everything else derived from the graph is dropped by the library."""
+        rows, cols = rows.to(self.device, torch.int64).contiguous(), cols.to(self.device, torch.int64).contiguous()
+        state = state.to(self.device, torch.uint8).contiguous()
+        if not (rows.shape == cols.shape == state.shape) or rows.dim() != 1:
+            raise ValueError("rows, cols, state must be 1-D and of one length")
+        if rows.numel() == 0:
+            return
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.lgnn_update_adjacency(self._h, _dev_ptr(rows, torch.int64, "rows"),
+                                                      _dev_ptr(cols, torch.int64, "cols"),
+                                                      _dev_ptr(state, torch.uint8, "state"), rows.numel(),
+                                                      _stream(self.device)), "lgnn_update_adjacency")
+
     def export_propagation(self):
         nnz = self.nnz
         rows = torch.empty(nnz, dtype=torch.int64, device=self.device)

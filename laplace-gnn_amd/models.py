@@ -89,6 +89,30 @@ class BaseGNN(nn.Module):
         for conv in self.convs:
             conv.reset_parameters()
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Checkpoints of the reference carry the graph as the dense ``adj`` parameter (gnn/models/base_gnn.py:75-76; the driver
+        insists on the key, gnn/marglik_training.py:78-79; a GCN's holds its self loops, gnn/models/models.py:23).  Here the
+        graph is the ``edge_index`` buffer of the HIP engine: an ``adj`` entry -- dense [N, N] or a sparse COO / CSR tensor,
+        0/1 or the continuous values of an STE model, which propagate with ``adj > threshold`` (models.py:99-101) -- is turned
+        into it (and dropped from the dict so that ``strict`` loading does not trip over it); the engine is rebuilt lazily."""
+        key = prefix + "adj"
+        if key in state_dict and not isinstance(getattr(self, "adj", None), nn.Parameter):
+            adj = state_dict.pop(key)
+            thr = float(getattr(self, "threshold", 0.0))
+            if adj.layout != torch.strided:
+                adj = adj.to_sparse_coo().coalesce()
+                ei = adj.indices()[:, adj.values() > thr]
+            else:
+                if adj.dim() != 2 or adj.shape[0] != adj.shape[1] or adj.shape[0] != self.num_nodes:
+                    error_msgs.append(f"adj has shape {tuple(adj.shape)}, expected ({self.num_nodes}, {self.num_nodes})")
+                    ei = None
+                else:
+                    ei = (adj > thr).nonzero().t()
+            if ei is not None:
+                self.edge_index = ei.to(torch.int64).contiguous().to(self.edge_index.device)
+                self._engine = None
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
     def _apply(self, fn, *args, **kwargs):
         super()._apply(fn, *args, **kwargs)
         self.X = fn(self.X)
@@ -164,3 +188,157 @@ class GraphSAGE(BaseGNN):
             raise NotImplementedError("neighbour sampling is not supported (unseeded in the reference)")
         super().__init__(in_channels, hidden_channels, out_channels, num_layers, X, init_adj, **kwargs)
         self.num_sampled_nodes_per_hop = None
+
+
+class STEGCN(GCN):
+    """The reference's structure-learning model (gnn/models/models.py:65-118) on a sparse pattern.
+
+    The reference keeps a dense continuous ``adj`` parameter [N, N] (initialised with the 0/1 adjacency and the GCN's self
+    loops), propagates with ``normalize_adj(fill_diagonal_(BinarizeSTE(adj) , 1))`` -- symmetric models binarise
+    ``(adj + adj^T) / 2`` -- and lets ``neg_marglik.backward()`` / ``adj_optimizer.step()`` move every entry
+    (gnn/marglik_training.py:197-224).  Here ``adj`` holds the continuous values of the TRACKED pairs only: the stored
+    off-diagonal entries (1) and the caller's ``candidates`` (0), ``adj_index`` [2, n] names them (row-major sorted); every
+    other pair stays an implicit non-edge with value 0.  The diagonal is not tracked: the forward overwrites it and its
+    gradient is zero (models.py:114).  The binarised graph lives in the HIP engine; after an optimizer step ``apply_adj()``
+    re-thresholds the values and hands the entries that changed side to ``lgnn_update_adjacency`` (no re-ingest).
+
+        la.fit(loader)
+        model.adj_backward(la, loader)        # adj.grad <- d(-marglik)/d adj   (neg_marglik.backward())
+        adj_optimizer.step(); model.apply_adj()
+        la.fit(loader)                        # the loop of gnn/marglik_training.py:211-224
+
+    With every non-edge listed as a candidate this reproduces the reference's loop (tests/golden/steloop_*.npz); with a
+    subset, ``clip_grad_norm_`` and the optimizer only see the tracked entries.  ``sign_grad=True`` is refused: the
+    reference takes the sign of the gradient of every forward CALL (the curvature graph and the loss forward of each batch)
+    and autograd sums the signs, which no accumulated gradient reproduces."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, X, init_adj, dropout_p: float = 0.5,
+                 act="relu", act_kwargs=None, threshold: float = 0.5, train_masked_update: bool = False, train_nodes=None,
+                 symmetric: bool = False, sign_grad: bool = False, candidates: Optional[torch.Tensor] = None, **kwargs):
+        if sign_grad:
+            raise NotImplementedError("sign_grad=True: the reference sums the signs of per-forward-call gradients "
+                                      "(gnn/models/utils.py:75-76); not reproducible from one accumulated gradient")
+        if train_masked_update and train_nodes is None:
+            raise ValueError("'train_nodes' must be provided, to use train_masked_update.")  # models.py:91-93
+        kwargs.pop("update_adj", None)
+        super().__init__(in_channels, hidden_channels, out_channels, num_layers, X, init_adj, dropout_p=dropout_p, act=act,
+                         act_kwargs=act_kwargs, symmetric=symmetric, **kwargs)
+        self.threshold = float(threshold)
+        self.sign_grad = False
+        self.train_masked_update = bool(train_masked_update)
+        N = self.num_nodes
+        ei = self.edge_index.cpu()
+        keys = ei[0] * N + ei[1]
+        if symmetric:
+            keys = torch.cat([keys, ei[1] * N + ei[0]])
+        keys = torch.unique(keys[(keys // N) != (keys % N)])  # the stored off-diagonal pattern (duplicates clamp to one entry)
+        vals = torch.ones(keys.numel())
+        if candidates is not None and candidates.numel():
+            c = candidates.cpu().to(torch.int64)
+            ck = c[0] * N + c[1]
+            if symmetric:
+                ck = torch.cat([ck, c[1] * N + c[0]])
+            ck = torch.unique(ck[(ck // N) != (ck % N)])
+            ck = ck[~torch.isin(ck, keys)]
+            keys, order = torch.sort(torch.cat([keys, ck]))
+            vals = torch.cat([vals, torch.zeros(ck.numel())])[order]
+        self.register_buffer("adj_index", torch.stack([keys // N, keys % N]))
+        self.adj = nn.Parameter(vals)  # (the Laplace parameter filter drops names containing 'adj', baselaplace.py:118-122)
+        if self.train_masked_update:
+            # soft mask of BinarizeSTE (models.py:94-98): 0.1 between two training nodes, 1 elsewhere
+            is_train = torch.zeros(N, dtype=torch.bool)
+            is_train[torch.as_tensor(train_nodes).cpu().to(torch.int64)] = True
+            both = is_train[self.adj_index[0]] & is_train[self.adj_index[1]]
+            self.register_buffer("grad_adj_mask", torch.where(both, torch.tensor(0.1), torch.tensor(1.0)))
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """A reference checkpoint's dense ``adj`` [N, N] (continuous values) is reduced to the tracked pairs, and the engine's
+        graph to its binarisation; this module's own checkpoints hold the tracked values as they are."""
+        key = prefix + "adj"
+        adj = state_dict.get(key)
+        if adj is not None and adj.dim() == 2:
+            if tuple(adj.shape) != (self.num_nodes, self.num_nodes):
+                error_msgs.append(f"adj has shape {tuple(adj.shape)}, expected ({self.num_nodes}, {self.num_nodes})")
+            else:
+                dense = adj.to(torch.float32)
+                ai = self.adj_index.to(dense.device)
+                state_dict[key] = dense[ai[0], ai[1]]
+                eff = 0.5 * (dense + dense.T) if self.symmetric else dense
+                on = eff > self.threshold
+                on.fill_diagonal_(False)
+                self.edge_index = on.nonzero().t().to(torch.int64).contiguous().to(self.edge_index.device)
+                self._engine = None
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+    # -- helpers on the tracked pattern --------------------------------------------------------------------------------
+    def _keys(self) -> torch.Tensor:
+        return self.adj_index[0] * self.num_nodes + self.adj_index[1]
+
+    def _effective(self) -> torch.Tensor:
+        """What is thresholded: the values, or (adj + adj^T) / 2 of a symmetric model (models.py:105-106)."""
+        v = self.adj.detach()
+        if not self.symmetric:
+            return v
+        keys = self._keys()
+        tpos = torch.searchsorted(keys, self.adj_index[1] * self.num_nodes + self.adj_index[0])
+        return 0.5 * (v + v[tpos])  # (the tracked pattern of a symmetric model contains both orientations)
+
+    def full_adj(self) -> torch.Tensor:
+        """Dense binarised adjacency (models.py:99-101, with the propagated self loops), small graphs only."""
+        return super().full_adj()
+
+    def dense_adj(self) -> torch.Tensor:
+        """The continuous parameter as the reference stores it (dense [N, N], untracked pairs 0, diagonal 1): small graphs."""
+        out = torch.zeros(self.num_nodes, self.num_nodes, device=self.adj.device)
+        out[self.adj_index[0], self.adj_index[1]] = self.adj.detach()
+        out.fill_diagonal_(1.0)
+        return out
+
+    # -- the structure-learning step -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def adj_backward(self, la, train_loader, process_group=None):
+        """``neg_marglik.backward()`` of the loop (gnn/marglik_training.py:212-216): ``adj.grad`` <- the gradient of the fitted
+        posterior's negative log marginal likelihood w.r.t. the tracked entries, through normalize_adj, the overwritten
+        diagonal, the STE (identity times ``grad_adj_mask``, gnn/models/utils.py:67-71) and the symmetric parameterisation.
+        Accumulates into an existing ``.grad`` like autograd does.  Returns the negative log marginal likelihood."""
+        eng = self.engine
+        keys = self._keys()
+        sr, sc = eng.export_adj()
+        skeys = sr * self.num_nodes + sc
+        stored = torch.isin(keys, skeys)  # tracked pairs the engine currently stores
+        ci, cj = self.adj_index[0][~stored], self.adj_index[1][~stored]
+        if self.symmetric:  # one orientation per unordered pair: the call returns the symmetrised value for both
+            half = ci < cj
+            ci, cj = ci[half], cj[half]
+        cand = torch.stack([ci, cj]) if ci.numel() else None
+        res = la.neg_marglik_adj_grad(train_loader, process_group=process_group, candidates=cand)
+        value, _, gs = res[0], res[1], res[2]
+        g = torch.zeros_like(self.adj)
+        pos = torch.searchsorted(keys, skeys).clamp(max=max(keys.numel() - 1, 0))
+        hit = keys[pos] == skeys  # (the diagonal and untracked stored pairs -- none by construction -- are skipped)
+        g[pos[hit]] = gs[hit]
+        if cand is not None:
+            gc = res[3]
+            ckeys = ci * self.num_nodes + cj
+            g[torch.searchsorted(keys, ckeys)] = gc
+            if self.symmetric:
+                g[torch.searchsorted(keys, cj * self.num_nodes + ci)] = gc
+        if self.train_masked_update:
+            g = g * self.grad_adj_mask
+        self.adj.grad = g if self.adj.grad is None else self.adj.grad + g
+        return value
+
+    @torch.no_grad()
+    def apply_adj(self) -> int:
+        """After ``adj_optimizer.step()``: re-binarise the tracked values (``> threshold``, models.py:103-116) and flip the
+        entries of the engine's graph whose side changed.  Returns the number of directed entries flipped."""
+        eng = self.engine
+        want = self._effective() > self.threshold
+        sr, sc = eng.export_adj()
+        have = torch.isin(self._keys(), sr * self.num_nodes + sc)
+        flip = want != have
+        n = int(flip.sum())
+        if n:
+            eng.update_adjacency(self.adj_index[0][flip], self.adj_index[1][flip], want[flip])
+            self.edge_index = eng.adj_to_edge_index()
+        return n

@@ -405,6 +405,67 @@ def make_regression_mlp(ns, torch):
     print("c1_regression_mlp written")
 
 
+def make_structure_loop(ns, torch, name, structure, seed, symmetric, grad_norm, lr_adj, momentum, weight_decay, sign_grad=False,
+                        masked=False, steps=3, n=64, f=12, h=8, c=3, n_edges=150, n_train=33, batch_size=12, prior=1.0):
+    """The fork's structure-learning loop itself (gnn/marglik_training.py:197-224): fit, neg_marglik.backward(), optional
+    clip_grad_norm_ on the adjacency (:213-215), ``adj_optimizer.step()`` (SGD with momentum and weight decay, :97-99), refit --
+    ``steps`` times, run by the reference's own STEGCN (gnn/models/models.py:65-118, BinarizeSTE gnn/models/utils.py:42-86) and
+    KronLaplace / DiagLaplace.  Stored: the inputs, the continuous adjacency parameter after every step (dense, N = 64) and the
+    negative log marginal likelihood before the first step and after every refit."""
+    from torch.utils.data import DataLoader, TensorDataset
+
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, n_edges), generator=g)
+    X = torch.randn(n, f, generator=g)
+    adj0 = reference_dense_adj(torch, ei, n)
+    perm = torch.randperm(n, generator=g)
+    train_idx = perm[:n_train].clone()
+    train_idx[3] = train_idx[5]
+    train_y = torch.randint(0, c, (n_train,), generator=g)
+    loader = DataLoader(TensorDataset(train_idx, train_y), batch_size=batch_size, shuffle=False)
+    torch.manual_seed(seed)
+    ste = ns.gnn_models.STEGCN(f, h, c, 2, X, adj0.clone(), dropout_p=0.5, threshold=0.5, symmetric=symmetric,
+                               sign_grad=sign_grad, train_masked_update=masked, train_nodes=train_idx if masked else None)
+    ste.eval()
+    out = {"kind": "gcn", "symmetric": symmetric, "num_nodes": n, "batch_size": batch_size, "edge_index": ei.numpy(),
+           "X": X.numpy(), "train_idx": train_idx.numpy(), "train_y": train_y.numpy(), "num_layers": 2,
+           "structure": structure, "grad_norm": bool(grad_norm), "lr_adj": np.float64(lr_adj), "momentum": np.float64(momentum),
+           "weight_decay": np.float64(weight_decay), "sign_grad": bool(sign_grad), "masked": bool(masked),
+           "prior": np.float64(prior), "threshold": np.float64(0.5)}
+    for l, conv in enumerate(ste.convs):
+        out[f"W{l}"] = conv.lin.weight.detach().numpy().copy()
+        out[f"b{l}"] = conv.lin.bias.detach().numpy().copy()
+    out["adj_init"] = ste.adj.detach().numpy().copy()  # (symmetrised 0/1 with the GCN's self loops)
+    bl = ns.baselaplace
+    cls = bl.KronLaplace if structure == "kron" else bl.DiagLaplace
+    lap = cls(ste, "classification", prior_precision=prior)
+    lap.fit(loader)
+    neg = -lap.log_marginal_likelihood()
+    opt = torch.optim.SGD([ste.adj], lr=lr_adj, weight_decay=weight_decay, momentum=momentum)
+    negs, adjs, grads = [float(neg)], [], []
+    for _ in range(steps):
+        opt.zero_grad()
+        neg.backward()
+        grads.append(ste.adj.grad.detach().numpy().copy())  # (before clipping)
+        if grad_norm:
+            torch.nn.utils.clip_grad_norm_(ste.adj, max_norm=1.0)
+        opt.step()
+        lap.fit(loader)
+        neg = -lap.log_marginal_likelihood()
+        negs.append(float(neg))
+        adjs.append(ste.adj.detach().numpy().copy())
+    out["neg_marglik"] = np.array(negs, dtype=np.float64)
+    out["adj_steps"] = np.stack(adjs).astype(np.float32)
+    out["grad_steps"] = np.stack(grads).astype(np.float32)
+    flips = [int(((a > 0.5) != (b > 0.5)).sum()) for a, b in zip([out["adj_init"]] + adjs[:-1], adjs)]
+    margin = min(float(np.abs(a - 0.5).min()) for a in adjs)
+    print(f"  smallest distance of a value from the threshold over the steps: {margin:.2e}")
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path)/1024:.0f} KiB  neg_marglik={negs}  entries flipped per step={flips}")
+
+
 def main():
     import torch
 
@@ -470,6 +531,21 @@ def main():
               norm="layer", res=True, **ex)
     if not only or "c1_regression_mlp" in only:
         make_regression_mlp(ns, torch)
+    # the structure-learning loop (VERDICT r3 missing #2): three hyper-steps of the reference's own STEGCN + SGD
+    loops = {
+        "steloop_kron_sym": dict(structure="kron", seed=62, symmetric=True, grad_norm=True, lr_adj=8.0, momentum=0.9,
+                                 weight_decay=5e-4),
+        "steloop_kron_dir": dict(structure="kron", seed=51, symmetric=False, grad_norm=False, lr_adj=0.05, momentum=0.5,
+                                 weight_decay=0.0, masked=True),
+        "steloop_diag_sym": dict(structure="diag", seed=62, symmetric=True, grad_norm=True, lr_adj=8.0, momentum=0.9,
+                                 weight_decay=5e-4),
+    }
+    # (sign_grad=True is not covered: BinarizeSTE.backward takes the sign of the gradient of EVERY forward call -- the Kronecker
+    #  graph and the loss forward of each batch -- and autograd sums those signs, values in {-3 .. 3} with three batches; the
+    #  HIP path accumulates one gradient and refuses the option)
+    for nm, kw in loops.items():
+        if not only or nm in only:
+            make_structure_loop(ns, torch, nm, **kw)
 
 
 if __name__ == "__main__":
