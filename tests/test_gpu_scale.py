@@ -643,6 +643,34 @@ def test_headline_shape_B0_against_an_independent_fp64_restatement(workload):
     eng.close()
 
 
+def test_headline_launch_of_all_40_classes_against_the_fp64_restatement():
+    """the headline's ONE launch of ``paths_fused_kernel`` over all 40 class columns of a full batch of
+    10 000 at N = 169 343 (what ``bench.py`` times) against the fp64 restatement of every class column -- not three single-class
+    calls, and not the plane route (HIP vs HIP).  B_0 256 x 256, B_1 40 x 40, the loss."""
+    import bench
+    import laplace_gnn_amd as lg
+
+    w, ei, X, train_idx, train_y = bench.make_workload("arxiv", "cuda")
+    torch.manual_seed(0)
+    model = lg.GCN(w["F"], w["H"], w["C"], 2, X, ei, symmetric=True).to("cuda").eval()
+    eng = model.engine
+    M = w["batch"]
+    idx, y = train_idx.cuda()[:M].clone(), train_y.cuda()[:M]
+    idx[-20:] = idx[:20]
+    Ws = [c.lin.weight.detach() for c in model.convs]
+    bs = [c.lin.bias.detach() for c in model.convs]
+    B0, B1, ce = _fp64_kfac_classes("gcn", eng, idx, y, range(w["C"]), X, Ws, bs)
+    _, views, loss = eng.new_kfac_buffers()
+    eng.kfac_accumulate(idx, y, w["n_train"], views, loss)  # all classes, one call: one launch of the fused kernel
+    torch.cuda.synchronize()
+    assert eng.last_kfac_used_paths
+    assert rel(views[0][1].cpu().numpy(), B0.cpu().numpy()) < RTOL, "B_0"
+    assert rel(views[1][1].cpu().numpy(), B1.cpu().numpy()) < RTOL, "B_1"
+    assert abs(float(loss) - ce) < RTOL * ce
+    eng.check_async_errors()
+    eng.close()
+
+
 @pytest.mark.parametrize("kind,structure", [("gcn", "kron"), ("sage", "kron"), ("gcn", "diag")])
 def test_no_device_allocation_after_the_first_fit(kind, structure):
     """the workspace is sized by the first fit; a second fit of the same shape allocates nothing
