@@ -227,8 +227,8 @@ def _median(xs):
 def _pmc_traffic(workload, structure, units_per_launch):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass of this same command
     (counters cannot be collected inside the timed run); null when no summary for this workload is committed."""
-    names = ["r03_arxiv_pmc_fused.json"] if (workload, structure) == ("arxiv", "kron") \
-        else [f"r03_{workload}_pmc_dominant.json", f"r02_{workload}_pmc_dominant.json"]
+    names = ["r04_arxiv_pmc_fused.json", "r03_arxiv_pmc_fused.json"] if (workload, structure) == ("arxiv", "kron") \
+        else [f"r04_{workload}_pmc_dominant.json", f"r03_{workload}_pmc_dominant.json", f"r02_{workload}_pmc_dominant.json"]
     if structure != DEFAULT_STRUCTURE[workload]:
         names = []
     for name in names:
@@ -329,6 +329,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     launches, kern_ms, units = eng.kernel_timing()
+    per_launch = eng.kernel_timing_launches() if hasattr(eng, "kernel_timing_launches") else []
     eng.enable_kernel_timing(False)
     step_ms = [e[0].elapsed_time(e[2]) for e in ev]
     acc_ms = [e[0].elapsed_time(e[1]) for e in ev]
@@ -371,6 +372,18 @@ def main():
                 xb, yb = next(iter(loader))
                 eng.kfac_accumulate(xb, yb, w["n_train"], pv, pl)
                 paths = eng.last_kfac_used_paths
+                # The last batch of a fit is short (arxiv: 941 of 10 000 samples): its launch is cheaper, yet SURVEY.md 8(d) credits
+                # it the same N-row work.  `achieved` / `frac` therefore count the FULL batches' launches only (the stricter
+                # reading: VERDICT r3 recomputed 0.77 where the blended average gave 0.82); the blended figure is kept beside it.
+                T = len(loader)
+                full_ms = last_ms = None
+                if per_launch and len(per_launch) == args.steps * T and T > 1 and w["n_train"] % w["batch"]:
+                    fl = [t for i, t in enumerate(per_launch) if i % T != T - 1]
+                    ll = [t for i, t in enumerate(per_launch) if i % T == T - 1]
+                    full_ms, last_ms = sum(fl) / len(fl), sum(ll) / len(ll)
+                    common.update({"full_batch_launch_ms": full_ms, "last_batch_launch_ms": last_ms,
+                                   "frac_all_launches": ach / PEAK_MFMA_F32_TFLOPS})
+                    ach = flops / launches / (full_ms * 1e-3) / 1e12
                 roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_MFMA_F32_TFLOPS, **common,
                             "kernel": "paths_fused_kernel" if paths else ("spmm_gram256_kernel" if H > 128 else "spmm_gram_kernel"),
@@ -382,13 +395,22 @@ def main():
                     # pass x 64 flop per busy cycle and SIMD, over this run's launch time
                     busy = (pmc or {}).get("SQ_VALU_MFMA_BUSY_CYCLES_avg")
                     per = (pmc or {}).get("planes_per_launch", upl)
-                    exe = busy * 64.0 * (upl / per) / (avg_ms * 1e-3) / 1e12 if busy else None
+                    t_ms = avg_ms
+                    # the counter pass keeps the template instances apart: <false> = the full batches' launches, <true> = the
+                    # short last batch's (node list); the full batches' busy cycles go over the full batches' launch time
+                    inst = {("<true>" in i["kernel"]): i for i in (pmc or {}).get("instances", [])}
+                    if full_ms and False in inst and "SQ_VALU_MFMA_BUSY_CYCLES_avg" in inst[False]:
+                        busy, t_ms = inst[False]["SQ_VALU_MFMA_BUSY_CYCLES_avg"], full_ms
+                        if True in inst and last_ms and "SQ_VALU_MFMA_BUSY_CYCLES_avg" in inst[True]:
+                            roofline["last_batch_executed_frac_of_peak"] = (inst[True]["SQ_VALU_MFMA_BUSY_CYCLES_avg"] * 64.0
+                                                                          / (last_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS)
+                    exe = busy * 64.0 * (upl / per) / (t_ms * 1e-3) / 1e12 if busy else None
                     roofline.update({
                         "executed_TFLOPs": exe, "executed_frac_of_peak": exe / PEAK_MFMA_F32_TFLOPS if exe else None,
                         "note": "'achieved' credits the SURVEY.md 8(d) count of what the kernel replaces (C planes x (2 nnz H + 2 N "
                                 "H^2), no credit for symmetry); executed_* = matrix-pipe busy cycles (rocprofv3 counter pass of "
-                                "this command, profiles/) x 64 flop: the kernel runs 36/64 of the Gram's sub-tiles plus the path "
-                                "products; its HBM traffic is below the algorithmic bytes because no class plane exists"})
+                                "this command, profiles/) x 64 flop, full batches' launches over their own time: the kernel runs "
+                                "the upper triangle of every node's Gram plus the path products; its HBM traffic is below the algorithmic bytes because no class plane exists"})
                 else:
                     roofline.update({
                         "executed_frac_of_peak": ach / PEAK_MFMA_F32_TFLOPS * 36.0 / 64.0 if H > 128 else None,
@@ -398,7 +420,8 @@ def main():
                                    "their neighbours), so frac can exceed 1 and executed_frac_of_peak overstates by the "
                                    "share of skipped rows" if w.get("kind") == "sage" else "")})
             elif structure == "diag":
-                # dominant kernel: the first-layer contraction (GCN: diag_first_layer_mfma_kernel, GraphSAGE:
+                # dominant kernel: the first-layer contraction (GCN: diag_first_layer_tile_kernel on wide inputs, else
+                # diag_first_layer_mfma_kernel; GraphSAGE:
                 # diag_first_layer_kernel<1>), one launch per batch.  ALGORITHMIC bytes per launch (SURVEY.md 8(d)
                 # "Diag (C2)"): N*F*4 + nnz*8 + 2*P*4; flops 2*M*dbar*H*(F+1).  HBM bound by that count (in practice latency
                 # bound: ~16 MB per launch; DESIGN.md has the phase breakdown).
@@ -407,7 +430,8 @@ def main():
                 ach = bytes_l * launches / (kern_ms * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": ach / PEAK_HBM_GBS, **common,
-                            "kernel": "diag_first_layer_kernel<1>" if w.get("kind") == "sage" else "diag_first_layer_mfma_kernel",
+                            "kernel": "diag_first_layer_kernel<1>" if w.get("kind") == "sage"
+                            else ("diag_first_layer_tile_kernel" if (F + 1 + 191) // 192 >= 4 and H % 4 == 0 else "diag_first_layer_mfma_kernel"),
                             "samples_per_launch": upl, "algorithmic_bytes_per_launch": bytes_l,
                             "algorithmic_TFLOPs": 2.0 * units * (nnz / N) * H * (F + 1) / (kern_ms * 1e-3) / 1e12}
             else:

@@ -286,6 +286,9 @@ LGNN_API int lgnn_check_async_errors(lgnn_ctx* h, void* stream);
  * class pairs); enabling resets the counters.                                                     */
 LGNN_API int lgnn_enable_kernel_timing(lgnn_ctx* h, int enable);
 LGNN_API int lgnn_kernel_timing_read(lgnn_ctx* h, int64_t* launches, double* total_ms, int64_t* planes);
+/* The same events, launch by launch (host array of `capacity` doubles, milliseconds, in launch order; *launches = how many
+ * were recorded): bench.py separates the full batches' launches from the short last batch's.  Synchronises on the events. */
+LGNN_API int lgnn_kernel_timing_launches(lgnn_ctx* h, double* ms_out, int64_t capacity, int64_t* launches);
 
 /* ---- per-sample Jacobians for the GLM predictive ("next" row) ------------------------------------
  * Replaces CurvatureInterface.jacobians (laplace/curvature/curvature.py:89-130, torch.func.jacrev of the dense

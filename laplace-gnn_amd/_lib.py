@@ -56,6 +56,7 @@ SIGNATURES = {
     "lgnn_check_async_errors": (_i32, [_vp, _vp]),
     "lgnn_enable_kernel_timing": (_i32, [_vp, _i32]),
     "lgnn_kernel_timing_read": (_i32, [_vp, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "lgnn_kernel_timing_launches": (_i32, [_vp, _vp, _i64, _vp]),
     "lgnn_kfac_adjgrad_batch": (_i32, [_vp, _vp, _vp, _i64, _u32, _pp, C.c_float, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "lgnn_adjgrad_finish": (_i32, [_vp, _vp, _pp, C.c_float, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "lgnn_diag_adjgrad_batch": (_i32, [_vp, _vp, _vp, _i64, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),

@@ -480,6 +480,19 @@ extern "C" int lgnn_kernel_timing_read(lgnn_ctx* h, int64_t* launches, double* t
   return 0;
 }
 
+extern "C" int lgnn_kernel_timing_launches(lgnn_ctx* h, double* ms_out, int64_t capacity, int64_t* launches) {
+  if (!h || !launches || (capacity > 0 && !ms_out)) { set_error("null argument"); return 2; }
+  const int64_t n = int64_t(h->ev_used / 2);
+  *launches = n;
+  for (int64_t i = 0; i < n && i < capacity; ++i) {
+    LGNN_HIP_CHECK(hipEventSynchronize(h->ev[2 * i + 1]));
+    float ms = 0.f;
+    LGNN_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+    ms_out[i] = ms;
+  }
+  return 0;
+}
+
 extern "C" int lgnn_kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, int64_t n_train,
                                     uint32_t flags, float* const* A_out, float* const* B_out, float* loss_out,
                                     void* stream) {

@@ -610,6 +610,14 @@ class GraphEngine:
     def enable_kernel_timing(self, on: bool = True):
         _lib.check(self.lib.lgnn_enable_kernel_timing(self._h, int(on)), "lgnn_enable_kernel_timing")
 
+    def kernel_timing_launches(self):
+        """Durations [ms] of the dominant kernel's launches since timing was enabled, in launch order."""
+        n = C.c_int64(0)
+        _lib.check(self.lib.lgnn_kernel_timing_launches(self._h, None, 0, C.byref(n)), "lgnn_kernel_timing_launches")
+        buf = (C.c_double * max(n.value, 1))()
+        _lib.check(self.lib.lgnn_kernel_timing_launches(self._h, buf, n.value, C.byref(n)), "lgnn_kernel_timing_launches")
+        return [buf[i] for i in range(n.value)]
+
     def kernel_timing(self):
         n, ms, planes = C.c_int64(0), C.c_double(0.0), C.c_int64(0)
         _lib.check(self.lib.lgnn_kernel_timing_read(self._h, C.byref(n), C.byref(ms), C.byref(planes)),

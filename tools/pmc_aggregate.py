@@ -35,6 +35,10 @@ for k in cands[:1]:
              "command": f"rocprofv3 --pmc <ctrs> -- python3 bench.py --workload {wl} --steps 1 --warmup 0 --no-cpu-baseline (one pass per counter group)",
              "dispatches": max(cnt[(k, c)] for c in v), "planes_per_launch": float(os.environ.get("LGNN_PLANES_PER_LAUNCH", "40"))}
         j.update({c + "_avg": a[c] for c in a})
+        # every template instance of the kernel with its own averages (arxiv: <false> = the full batches' launches,
+        # <true> = the short last batch's, which walks a node list)
+        j["instances"] = [{"kernel": kk[:120], "dispatches": max(cnt[(kk, c)] for c in val[kk]),
+                           **{c + "_avg": val[kk][c] / cnt[(kk, c)] for c in val[kk]}} for kk in cands]
         if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
             j["note"] = ("gfx950: FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md HBM section) -> "
                          "traffic = (2*FETCH_SIZE + WRITE_SIZE) KB; FETCH_SIZE counts Infinity-Cache hits too")
