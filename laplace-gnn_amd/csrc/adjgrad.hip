@@ -951,12 +951,464 @@ int sage_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0
 
 }  // namespace
 
-int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags, const float* gamma_B0,
-                       const float* gamma_B1, float loss_scale, float* grad_P, float* out_bar, const int32_t* cand_a,
-                       const int32_t* cand_b, int64_t K, float* grad_cand, hipStream_t s) {
+namespace {
+// ---------------------------------------------------------------------------------------------------------------------------
+// Models with res / norm (gnn/models/base_gnn.py:141-149; the STE-GCN configurations of Cornell / Texas / Wisconsin / Circle,
+// gnn/configs/original/stegcn_config.yaml:54-105, 129-145):  s = P Z0 + res(X),  n = norm(s),  H1 = relu(n).
+// The norm's row-local backward y = rstd Pi(xhat) x (Pi x = x - mean(x) - xhat mean(x xhat); symmetric) appears in two places
+// of the second-order sweep, each time with an adjoint ybar of y:
+//   KRON  u = norm_bwd(dn):        x = gamma * dn,  ybar = ubar;         needed: dn_bar = mask * gamma * (rstd Pi ybar)
+//   !KRON ndot = norm_tangent(sdot): x = sdot,      ybar = gamma * nbar;   needed: sdot_bar = rstd Pi ybar
+// and, both times, the adjoint of the pre-norm rows s through the norm's own statistics (x held fixed):
+//   rstd_bar = <ybar, y> / rstd,   xhat_bar_j = -rstd (ybar_j mean(x xhat) + mean(ybar xhat) x_j),
+//   s_bar    = rstd Pi xhat_bar - rstd_bar rstd^2 xhat / W          (d rstd / d s_j = -rstd^2 xhat_j / W).
+// In place: YB <- the first result, X <- s_bar (LayerNorm only; untouched otherwise).  One wave per plane row, node = row % N.
+// BatchNorm1d in eval mode is a fixed affine map (no second-order term), Identity passes through.
+template <bool KRON>
+__global__ __launch_bounds__(256) void norm_pair_kernel(float* __restrict__ X, float* __restrict__ YB, int64_t rows, int64_t N,
+                                                        int64_t W, int norm, const float* __restrict__ gamma,
+                                                        const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                        const float* __restrict__ hact, int64_t hact_ld, int act) {
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = int64_t(gridDim.x) * 4;
+  for (int64_t r = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); r < rows; r += stride) {
+    const int64_t n = r % N;
+    float* __restrict__ x = X + r * W;
+    float* __restrict__ yb = YB + r * W;
+    const float* __restrict__ hn = (KRON && hact) ? hact + n * hact_ld : nullptr;
+    if (norm != LGNN_NORM_LAYER) {
+      for (int64_t j = lane; j < W; j += 64) {
+        float t = yb[j];
+        if (norm == LGNN_NORM_BATCH) t *= gamma[j] * rstd[j];
+        if (hn) t *= act_deriv_from_out(hn[j], act);
+        yb[j] = t;
+      }
+      continue;
+    }
+    const float* __restrict__ xh = xhat + n * W;
+    float sx = 0.f, sxx = 0.f, sy = 0.f, syx = 0.f, sxy = 0.f;
+    for (int64_t j = lane; j < W; j += 64) {
+      const float g = gamma[j], h = xh[j];
+      const float xv = KRON ? x[j] * g : x[j];
+      const float yv = KRON ? yb[j] : yb[j] * g;
+      sx += xv; sxx += xv * h; sy += yv; syx += yv * h; sxy += xv * yv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sx += __shfl_xor(sx, o); sxx += __shfl_xor(sxx, o); sy += __shfl_xor(sy, o); syx += __shfl_xor(syx, o);
+      sxy += __shfl_xor(sxy, o);
+    }
+    const float iw = 1.f / float(W);
+    const float mx1 = sx * iw, mx = sxx * iw, my1 = sy * iw, my = syx * iw;
+    const float rs = rstd[n];
+    const float rstd_bar = sxy - float(W) * (my1 * mx1 + my * mx);
+    const float m_xb = -rs * (my1 * mx + my * mx1);  // mean(xhat_bar)
+    const float m_xbx = -2.f * rs * my * mx;          // mean(xhat_bar * xhat)
+    for (int64_t j = lane; j < W; j += 64) {
+      const float g = gamma[j], h = xh[j];
+      const float xv = KRON ? x[j] * g : x[j];
+      const float yv = KRON ? yb[j] : yb[j] * g;
+      const float xb = -rs * (yv * mx + my * xv);
+      x[j] = rs * (xb - m_xb - h * m_xbx) - rstd_bar * rs * rs * h * iw;
+      float o1 = rs * (yv - my1 - h * my);
+      if (KRON) {
+        o1 *= g;
+        if (hn) o1 *= act_deriv_from_out(hn[j], act);
+      }
+      yb[j] = o1;
+    }
+  }
+}
+
+// ndot = mask * norm_tangent(sdot): out[r] = act'(h[n]) * gamma * rstd * Pi sdot[r] (LayerNorm), * gamma * rstd_channel
+// (BatchNorm), sdot itself (Identity); one wave per plane row
+__global__ __launch_bounds__(256) void norm_tangent_kernel(const float* __restrict__ S, float* __restrict__ out, int64_t rows,
+                                                           int64_t N, int64_t W, int norm, const float* __restrict__ gamma,
+                                                           const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                           const float* __restrict__ hact, int64_t hact_ld, int act) {
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = int64_t(gridDim.x) * 4;
+  for (int64_t r = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); r < rows; r += stride) {
+    const int64_t n = r % N;
+    const float* __restrict__ sd = S + r * W;
+    const float* __restrict__ hn = hact + n * hact_ld;
+    float m1 = 0.f, m2 = 0.f, rs = 1.f;
+    if (norm == LGNN_NORM_LAYER) {
+      const float* __restrict__ xh = xhat + n * W;
+      for (int64_t j = lane; j < W; j += 64) { m1 += sd[j]; m2 += sd[j] * xh[j]; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+      m1 /= float(W); m2 /= float(W);
+      rs = rstd[n];
+    }
+    for (int64_t j = lane; j < W; j += 64) {
+      float t = sd[j];
+      if (norm == LGNN_NORM_LAYER) t = gamma[j] * rs * (t - m1 - xhat[n * W + j] * m2);
+      else if (norm == LGNN_NORM_BATCH) t *= gamma[j] * rstd[j];
+      out[r * W + j] = t * act_deriv_from_out(hn[j], act);
+    }
+  }
+}
+
+// Y[q][r][:] += bias_q[:]  (bias_q = base + q * bias_stride); planes [Q][rows][W]
+__global__ void plane_bias_kernel(float* __restrict__ Y, int64_t rows, int64_t W, const float* __restrict__ base,
+                                  int64_t bias_stride, int64_t total) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t q = t / (rows * W), j = t % W;
+    Y[t] += base[q * bias_stride + j];
+  }
+}
+
+// Diagonal posterior, per sample m of the chunk (one workgroup): p = softmax(f_n);  K = J_m diag(gamma) J_m^T  [C, C];
+// out_bar[n] += Lambda (diag K - 2 K p) + loss_scale (p - onehot(y));   probs[m] = p (kept for the R kernel)
+__global__ __launch_bounds__(256) void diag_ext_sample_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
+                                                              int64_t N, int64_t C, int64_t P, const float* __restrict__ J,
+                                                              const float* __restrict__ gamma, const float* __restrict__ logits,
+                                                              float loss_scale, float* __restrict__ probs,
+                                                              float* __restrict__ out_bar) {
+  extern __shared__ float sh[];  // K [C*C] | p [C] | red [4]
+  float* Ks = sh;
+  float* ps = sh + C * C;
+  float* red = ps + C;
+  const int64_t m = blockIdx.x;
+  const int64_t n = idx[m];
+  if (n < 0 || n >= N) return;
+  const float* __restrict__ Jm = J + m * C * P;
+  for (int64_t cc = 0; cc < C * C; ++cc) {
+    const int64_t a = cc / C, b = cc - a * C;
+    if (b < a) continue;  // symmetric
+    float acc = 0.f;
+    for (int64_t p = threadIdx.x; p < P; p += 256) acc += Jm[a * P + p] * gamma[p] * Jm[b * P + p];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { const float v = red[0] + red[1] + red[2] + red[3]; Ks[a * C + b] = v; Ks[b * C + a] = v; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mx = -INFINITY, sum = 0.f;
+    for (int64_t c = 0; c < C; ++c) mx = fmaxf(mx, logits[n * C + c]);
+    for (int64_t c = 0; c < C; ++c) { ps[c] = expf(logits[n * C + c] - mx); sum += ps[c]; }
+    for (int64_t c = 0; c < C; ++c) { ps[c] /= sum; probs[m * C + c] = ps[c]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int64_t c = threadIdx.x;
+    // t = diag K - 2 K p;  (Lambda t)_c = p_c (t_c - <p, t>)
+    float pt = 0.f, tc = 0.f;
+    for (int64_t a = 0; a < C; ++a) {
+      float kp = 0.f;
+      for (int64_t b = 0; b < C; ++b) kp += Ks[a * C + b] * ps[b];
+      const float ta = Ks[a * C + a] - 2.f * kp;
+      pt += ps[a] * ta;
+      if (a == c) tc = ta;
+    }
+    const float v = ps[c] * (tc - pt) + loss_scale * (ps[c] - (y[m] == c ? 1.f : 0.f));
+    atomicAdd(&out_bar[n * C + c], v);
+  }
+}
+
+// R[m][c][p] = 2 gamma_p (Lambda_m J_m)[c, p] = 2 gamma_p p_c (J[m][c][p] - sum_k p_k J[m][k][p])
+__global__ void diag_ext_direction_kernel(const float* __restrict__ J, const float* __restrict__ gamma,
+                                          const float* __restrict__ probs, int64_t mc, int64_t C, int64_t P,
+                                          float* __restrict__ R) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < mc * P; t += stride) {
+    const int64_t m = t / P, p = t - m * P;
+    const float* __restrict__ Jm = J + m * C * P + p;
+    const float* __restrict__ pm = probs + m * C;
+    float jb = 0.f;
+    for (int64_t k = 0; k < C; ++k) jb += pm[k] * Jm[k * P];
+    const float g2 = 2.f * gamma[p];
+    for (int64_t c = 0; c < C; ++c) R[(m * C + c) * P + p] = g2 * pm[c] * (Jm[c * P] - jb);
+  }
+}
+
+// plane q = (m, c) of the chunk, one wave: the directional derivative is qv = sum_b P[n, b] z1dot_q[b, c], n = idx[m]:
+//   gradP[(n, b)] += z1dot_q[b, c];   nbar_q[b, :] = act'(h[b]) P[n, b] W1[c, :]  (rows outside the row of n stay 0);
+//   h1_bar[b, :] += P[n, b] dW1_q[c, :]
+__global__ __launch_bounds__(256) void diag_ext_row_kernel(const int64_t* __restrict__ idx, int64_t planes, int64_t N, int64_t C,
+                                                           int64_t H, const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                           const float* __restrict__ Z1d, const float* __restrict__ W1,
+                                                           const float* __restrict__ dW1, int64_t dir_stride,
+                                                           const float* __restrict__ hact, int64_t hact_ld, int act,
+                                                           float* __restrict__ nbar, float* __restrict__ h1_bar,
+                                                           float* __restrict__ grad_P) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (q >= planes) return;
+  const int64_t m = q / C, c = q - m * C;
+  const int64_t n = idx[m];
+  if (n < 0 || n >= N) return;
+  const float* __restrict__ w = W1 + c * H;
+  const float* __restrict__ dw = dW1 + q * dir_stride + c * H;
+  for (int32_t p = rowptr[n]; p < rowptr[n + 1]; ++p) {
+    const int64_t b = col[p];
+    const float pv = val[p];
+    if (lane == 0) atomicAdd(&grad_P[p], Z1d[(q * N + b) * C + c]);
+    for (int64_t j = lane; j < H; j += 64) {
+      nbar[(q * N + b) * H + j] = act_deriv_from_out(hact[b * hact_ld + j], act) * pv * w[j];
+      atomicAdd(&h1_bar[b * H + j], pv * dw[j]);
+    }
+  }
+}
+
+// candidate pairs (a, b) of P: grad_cand[k] += z1dot_q[b, c] for every plane q = (m, c) with idx[m] == a
+__global__ void diag_ext_cand_kernel(const int32_t* __restrict__ ca, const int32_t* __restrict__ cb, int64_t K,
+                                     const int64_t* __restrict__ idx, int64_t planes, int64_t N, int64_t C,
+                                     const float* __restrict__ Z1d, float* __restrict__ grad_cand) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= K * planes) return;
+  const int64_t k = t / planes, q = t - k * planes;
+  const int64_t m = q / C, c = q - m * C;
+  if (idx[m] != ca[k]) return;
+  atomicAdd(&grad_cand[k], Z1d[(q * N + cb[k]) * C + c]);
+}
+
+// row-major C_q[R, Nout] = alpha * A[R, K] (shared by all planes) * B_q[Nout, K]^T + beta * C_q,  B_q = B + q * strideB
+int sgemm_rm_nt_shared(hipStream_t s, int64_t R, int64_t Nout, int64_t K, const float* A, int64_t lda, const float* B,
+                       int64_t strideB, float beta, float* Cm, int64_t strideC, int64_t batch) {
+  rocblas_handle blas = static_cast<rocblas_handle>(blas_handle(s));
+  LGNN_REQUIRE(blas != nullptr, "rocBLAS handle");
+  const float one = 1.f;
+  const rocblas_status st = rocblas_sgemm_strided_batched(
+      blas, rocblas_operation_transpose, rocblas_operation_none, rocblas_int(Nout), rocblas_int(R), rocblas_int(K), &one, B,
+      rocblas_int(K), rocblas_stride(strideB), A, rocblas_int(lda), 0, &beta, Cm, rocblas_int(Nout), rocblas_stride(strideC),
+      rocblas_int(batch));
+  if (st != rocblas_status_success) { set_error("rocblas_sgemm_strided_batched failed"); return 3; }
+  return 0;
+}
+
+int check_model_ext(const lgnn_ctx* h) {
+  LGNN_REQUIRE(h->L == 2, "adjacency gradient: 2-layer models (SURVEY.md 8(f)-4)");
+  LGNN_REQUIRE(h->kind == LGNN_KIND_GCN, "adjacency gradient with res / norm: GCN models (the reference's STEGCN configurations)");
+  LGNN_REQUIRE(h->act == LGNN_ACT_RELU && h->lik == LGNN_LIK_CLASSIFICATION, "adjacency gradient: ReLU, classification");
+  LGNN_REQUIRE(h->dims[2] <= 256, "adjacency gradient: at most 256 classes");
+  return 0;
+}
+
+int launch_norm_pair(lgnn_ctx* h, bool kron, float* X, float* YB, int64_t rows, hipStream_t s) {
+  const int64_t N = h->N, H = h->dims[1];
+  const bool nrm = h->norm != LGNN_NORM_NONE;
+  const float* g = nrm ? h->norm_w[0] : nullptr;
+  const float* xh = nrm ? h->fc.xhat[0].as<float>() : nullptr;
+  const float* rs = nrm ? h->fc.rstd[0].as<float>() : nullptr;
+  const unsigned grid = unsigned(std::min<int64_t>(cdiv(rows, 4), 65536));
+  if (kron)
+    hipLaunchKernelGGL(norm_pair_kernel<true>, dim3(grid), dim3(256), 0, s, X, YB, rows, N, H, h->norm, g, xh, rs,
+                       h->fc.hact_p[0], h->fc.hact_ld[0], h->act);
+  else
+    hipLaunchKernelGGL(norm_pair_kernel<false>, dim3(grid), dim3(256), 0, s, X, YB, rows, N, H, h->norm, g, xh, rs,
+                       static_cast<const float*>(nullptr), int64_t(0), h->act);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// Z0 = X W0^T + b0 [N, H] (the forward keeps only P Z0 + ...): what every adjoint of s = P Z0 + res(X) pairs with
+int ext_z0(lgnn_ctx* h, hipStream_t s) {
+  const int64_t N = h->N, H = h->dims[1], F = h->dims[0];
+  LGNN_CALL(h->ws.adj_z0.reserve(size_t(N) * H * 4));
+  GemmEpilogue eb0;
+  eb0.bias = h->b[0];
+  LGNN_CALL(launch_gemm(h->fc.lin_in_p[0], h->fc.lin_in_ld[0], h->Wt[0].as<float>(), H, h->ws.adj_z0.as<float>(), H, N, F, H,
+                        eb0, s));
+  return 0;
+}
+
+// Kronecker posterior, GCN with res / norm: kfac_adjgrad_batch's chain with the norm's row-local backward between the mask and
+// P^T, the res block's B (gamma_Br; u = the gradient at s) and the adjoint of s through the LayerNorm statistics.  All N rows,
+// unfused kernels (the configurations that use it are graphs of a few hundred to a few thousand nodes).
+int kfac_adjgrad_batch_ext(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, bool fork_exact, const float* gamma_B0,
+                           const float* gamma_B1, const float* gamma_Br, float loss_scale, float* grad_P, float* out_bar,
+                           const int32_t* cand_a, const int32_t* cand_b, int64_t K, float* grad_cand, hipStream_t s) {
+  LGNN_CALL(check_model_ext(h));
+  LGNN_REQUIRE(!h->has_res || gamma_Br, "res=True: gamma_B needs a third entry (the res.0 block)");
+  LGNN_CALL(forward_ensure(h, s));
+  LGNN_CALL(ensure_wt(h, s));
+  LGNN_CALL(forward_input_view(h, s));
+  const int64_t N = h->N, C = h->dims[2], H = h->dims[1], CC = C * C;
+  const bool ln = h->norm == LGNN_NORM_LAYER;
+  LGNN_CALL(batch_prologue(h, idx, y, M, true, fork_exact, nullptr, s));
+  LGNN_CALL(ext_z0(h, s));
+  const float* Z0 = h->ws.adj_z0.as<float>();
+  LGNN_CALL(h->ws.top.reserve(size_t(N) * CC * 4 + 16));
+  LGNN_CALL(h->ws.active.reserve(size_t(N)));
+  float* g1 = h->ws.top.as<float>();
+  hipLaunchKernelGGL(seed_planes_kernel, dim3(unsigned(cdiv(N, 4))), dim3(256), 0, s, h->PT.rowptr, h->PT.col, h->PT.val, N, C,
+                     h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), g1, h->ws.active.as<uint8_t>());
+  LGNN_HIP_CHECK(hipGetLastError());
+  LGNN_CALL(h->ws.jac.reserve(size_t(M) * CC * 4));  // Vbar [M][C][C]
+  float* vbar = h->ws.jac.as<float>();
+  const int64_t per_class = N * (4 * H + C) * 4;
+  const int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(C, h->ws_limit / std::max<int64_t>(per_class, 1)));
+  LGNN_CALL(h->ws.planes_a.reserve(size_t(cc_max) * N * 2 * H * 4));
+  LGNN_CALL(h->ws.planes_b.reserve(size_t(cc_max) * N * (2 * H + C) * 4));
+  h->ws.planes_a_zero_ptr = nullptr;
+  for (int64_t c0 = 0; c0 < C; c0 += cc_max) {
+    const int64_t cc = std::min(cc_max, C - c0);
+    float* DN = h->ws.planes_a.as<float>();   // mask * (g1 W1); later the adjoint of s through the norm's statistics
+    float* U = DN + cc_max * N * H;           // u = norm_bwd(dn)
+    float* UB = h->ws.planes_b.as<float>();   // g0, then ubar, then dn_bar
+    float* G0B = UB + cc_max * N * H;
+    float* G1B = G0B + cc_max * N * H;
+    const float* g1c = g1 + c0 * N * C;
+    GemmEpilogue ep;
+    ep.hact = h->fc.hact_p[0]; ep.hact_ld = h->fc.hact_ld[0]; ep.act = h->act; ep.hact_row_mod = N;
+    LGNN_CALL(launch_gemm(g1c, C, h->W[1], H, DN, H, cc * N, C, H, ep, s));
+    LGNN_HIP_CHECK(hipMemcpyAsync(U, DN, size_t(cc) * N * H * 4, hipMemcpyDeviceToDevice, s));
+    if (h->norm != LGNN_NORM_NONE) LGNN_CALL(launch_resnorm_backward(h, 0, U, H, cc * N, nullptr, false, s));
+    SpmmArgs sa{};
+    sa.rowptr = h->PT.rowptr; sa.col = h->PT.col; sa.val = h->PT.val; sa.nrows = N;
+    sa.in = U; sa.in_ld = H; sa.in_plane_stride = N * H; sa.out = UB; sa.out_ld = H; sa.out_plane_stride = N * H;
+    sa.width = H; sa.out_act = -1;
+    LGNN_CALL(launch_spmm_ex(sa, cc, s));                                          // g0 = P^T u
+    LGNN_CALL(sgemm_rm(s, cc * N, H, H, 2.f, UB, H, gamma_B0, H, 0.f, G0B, H));    // g0bar = 2 g0 Gamma_B0
+    LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, U, H, N * H, G0B, H, N * H, H, cc, grad_P, s));
+    LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, U, H, N * H, G0B, H, N * H, H, cc, nullptr, grad_cand, s));
+    SpmmArgs sb{};
+    sb.rowptr = h->P.rowptr; sb.col = h->P.col; sb.val = h->P.val; sb.nrows = N;
+    sb.in = G0B; sb.in_ld = H; sb.in_plane_stride = N * H; sb.out = UB; sb.out_ld = H; sb.out_plane_stride = N * H;
+    sb.width = H; sb.out_act = -1;
+    LGNN_CALL(launch_spmm_ex(sb, cc, s));                                          // ubar = P g0bar
+    if (h->has_res) LGNN_CALL(sgemm_rm(s, cc * N, H, H, 2.f, U, H, gamma_Br, H, 1.f, UB, H));  // + 2 u Gamma_Br
+    LGNN_CALL(launch_norm_pair(h, true, DN, UB, cc * N, s));                       // UB = dn_bar, DN = s_bar (LayerNorm)
+    if (ln) {
+      LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, DN, H, N * H, Z0, H, 0, H, cc, grad_P, s));
+      LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, DN, H, N * H, Z0, H, 0, H, cc, nullptr, grad_cand, s));
+    }
+    // g1bar = dn_bar W1^T + 2 g1 Gamma_B1     [cc * N, C]
+    LGNN_CALL(sgemm_rm(s, cc * N, C, H, 1.f, UB, H, h->Wt[1].as<float>(), C, 0.f, G1B, C));
+    LGNN_CALL(sgemm_rm(s, cc * N, C, C, 2.f, g1c, C, gamma_B1, C, 1.f, G1B, C));
+    hipLaunchKernelGGL(sddmm_seed_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), 0, s, h->P.rowptr, h->P.col, idx, M, N, C,
+                       h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), G1B, c0, cc, grad_P);
+    LGNN_HIP_CHECK(hipGetLastError());
+    if (K > 0)
+      hipLaunchKernelGGL(sddmm_coo_seed_kernel, dim3(unsigned(cdiv(K, 4))), dim3(256), 0, s, cand_a, cand_b, K, N, C,
+                         h->ws.pos.as<int32_t>(), h->ws.seeds.as<float>(), G1B, c0, cc, grad_cand);
+    hipLaunchKernelGGL(seed_adjoint_gather_kernel, dim3(unsigned(cdiv(M * cc * C, 256))), dim3(256), 0, s, h->P.rowptr,
+                       h->P.col, h->P.val, idx, M, N, C, G1B, c0, cc, vbar);
+    LGNN_HIP_CHECK(hipGetLastError());
+  }
+  LGNN_REQUIRE(size_t(4) * 8 * C * 4 <= 64 * 1024, "too many classes for the seed adjoint kernel");
+  hipLaunchKernelGGL(seed_adjoint_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), size_t(4) * 8 * C * 4, s,
+                     h->fc.out.as<float>(), h->ws.probs.as<float>(), idx, static_cast<const int64_t*>(y), M, N, C, vbar,
+                     fork_exact ? 1 : 0, loss_scale, out_bar);
+  LGNN_HIP_CHECK(hipGetLastError());
+  LGNN_CALL(batch_epilogue(h, idx, M, s));
+  return 0;
+}
+
+// Diagonal posterior, GCN with res / norm (no closed form of the diagonal GGN with a LayerNorm between the layers):
+//     d sum_p gamma_p H_p = sum_n <K_n, d Lambda_n> + sum_{n,c} <R_n[c, :], d J_n[c, :]>,   K_n = J_n diag(gamma) J_n^T,
+//     R_n = 2 Lambda_n J_n diag(gamma)
+// (laplace/curvature/curvature.py:412-432 with the fork's attached Jacobians, :89-130).  <R, d grad_theta f_{n,c}> = the
+// derivative of the directional derivative of f_{n,c} along the parameter direction R: per (sample, class) plane one tangent
+// forward pass with the weights replaced by R's blocks, then its reverse pass.  Chunks of samples under the workspace cap.
+int diag_adjgrad_batch_ext(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, const float* gamma, float loss_scale,
+                           float* grad_P, float* out_bar, float* h1_bar, const int32_t* cand_a, const int32_t* cand_b,
+                           int64_t K, float* grad_cand, hipStream_t s) {
+  LGNN_CALL(check_model_ext(h));
+  LGNN_REQUIRE(M > 0 && idx && y && gamma && grad_P && out_bar && h1_bar, "empty batch or null pointers");
   LGNN_REQUIRE(K == 0 || (cand_a && cand_b && grad_cand), "candidate pairs without their buffers");
-  LGNN_CALL(check_model(h));
+  LGNN_CALL(forward_ensure(h, s));
+  LGNN_CALL(ensure_wt(h, s));
+  LGNN_CALL(forward_input_view(h, s));
+  const int64_t N = h->N, C = h->dims[2], H = h->dims[1], F = h->dims[0], P = h->n_params;
+  const bool ln = h->norm == LGNN_NORM_LAYER, nrm = h->norm != LGNN_NORM_NONE;
+  const int64_t oW0 = 0, ob0 = H * F, oW1 = ob0 + H, ob1 = oW1 + C * H, oR0 = ob1 + C, or0 = oR0 + H * F;
+  LGNN_REQUIRE(P == (h->has_res ? or0 + H : oR0), "internal: parameter count");
+  LGNN_REQUIRE(size_t(C * C + C + 4) * 4 <= 64 * 1024, "too many classes");
+  LGNN_CALL(ext_z0(h, s));
+  const float* Z0 = h->ws.adj_z0.as<float>();
+  const float* X = h->fc.lin_in_p[0];
+  const int64_t ldx = h->fc.lin_in_ld[0];
+  // per sample: J and R rows, three [C][N][H] plane sets + [C][N][C], and the Jacobian pass's own two plane sets
+  const int64_t per_sample = C * (2 * P + N * (3 * H + C) + 2 * N * std::max(H, C)) * 4;
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(M, h->ws_limit / std::max<int64_t>(per_sample, 1)));
+  LGNN_REQUIRE(chunk * C < (int64_t(1) << 31), "diag adjacency gradient: chunk too large");
+  LGNN_CALL(h->ws.jac.reserve(size_t(chunk) * C * P * 4));
+  LGNN_CALL(h->ws.adj_dir.reserve(size_t(chunk) * C * P * 4));
+  LGNN_CALL(h->ws.probs.reserve(size_t(chunk) * C * 4));
+  LGNN_CALL(h->ws.planes_c.reserve(size_t(chunk) * C * N * (3 * H + C) * 4));
+  float* J = h->ws.jac.as<float>();
+  float* R = h->ws.adj_dir.as<float>();
+  float* probs = h->ws.probs.as<float>();
+  const int64_t* yy = static_cast<const int64_t*>(y);
+  for (int64_t m0 = 0; m0 < M; m0 += chunk) {
+    const int64_t mc = std::min(chunk, M - m0);
+    const int64_t Q = mc * C;
+    LGNN_CALL(jacobians(h, idx + m0, mc, J, nullptr, s));
+    hipLaunchKernelGGL(diag_ext_sample_kernel, dim3(unsigned(mc)), dim3(256), size_t(C * C + C + 4) * 4, s, idx + m0, yy + m0, N,
+                       C, P, J, gamma, h->fc.out.as<float>(), loss_scale, probs, out_bar);
+    hipLaunchKernelGGL(diag_ext_direction_kernel, dim3(unsigned(std::min<int64_t>(cdiv(mc * P, 256), 8192))), dim3(256), 0, s, J,
+                       gamma, probs, mc, C, P, R);
+    LGNN_HIP_CHECK(hipGetLastError());
+    float* Z0d = h->ws.planes_c.as<float>();  // [Q][N][H] tangent of Z0
+    float* Sd = Z0d + Q * N * H;              // tangent of s; later the adjoint of s through the norm's statistics
+    float* Hd = Sd + Q * N * H;               // tangent of H1; later nbar, then the adjoint of sdot
+    float* Z1d = Hd + Q * N * H;              // [Q][N][C] tangent of Z1
+    const unsigned gq = unsigned(std::min<int64_t>(cdiv(Q * N * H, 256), 16384));
+    // tangent forward: Z0dot = X dW0^T + db0;  sdot = P Z0dot (+ X dR0^T + dr0);  H1dot = mask * norm_tangent(sdot);
+    //                  Z1dot = H1dot W1^T + H1 dW1^T + db1
+    LGNN_CALL(sgemm_rm_nt_shared(s, N, H, F, X, ldx, R + oW0, P, 0.f, Z0d, N * H, Q));
+    hipLaunchKernelGGL(plane_bias_kernel, dim3(gq), dim3(256), 0, s, Z0d, N, H, R + ob0, P, Q * N * H);
+    LGNN_HIP_CHECK(hipGetLastError());
+    SpmmArgs sa{};
+    sa.rowptr = h->P.rowptr; sa.col = h->P.col; sa.val = h->P.val; sa.nrows = N;
+    sa.in = Z0d; sa.in_ld = H; sa.in_plane_stride = N * H; sa.out = Sd; sa.out_ld = H; sa.out_plane_stride = N * H;
+    sa.width = H; sa.out_act = -1;
+    LGNN_CALL(launch_spmm_ex(sa, Q, s));
+    if (h->has_res) {
+      LGNN_CALL(sgemm_rm_nt_shared(s, N, H, F, X, ldx, R + oR0, P, 1.f, Sd, N * H, Q));
+      hipLaunchKernelGGL(plane_bias_kernel, dim3(gq), dim3(256), 0, s, Sd, N, H, R + or0, P, Q * N * H);
+      LGNN_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(norm_tangent_kernel, dim3(unsigned(std::min<int64_t>(cdiv(Q * N, 4), 65536))), dim3(256), 0, s, Sd, Hd,
+                       Q * N, N, H, h->norm, nrm ? h->norm_w[0] : static_cast<const float*>(nullptr),
+                       nrm ? h->fc.xhat[0].as<float>() : static_cast<const float*>(nullptr),
+                       nrm ? h->fc.rstd[0].as<float>() : static_cast<const float*>(nullptr), h->fc.hact_p[0], h->fc.hact_ld[0],
+                       h->act);
+    LGNN_HIP_CHECK(hipGetLastError());
+    LGNN_CALL(sgemm_rm(s, Q * N, C, H, 1.f, Hd, H, h->Wt[1].as<float>(), C, 0.f, Z1d, C));
+    LGNN_CALL(sgemm_rm_nt_shared(s, N, C, H, h->fc.hact_p[0], h->fc.hact_ld[0], R + oW1, P, 1.f, Z1d, N * C, Q));
+    hipLaunchKernelGGL(plane_bias_kernel, dim3(unsigned(std::min<int64_t>(cdiv(Q * N * C, 256), 16384))), dim3(256), 0, s, Z1d, N,
+                       C, R + ob1, P, Q * N * C);
+    LGNN_HIP_CHECK(hipGetLastError());
+    // reverse: the row of n_q
+    LGNN_HIP_CHECK(hipMemsetAsync(Hd, 0, size_t(Q) * N * H * 4, s));
+    hipLaunchKernelGGL(diag_ext_row_kernel, dim3(unsigned(cdiv(Q, 4))), dim3(256), 0, s, idx + m0, Q, N, C, H, h->P.rowptr,
+                       h->P.col, h->P.val, Z1d, h->W[1], R + oW1, P, h->fc.hact_p[0], h->fc.hact_ld[0], h->act, Hd, h1_bar,
+                       grad_P);
+    if (K > 0)
+      hipLaunchKernelGGL(diag_ext_cand_kernel, dim3(unsigned(cdiv(K * Q, 256))), dim3(256), 0, s, cand_a, cand_b, K, idx + m0, Q,
+                         N, C, Z1d, grad_cand);
+    LGNN_HIP_CHECK(hipGetLastError());
+    LGNN_CALL(launch_norm_pair(h, false, Sd, Hd, Q * N, s));  // Hd = adjoint of sdot, Sd = adjoint of s (LayerNorm)
+    LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, Hd, H, N * H, Z0d, H, N * H, H, Q, grad_P, s));
+    LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, Hd, H, N * H, Z0d, H, N * H, H, Q, nullptr, grad_cand, s));
+    if (ln) {
+      LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, Sd, H, N * H, Z0, H, 0, H, Q, grad_P, s));
+      LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, Sd, H, N * H, Z0, H, 0, H, Q, nullptr, grad_cand, s));
+    }
+  }
+  h->ws.planes_a_zero_ptr = nullptr;
+  return 0;
+}
+}  // namespace
+
+int kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags, const float* gamma_B0,
+                       const float* gamma_B1, const float* gamma_Br, float loss_scale, float* grad_P, float* out_bar,
+                       const int32_t* cand_a, const int32_t* cand_b, int64_t K, float* grad_cand, hipStream_t s) {
+  LGNN_REQUIRE(K == 0 || (cand_a && cand_b && grad_cand), "candidate pairs without their buffers");
   LGNN_REQUIRE(M > 0 && idx && y && gamma_B0 && gamma_B1 && grad_P && out_bar, "empty batch or null pointers");
+  if (h->extras())
+    return kfac_adjgrad_batch_ext(h, idx, y, M, (flags & LGNN_FLAG_FORK_EXACT_SEED) != 0, gamma_B0, gamma_B1, gamma_Br,
+                                  loss_scale, grad_P, out_bar, cand_a, cand_b, K, grad_cand, s);
+  LGNN_CALL(check_model(h));
   LGNN_CALL(forward_ensure_aux(h, s));  // act'(h_1) is part of the auxiliary forward products
   LGNN_CALL(ensure_wt(h, s));
   const int64_t N = h->N, C = h->dims[2], H = h->dims[1], CC = C * C;
@@ -1453,6 +1905,8 @@ int diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
                        float* grad_P, float* out_bar, float* h1_bar, float* e_bar, const int32_t* cand_a, const int32_t* cand_b,
                        int64_t K, float* grad_cand, hipStream_t s) {
   LGNN_REQUIRE(K == 0 || (cand_a && cand_b && grad_cand), "candidate pairs without their buffers");
+  if (h->extras())  // res / norm: no closed form, (sample, class) planes (e_bar stays untouched)
+    return diag_adjgrad_batch_ext(h, idx, y, M, gamma, loss_scale, grad_P, out_bar, h1_bar, cand_a, cand_b, K, grad_cand, s);
   LGNN_CALL(check_model(h));
   LGNN_REQUIRE(h->kind == LGNN_KIND_GCN, "adjacency gradient, diagonal posterior: GCN models");
   LGNN_REQUIRE(M > 0 && idx && y && gamma && grad_P && out_bar && h1_bar && e_bar, "empty batch or null pointers");
@@ -1503,7 +1957,8 @@ int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0, con
                    float* grad_P, float* grad_adj, const int32_t* cand_a, const int32_t* cand_b, int64_t K, float* grad_cand,
                    float* grad_cand_adj, hipStream_t s, const float* h1_bar, const float* e_bar) {
   LGNN_REQUIRE(K == 0 || (cand_a && cand_b && grad_cand && grad_cand_adj), "candidate pairs without their buffers");
-  LGNN_CALL(check_model(h));
+  if (h->extras()) LGNN_CALL(check_model_ext(h));
+  else LGNN_CALL(check_model(h));
   LGNN_REQUIRE(out_bar && (gamma_A1 || (h1_bar && e_bar)) && grad_P && grad_adj, "null pointers");
   LGNN_REQUIRE(!(h1_bar || e_bar) || h->kind == LGNN_KIND_GCN, "adjacency gradient, diagonal posterior: GCN models");
   if (h->kind == LGNN_KIND_SAGE) {
@@ -1535,9 +1990,13 @@ int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0, con
                        N * H);
     LGNN_HIP_CHECK(hipGetLastError());
   }
-  hipLaunchKernelGGL(relu_mask_inplace_kernel, dim3(unsigned(std::min<int64_t>(cdiv(N * H, 256), 4096))), dim3(256), 0, s,
-                     Hb, h->fc.hact_p[0], N * H);
-  LGNN_HIP_CHECK(hipGetLastError());
+  if (h->extras()) {  // s_bar = norm_bwd(mask * H1bar): the mask and the norm's row-local backward (resnorm.hip)
+    LGNN_CALL(launch_resnorm_backward(h, 0, Hb, H, N, nullptr, true, s));
+  } else {
+    hipLaunchKernelGGL(relu_mask_inplace_kernel, dim3(unsigned(std::min<int64_t>(cdiv(N * H, 256), 4096))), dim3(256), 0, s,
+                       Hb, h->fc.hact_p[0], N * H);
+    LGNN_HIP_CHECK(hipGetLastError());
+  }
   GemmEpilogue eb0;
   eb0.bias = h->b[0];
   LGNN_CALL(launch_gemm(h->fc.lin_in_p[0], h->fc.lin_in_ld[0], h->Wt[0].as<float>(), H, Z, H, N, F, H, eb0, s));
@@ -1582,8 +2041,8 @@ extern "C" int lgnn_kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const vo
                                        const int32_t* cand_a, const int32_t* cand_b, int64_t num_cand, float* grad_cand,
                                        void* stream) {
   if (!h || !gamma_B) { lgnn::set_error("null argument"); return 2; }
-  return lgnn::kfac_adjgrad_batch(h, idx, y, M, flags, gamma_B[0], gamma_B[1], loss_scale, grad_P, out_bar, cand_a, cand_b,
-                                  num_cand, grad_cand, static_cast<hipStream_t>(stream));
+  return lgnn::kfac_adjgrad_batch(h, idx, y, M, flags, gamma_B[0], gamma_B[1], h->has_res ? gamma_B[2] : nullptr, loss_scale,
+                                  grad_P, out_bar, cand_a, cand_b, num_cand, grad_cand, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* const* gamma_A, float a_scale,

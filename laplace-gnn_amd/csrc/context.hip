@@ -339,7 +339,7 @@ extern "C" void lgnn_destroy(lgnn_ctx* h) {
   if (getenv("LGNN_PHASE_REPORT")) lgnn::paths_phase_report();
 #endif
   DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
-                    &h->fc.out, &h->fc.tmp, &h->fc.res_out, &h->fc.pre_norm, &h->ws.planes_c, &h->ws.path_coef, &h->ws.path_up, &h->ws.path_bg, &h->ws.path_alpha, &h->ws.path_cnt, &h->ws.path_rptr, &h->ws.path_rm, &h->ws.path_rw, &h->ws.path_zeros, &h->ws.path_pcnt, &h->ws.path_pptr, &h->ws.path_pm, &h->ws.path_pv, &h->ws.path_pw, &h->ws.path_flags, &h->ws.path_nodes, &h->ws.path_nnodes, &h->fc.rowsum, &h->fc.dact0, &h->fc.Xpad, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult, &h->ws.planes_a,
+                    &h->fc.out, &h->fc.tmp, &h->fc.res_out, &h->fc.pre_norm, &h->ws.planes_c, &h->ws.path_coef, &h->ws.path_up, &h->ws.path_bg, &h->ws.path_alpha, &h->ws.adj_z0, &h->ws.adj_dir, &h->ws.path_cnt, &h->ws.path_rptr, &h->ws.path_rm, &h->ws.path_rw, &h->ws.path_zeros, &h->ws.path_pcnt, &h->ws.path_pptr, &h->ws.path_pm, &h->ws.path_pv, &h->ws.path_pw, &h->ws.path_flags, &h->ws.path_nodes, &h->ws.path_nnodes, &h->fc.rowsum, &h->fc.dact0, &h->fc.Xpad, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult, &h->ws.planes_a,
                     &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->long_rows, &h->long_slot, &h->long_tasks, &h->hub, &h->long_rows_fwd, &h->top_multi, &h->top_tasks, &h->top_task_count, &h->top_cnt, &h->top_offs, &h->top_hub_tiles, &h->ws.top, &h->ws.flags, &h->ws.out_flags, &h->ws.out_list, &h->ws.out_count, &h->ws.val_act2, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (DevBuf* b : bufs) b->release();
   for (int l = 0; l < kMaxLayers; ++l) {
@@ -416,7 +416,7 @@ extern "C" int64_t lgnn_device_bytes(const lgnn_ctx* h) {
   if (!h) return -1;
   size_t t = 0;
   const DevBuf* bufs[] = {&h->A_rowptr, &h->A_col, &h->AT_rowptr, &h->AT_col, &h->val_fwd, &h->val_bwd, &h->deg_scale,
-                          &h->fc.out, &h->fc.tmp, &h->fc.res_out, &h->fc.pre_norm, &h->ws.planes_c, &h->ws.path_coef, &h->ws.path_up, &h->ws.path_bg, &h->ws.path_alpha, &h->ws.path_cnt, &h->ws.path_rptr, &h->ws.path_rm, &h->ws.path_rw, &h->ws.path_zeros, &h->ws.path_pcnt, &h->ws.path_pptr, &h->ws.path_pm, &h->ws.path_pv, &h->ws.path_pw, &h->ws.path_flags, &h->ws.path_nodes, &h->ws.path_nnodes, &h->fc.rowsum, &h->fc.dact0, &h->fc.Xpad, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult,
+                          &h->fc.out, &h->fc.tmp, &h->fc.res_out, &h->fc.pre_norm, &h->ws.planes_c, &h->ws.path_coef, &h->ws.path_up, &h->ws.path_bg, &h->ws.path_alpha, &h->ws.adj_z0, &h->ws.adj_dir, &h->ws.path_cnt, &h->ws.path_rptr, &h->ws.path_rm, &h->ws.path_rw, &h->ws.path_zeros, &h->ws.path_pcnt, &h->ws.path_pptr, &h->ws.path_pm, &h->ws.path_pv, &h->ws.path_pw, &h->ws.path_flags, &h->ws.path_nodes, &h->ws.path_nnodes, &h->fc.rowsum, &h->fc.dact0, &h->fc.Xpad, &h->ws.pos, &h->ws.seeds, &h->ws.probs, &h->ws.mult,
                           &h->ws.planes_a, &h->ws.planes_b, &h->ws.misc, &h->ws.jac, &h->long_rows, &h->long_slot, &h->long_tasks, &h->hub, &h->long_rows_fwd, &h->top_multi, &h->top_tasks, &h->top_task_count, &h->top_cnt, &h->top_offs, &h->top_hub_tiles, &h->ws.top, &h->ws.flags, &h->ws.out_flags, &h->ws.out_list, &h->ws.out_count, &h->ws.val_act2, &h->ws.active, &h->ws.val_act, &h->ws.act_list, &h->ws.act_count, &h->ws.select_tmp};
   for (const DevBuf* b : bufs) t += b->bytes;
   for (int l = 0; l < kMaxLayers; ++l)

@@ -121,7 +121,9 @@ struct Workspace {
   // (the list's capacity is max(4 nnz, 4 M entries); a batch whose list is longer takes the enumerating route on the device)
   bool path_zeros_set = false;
   DevBuf gram_scratch_res[kMaxLayers];  // res / norm models: per-call partial B of res.{l} (GCN; GraphSAGE shares the conv's)
-  DevBuf planes_c;  // GCN with res, >= 3 layers: u_l Wr_l of the level being computed
+  DevBuf planes_c;  // GCN with res, >= 3 layers: u_l Wr_l of the level being computed; adjacency gradient (diag, res / norm): tangent planes
+  DevBuf adj_z0;    // adjacency gradient of res / norm models: Z0 = X W0^T + b0 [N, H]
+  DevBuf adj_dir;   // the same, diagonal posterior: parameter directions R [chunk, C, P]
 };
 
 }  // namespace lgnn

@@ -422,7 +422,8 @@ def make_regression_mlp(ns, torch):
 
 
 def make_structure_loop(ns, torch, name, structure, seed, symmetric, grad_norm, lr_adj, momentum, weight_decay, sign_grad=False,
-                        masked=False, steps=3, n=64, f=12, h=8, c=3, n_edges=150, n_train=33, batch_size=12, prior=1.0):
+                        masked=False, steps=3, n=64, f=12, h=8, c=3, n_edges=150, n_train=33, batch_size=12, prior=1.0,
+                        norm=None, res=False):
     """The fork's structure-learning loop itself (gnn/marglik_training.py:197-224): fit, neg_marglik.backward(), optional
     clip_grad_norm_ on the adjacency (:213-215), ``adj_optimizer.step()`` (SGD with momentum and weight decay, :97-99), refit --
     ``steps`` times, run by the reference's own STEGCN (gnn/models/models.py:65-118, BinarizeSTE gnn/models/utils.py:42-86) and
@@ -440,8 +441,16 @@ def make_structure_loop(ns, torch, name, structure, seed, symmetric, grad_norm, 
     train_y = torch.randint(0, c, (n_train,), generator=g)
     loader = DataLoader(TensorDataset(train_idx, train_y), batch_size=batch_size, shuffle=False)
     torch.manual_seed(seed)
+    extras = dict(norm=norm, res=res) if (norm is not None or res) else {}  # the WebKB / Circle configurations
     ste = ns.gnn_models.STEGCN(f, h, c, 2, X, adj0.clone(), dropout_p=0.5, threshold=0.5, symmetric=symmetric,
-                               sign_grad=sign_grad, train_masked_update=masked, train_nodes=train_idx if masked else None)
+                               sign_grad=sign_grad, train_masked_update=masked, train_nodes=train_idx if masked else None,
+                               **extras)
+    if norm is not None:
+        gn = torch.Generator().manual_seed(seed + 1000)
+        with torch.no_grad():
+            for nm in ste.norms:
+                nm.weight.copy_(0.5 + torch.rand(h, generator=gn))
+                nm.bias.copy_(0.3 * torch.randn(h, generator=gn))
     ste.eval()
     out = {"kind": "gcn", "symmetric": symmetric, "num_nodes": n, "batch_size": batch_size, "edge_index": ei.numpy(),
            "X": X.numpy(), "train_idx": train_idx.numpy(), "train_y": train_y.numpy(), "num_layers": 2,
@@ -451,6 +460,14 @@ def make_structure_loop(ns, torch, name, structure, seed, symmetric, grad_norm, 
     for l, conv in enumerate(ste.convs):
         out[f"W{l}"] = conv.lin.weight.detach().numpy().copy()
         out[f"b{l}"] = conv.lin.bias.detach().numpy().copy()
+    if extras:
+        out["norm"], out["res"] = str(norm), bool(res)
+        for l, lin in enumerate(ste.res):
+            out[f"Wr{l}"], out[f"br{l}"] = lin.weight.detach().numpy().copy(), lin.bias.detach().numpy().copy()
+        if norm is not None:
+            out["norm_eps"] = np.float64(ste.norms[0].eps)
+            for l, nm in enumerate(ste.norms):
+                out[f"norm_w{l}"], out[f"norm_b{l}"] = nm.weight.detach().numpy().copy(), nm.bias.detach().numpy().copy()
     out["adj_init"] = ste.adj.detach().numpy().copy()  # (symmetrised 0/1 with the GCN's self loops)
     bl = ns.baselaplace
     cls = bl.KronLaplace if structure == "kron" else bl.DiagLaplace
@@ -559,6 +576,13 @@ def main():
         "steloop_diag_sym": dict(structure="diag", seed=62, symmetric=True, grad_norm=True, lr_adj=8.0, momentum=0.9,
                                  weight_decay=5e-4),
     }
+    # Cornell / Texas / Wisconsin (gnn/configs/original/stegcn_config.yaml:54-105): diag + res + LayerNorm, symmetric,
+    # momentum 0.9, weight decay 5e-4 on the adjacency, clipped gradient; Circle (:129-145): LayerNorm only.  (seeds: the
+    # first of 50..65 whose continuous values stay >= 4e-4 away from the threshold over the three steps)
+    loops["steloop_diag_resln_sym"] = dict(structure="diag", seed=55, symmetric=True, grad_norm=True, lr_adj=10.0, momentum=0.9,
+                                           weight_decay=5e-4, norm="layer", res=True)
+    loops["steloop_kron_ln_sym"] = dict(structure="kron", seed=55, symmetric=True, grad_norm=True, lr_adj=5.0, momentum=0.9,
+                                        weight_decay=2e-3, norm="layer")
     # (sign_grad=True is not covered: BinarizeSTE.backward takes the sign of the gradient of EVERY forward call -- the Kronecker
     #  graph and the loss forward of each batch -- and autograd sums those signs, values in {-3 .. 3} with three batches; the
     #  HIP path accumulates one gradient and refuses the option)

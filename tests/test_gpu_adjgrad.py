@@ -232,3 +232,65 @@ def test_diag_adjacency_gradient_is_refused_for_graphsage():
     la.fit(loader)
     with pytest.raises(NotImplementedError, match="GCN"):
         la.neg_marglik_adj_grad(loader)
+
+
+@pytest.mark.parametrize("structure", ["kron", "diag"])
+@pytest.mark.parametrize("norm,res,sym,H", [("layer", True, True, 64), ("layer", False, False, 33), ("batch", True, False, 32),
+                                            (None, True, True, 16)])
+def test_adjacency_gradient_of_res_norm_models_midsize_vs_oracle(norm, res, sym, H, structure):
+    """``res=True`` / ``norm="layer"|"batch"`` (gnn/models/base_gnn.py:141-149; the STE-GCN configurations of the WebKB graphs
+    and Circle, gnn/configs/original/stegcn_config.yaml:54-105, 129-145) at a WebKB-like size: several plane chunks under a
+    small workspace cap, repeated node ids, non-trivial norm state, candidates against the oracle's dense gradient."""
+    import laplace_gnn_amd as lg
+
+    N, F, C, E, M = 400, 48, 5, 1500, 90
+    gen = torch.Generator().manual_seed(23)
+    ei = torch.randint(0, N, (2, E), generator=gen)
+    X = torch.randn(N, F, generator=gen)
+    torch.manual_seed(4)
+    model = lg.GCN(F, H, C, 2, X, ei, symmetric=sym, norm=norm, res=res)
+    extras = {}
+    with torch.no_grad():
+        if norm is not None:
+            nm = model.norms[0]
+            nm.weight.copy_(0.5 + torch.rand(H, generator=gen))
+            nm.bias.copy_(0.3 * torch.randn(H, generator=gen))
+            extras.update(norm=norm, norm_weight=[nm.weight.numpy().copy()], norm_bias=[nm.bias.numpy().copy()],
+                          norm_eps=float(nm.eps))
+            if norm == "batch":
+                nm.running_mean.copy_(0.2 * torch.randn(H, generator=gen))
+                nm.running_var.copy_(0.5 + torch.rand(H, generator=gen))
+                extras.update(norm_mean=[nm.running_mean.numpy().copy()], norm_var=[nm.running_var.numpy().copy()])
+        if res:
+            extras.update(res_weights=[model.res[0].weight.detach().numpy().copy()],
+                          res_biases=[model.res[0].bias.detach().numpy().copy()])
+    model = model.to("cuda").eval()
+    idx = torch.randperm(N, generator=gen)[:M]
+    idx[M // 2:M // 2 + 10] = idx[:10]
+    y = torch.randint(0, C, (M,), generator=gen)
+    loader = lg.TensorBatchLoader(idx.cuda(), y.cuda(), batch_size=40)  # 40 / 40 / 10
+    model.engine.set_workspace_limit(4 << 20)
+    la = lg.Laplace(model, "classification", "all", structure, prior_precision=0.5)
+    la.fit(loader)
+    rows_s, cols_s = model.engine.export_adj()
+    stored = set(zip(rows_s.cpu().tolist(), cols_s.cpu().tolist()))
+    cand = torch.randint(0, N, (2, 200), generator=torch.Generator().manual_seed(5))
+    cand = torch.cat([cand, torch.stack([idx[:30], (idx[:30] + 11) % N])], dim=1)
+    cand = cand[:, torch.tensor([(int(i), int(j)) not in stored and int(i) != int(j) for i, j in cand.t().tolist()])]
+    val0, _, grad0 = la.neg_marglik_adj_grad(loader)
+    val, e2, grad, gc = la.neg_marglik_adj_grad(loader, candidates=cand.cuda())
+    assert abs(float(val0) - float(val)) <= 1e-6 * abs(float(val)) and rel(grad0.cpu().numpy(), grad.cpu().numpy()) < 1e-5
+    Ws = [c.lin.weight.detach().cpu().numpy() for c in model.convs]
+    bs = [c.lin.bias.detach().cpu().numpy() for c in model.convs]
+    om = oracle_from_arrays("gcn", N, ei.numpy(), X.numpy(), Ws, bs, sym, **extras)
+    if structure == "kron":
+        oval, rows, cols, og = O.kron_marglik_adj_grad(om, idx.numpy(), y.numpy(), 40, 0.5, True, sym)
+        _, gd = O.kron_marglik_adj_grad(om, idx.numpy(), y.numpy(), 40, 0.5, True, sym, dense=True)
+    else:
+        oval, rows, cols, og = O.diag_marglik_adj_grad(om, idx.numpy(), y.numpy(), 40, 0.5, sym)
+        _, gd = O.diag_marglik_adj_grad(om, idx.numpy(), y.numpy(), 40, 0.5, sym, dense=True)
+    assert np.array_equal(e2[0].cpu().numpy(), rows) and np.array_equal(e2[1].cpu().numpy(), cols)
+    assert abs(float(val) - oval) <= 5e-6 * abs(oval)
+    assert rel(grad.cpu().numpy(), og) < 1e-4
+    assert rel(gc.cpu().numpy(), gd[cand[0].numpy(), cand[1].numpy()]) < 1e-4
+    model.engine.check_async_errors()

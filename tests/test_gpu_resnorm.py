@@ -106,8 +106,9 @@ def test_jacobians_diag_and_full_with_res_and_norm_vs_oracle(kind, L, norm, res)
 
 
 def test_unsupported_routes_refuse_models_with_res_or_norm():
-    """The adjacency gradient and the matrix-free GLM variance are closed forms of plain 2-layer models: with res / norm
-    bound they must say so (the Laplace front then takes the Jacobian route for the predictive)."""
+    """The matrix-free GLM variance is a closed form of plain 2-layer models, and the adjacency gradient with res / norm covers
+    GCNs (the reference's STEGCN configurations): anything else must say so (the Laplace front then takes the Jacobian route
+    for the predictive)."""
     import laplace_gnn_amd as lg
     from laplace_gnn_amd._lib import HipLibraryError
 
@@ -116,9 +117,11 @@ def test_unsupported_routes_refuse_models_with_res_or_norm():
     one = torch.ones(3, 9, device="cuda")
     with pytest.raises(HipLibraryError, match="res / norm"):
         eng.glm_variance(idx, torch.ones(8, 9, device="cuda"), torch.ones(3, 8, device="cuda"), torch.ones(3, device="cuda"))
+    eng.close()
+    eng, _ = _both("sage", 200, 8, 8, 3, 600, 2, "layer", True, seed=2)
     with pytest.raises(HipLibraryError, match="res / norm"):
         eng.adjgrad_batch(idx, torch.zeros(10, dtype=torch.int64, device="cuda"),
-                          [torch.eye(8, device="cuda"), torch.eye(3, device="cuda")],
+                          [torch.eye(8, device="cuda"), torch.eye(3, device="cuda"), torch.eye(8, device="cuda")],
                           torch.zeros(eng.nnz, device="cuda"), torch.zeros(200, 3, device="cuda"))
     del one
     eng.close()

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from golden_utils import constructor_extras
+
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -75,7 +77,8 @@ def test_update_adjacency_is_bit_exact_against_a_fresh_ingest(kind, sym):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["steloop_kron_sym", "steloop_kron_dir", "steloop_diag_sym"])
+@pytest.mark.parametrize("name", ["steloop_kron_sym", "steloop_kron_dir", "steloop_diag_sym", "steloop_diag_resln_sym",
+                                  "steloop_kron_ln_sym"])
 def test_structure_learning_loop_matches_the_reference(name):
     """Three hyper-steps of the fork's loop: value of the negative log marginal likelihood and ``adj.grad`` of every step,
     the continuous adjacency after every optimizer step (<= 1e-4) and the binarised edge set (bit exact)."""
@@ -89,11 +92,19 @@ def test_structure_learning_loop_matches_the_reference(name):
     cand = (~init).nonzero().t().contiguous()  # EVERY non-edge is tracked: the reference's dense parameter
     train_idx, train_y = torch.from_numpy(g["train_idx"]), torch.from_numpy(g["train_y"])
     model = lg.STEGCN(X.shape[1], int(g["W0"].shape[0]), int(g["W1"].shape[0]), 2, X, ei, threshold=float(g["threshold"]),
-                      symmetric=sym, train_masked_update=bool(g["masked"]), train_nodes=train_idx, candidates=cand)
+                      symmetric=sym, train_masked_update=bool(g["masked"]), train_nodes=train_idx, candidates=cand,
+                      **constructor_extras(g))  # (res / norm: the WebKB and Circle configurations)
     with torch.no_grad():
         for l, conv in enumerate(model.convs):
             conv.lin.weight.copy_(torch.from_numpy(g[f"W{l}"]))
             conv.lin.bias.copy_(torch.from_numpy(g[f"b{l}"]))
+        for l, lin in enumerate(model.res):
+            lin.weight.copy_(torch.from_numpy(g[f"Wr{l}"]))
+            lin.bias.copy_(torch.from_numpy(g[f"br{l}"]))
+        if "norm" in g.files and str(g["norm"]) != "None":
+            for l, nm in enumerate(model.norms):
+                nm.weight.copy_(torch.from_numpy(g[f"norm_w{l}"]))
+                nm.bias.copy_(torch.from_numpy(g[f"norm_b{l}"]))
     model = model.cuda().eval()
     assert model.adj.numel() == N * N - N  # all off-diagonal pairs
     assert torch.equal(model.dense_adj().cpu(), torch.from_numpy(g["adj_init"]))
