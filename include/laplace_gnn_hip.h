@@ -19,12 +19,9 @@
  *       lgnn_check_async_errors                 by design (reports the sticky error flags);
  *       the FIRST KFAC / adjacency-gradient call on a graph, once per graph: the list of rows with
  *         more than 64 stored entries (hubs) and the graph's number of 2-hop paths;
- *       lgnn_kfac_accumulate* on GraphSAGE models of three or more layers, once per batch: the
- *         number of rows the second backward level can reach sizes its gather / GEMM / scatter
- *         (a host-side bound would be N on hub-heavy graphs: 5x the buffers at the products shape);
  *       lgnn_kfac_adjgrad_batch on GraphSAGE models, once per batch: the active-row count sizes a
  *         library GEMM;   lgnn_glm_variance(_mapped), once per call: the size of the rotated-row table.
- *     The headline paths -- 2-layer GCN / GraphSAGE KFAC, diagonal and last-layer GGN, forward,
+ *     Everything else -- KFAC of GCN / GraphSAGE models of any depth, diagonal and last-layer GGN, forward,
  *     Jacobians -- enqueue only; workspaces grow on first use of a shape and are reused after;
  *   - every function returns 0 on success, non-zero on error; the message is available
  *     from lgnn_last_error() (thread-local).  No C++ exception crosses the boundary;
@@ -314,7 +311,12 @@ LGNN_API int lgnn_jacobians(lgnn_ctx* h, const int64_t* idx, int64_t M, float* J
  * its structure learning proposes edges.  cand_a / cand_b int32 [num_cand] list pairs in the propagation matrix's
  * coordinates (entry (i, j) of the adjacency <-> a = j, b = i); grad_cand [num_cand] accumulates like grad_P and
  * lgnn_adjgrad_finish writes grad_cand_adj [num_cand] = d / d adj[i, j] (no symmetrisation: a symmetric model's caller
- * lists both orientations and averages).                                                                        */
+ * lists both orientations and averages).
+ * Models bound with res / norm (lgnn_bind_extras; gnn/models/base_gnn.py:141-149 -- the STE-GCN configurations of Cornell /
+ * Texas / Wisconsin / Circle, gnn/configs/original/stegcn_config.yaml:54-105, 129-145): GCN only.  gamma_B then has one more
+ * entry per hidden layer after the conv entries (the res.{l} blocks, named_parameters order; res=True only); the chain gains
+ * the norm's row-local backward, the res block's B and the adjoint of the pre-norm rows through the LayerNorm statistics.
+ * All N rows, unfused kernels: these configurations are graphs of a few hundred to a few thousand nodes.               */
 LGNN_API int lgnn_kfac_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, uint32_t flags,
                             const float* const* gamma_B /* host array of L device ptrs */, float loss_scale,
                             float* grad_P, float* out_bar, const int32_t* cand_a, const int32_t* cand_b, int64_t num_cand,
@@ -334,7 +336,12 @@ LGNN_API int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float*
  *   once      :  lgnn_diag_adjgrad_finish propagates out_bar, h1_bar and e_bar through the forward pass into grad_P and writes
  *                grad_adj [nnz] / grad_cand_adj exactly like lgnn_adjgrad_finish.
  * Workspace: [chunk][H][F + 1 rounded up to 4] floats for the first-layer tiles of a chunk of samples (0.5 GB for a Cora-shaped
- * batch), under the workspace limit (lgnn_set_workspace_limit); no synchronisation, nothing allocated after the first call.  */
+ * batch), under the workspace limit (lgnn_set_workspace_limit); no synchronisation, nothing allocated after the first call.
+ * Models bound with res / norm (GCN; the shipped WebKB / Circle configurations are exactly diag + res + LayerNorm): no closed
+ * form of the diagonal GGN exists; gamma covers the res.{l} parameters too (after W_1, b_1), e_bar is left untouched, and per
+ * (sample, class) the kernel chain runs one tangent forward pass along R = 2 Lambda J diag(gamma) and its reverse pass
+ * (d sum_p gamma_p H_p = <K, d Lambda> + <R, d J>, K = J diag(gamma) J^T).  Workspace per sample of a chunk: 2 C P floats
+ * (Jacobian rows and directions) + C N (3 H + C) floats of planes -- sized for graphs of a few hundred to a few thousand nodes. */
 LGNN_API int lgnn_diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, const float* gamma,
                             float loss_scale, float* grad_P, float* out_bar, float* h1_bar, float* e_bar,
                             const int32_t* cand_a, const int32_t* cand_b, int64_t num_cand, float* grad_cand, void* stream);

@@ -217,15 +217,28 @@ struct GemmArgs {
   int vecA, vecB;
   const uint8_t* row_active;  // optional, indexed like hact rows: inactive rows are not written
   int64_t k_chunk;            // split-K: blockIdx.z covers [z*k_chunk, (z+1)*k_chunk); 0 = whole K
+  // LIST instance: the rows are the listed nodes of every plane, A and C are planes [plane][plane_rows][.]; the list's
+  // length is read on the device (no host round trip): workgroup blockIdx.x = plane * tiles_per_plane + tile, tiles
+  // beyond the list exit at once
+  const int32_t* row_list; const int32_t* na_dev; int64_t plane_rows; int64_t tiles_per_plane;
 };
 
+template <bool LIST>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ float As[GBM][GBK + 1];  // odd stride: column reads of the A operand are conflict free
   __shared__ float Bs[GBK][GBN];
+  __shared__ int64_t rowsh[LIST ? GBM : 1];  // LIST: A / C row of every tile row (-1: past the end of the list)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int64_t row0 = int64_t(blockIdx.x) * GBM, col0 = int64_t(blockIdx.y) * GBN;
+  const int64_t row0 = LIST ? 0 : int64_t(blockIdx.x) * GBM, col0 = int64_t(blockIdx.y) * GBN;
+  if (LIST) {
+    const int64_t plane = int64_t(blockIdx.x) / g.tiles_per_plane, t0 = (int64_t(blockIdx.x) % g.tiles_per_plane) * GBM;
+    const int64_t na = *g.na_dev;
+    if (t0 >= na) return;
+    if (tid < GBM) rowsh[tid] = t0 + tid < na ? plane * g.plane_rows + g.row_list[t0 + tid] : -1;
+    __syncthreads();
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -243,9 +256,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int r = (tid >> 3) + 32 * it, k4 = (tid & 7) * 4;
-      const int64_t grow = row0 + r;
+      const int64_t grow = LIST ? rowsh[r] : row0 + r;
       float x[4] = {0.f, 0.f, 0.f, 0.f};
-      if (grow < g.R) {
+      if (LIST ? grow >= 0 : grow < g.R) {
         const float* src = g.A + grow * g.lda + k0 + k4;
         if (g.vecA && k4 + 4 <= kvalid) {
           float4 t = *reinterpret_cast<const float4*>(src);
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
   // epilogue.  hact / row_active rows are r % hact_row_mod; rows of a tile are consecutive, so one
   // modulo per workgroup and a conditional subtract per row replace 64 integer divisions per lane
-  const bool wrap = g.hact_row_mod > 0;
+  const bool wrap = !LIST && g.hact_row_mod > 0;
   const int64_t hbase = wrap ? row0 % g.hact_row_mod : row0;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
@@ -308,9 +321,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int lr = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        const int64_t row = row0 + lr;
-        if (row >= g.R) continue;
-        int64_t hr = hbase + lr;
+        const int64_t row = LIST ? rowsh[lr] : row0 + lr;
+        if (LIST ? row < 0 : row >= g.R) continue;
+        int64_t hr = LIST ? row % g.plane_rows : hbase + lr;
         if (wrap) { while (hr >= g.hact_row_mod) hr -= g.hact_row_mod; }
         if (g.row_active && !g.row_active[hr]) continue;
         float v = acc[m][n][r] + bias;
@@ -503,7 +516,29 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float*
     }
   }
   const dim3 grid{unsigned(cdiv(R, GBM)), unsigned(cdiv(Nout, GBN)), splitk};
-  hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, g);
+  hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, s, g);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// C[p][n][:] = A[p][n][:] @ B for the nodes n = list[0 .. *na_dev) of every plane p (planes of `plane_rows` rows); the other
+// rows of C are not touched.  The list's length stays on the device: the grid covers the worst case (all rows listed) and the
+// workgroups past the end leave at once.
+int launch_gemm_listed(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t planes,
+                       int64_t plane_rows, const int32_t* list, const int32_t* na_dev, int64_t K, int64_t Nout,
+                       const GemmEpilogue& ep, hipStream_t s) {
+  if (planes <= 0 || plane_rows <= 0 || Nout <= 0) return 0;
+  LGNN_REQUIRE(K > 0 && list && na_dev, "listed gemm: empty K or no list");
+  LGNN_REQUIRE(ep.row_active == nullptr && ep.bias == nullptr, "listed gemm: plain or activation-derivative epilogue only");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.R = planes * plane_rows; g.K = K; g.Nout = Nout;
+  g.hact = ep.hact; g.hact_ld = ep.hact_ld; g.act = ep.act; g.out_act = ep.out_act;
+  g.vecA = (lda % 4 == 0) && aligned16(A);
+  g.vecB = (ldb % 4 == 0) && aligned16(B);
+  g.row_list = list; g.na_dev = na_dev; g.plane_rows = plane_rows; g.tiles_per_plane = cdiv(plane_rows, GBM);
+  LGNN_REQUIRE(planes * g.tiles_per_plane < (int64_t(1) << 31), "listed gemm: too many row tiles");
+  const dim3 grid{unsigned(planes * g.tiles_per_plane), unsigned(cdiv(Nout, GBN)), 1};
+  hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, s, g);
   LGNN_HIP_CHECK(hipGetLastError());
   return 0;
 }

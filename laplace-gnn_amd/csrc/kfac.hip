@@ -588,22 +588,6 @@ int seed_spmm_gram_launch(lgnn_ctx* h, bool fork_exact, float* g, int64_t cb, in
   return 0;
 }
 
-// out[c][w][:] = in[c][list[w]][:] (gather) resp. out[c][list[w]][:] = in[c][w][:] (scatter); width % 4 == 0
-__global__ void plane_rows_by_list_kernel(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ list,
-                                          int64_t na, int64_t N, int64_t width, int scatter) {
-  const int64_t w4 = width / 4;
-  const int64_t total = na * w4;
-  const int64_t plane = blockIdx.y;
-  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t w = t / w4, q = t - w * w4;
-    const int64_t n = list[w];
-    const float4* src = reinterpret_cast<const float4*>(in + (plane * (scatter ? na : N) + (scatter ? w : n)) * width) + q;
-    float4* dst = reinterpret_cast<float4*>(out + (plane * (scatter ? N : na) + (scatter ? n : w)) * width) + q;
-    *dst = *src;
-  }
-}
-
 // values of P^T with the columns of all-zero source rows removed: the fused SpMM issues no load for them
 __global__ void mask_values_kernel(const int32_t* __restrict__ col, const float* __restrict__ val, int64_t nnz,
                                    const uint8_t* __restrict__ active, const int32_t* __restrict__ pos,
@@ -967,7 +951,6 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
     if (need_pong) LGNN_CALL(h->ws.planes_b.reserve(size_t(cc_max) * N * maxw * 4));
     const bool gcn_res_deep = h->has_res && h->kind == LGNN_KIND_GCN && L > 2;  // dh_l = g_l W_l + u_l Wr_l below the top level
     if (gcn_res_deep) LGNN_CALL(h->ws.planes_c.reserve(size_t(cc_max) * N * maxw * 4));
-    int64_t second_rows = 0;  // GraphSAGE, deeper models: rows the second backward level reads (host copy, per batch)
     for (int64_t c0 = cb; c0 < ce; c0 += cc_max) {
       const int64_t cc = std::min(cc_max, ce - c0);
       const float* g = gtop + c0 * N * C;  // planes [cc][N][dims[l+1]] of layer l
@@ -1059,8 +1042,8 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
           } else {
             // second backward level of a deeper model: g (the level above's output) is non-zero only where that level could
             // write, i.e. on the batch nodes and their neighbours (products shape: 20 % of the rows).  Once per batch: the
-            // flags and the list of those rows, P^T's values with the other columns zeroed (their rows are not gathered
-            // below), and the list's length on the host for the compacted GEMM.
+            // flags and the list of those rows and P^T's values with the other columns zeroed (their rows are not gathered
+            // below); the list's length stays on the device.
             const bool second = l == L - 2 && !no_fuse && h->nnz > 0;
             if (second && c0 == cb) {
               LGNN_CALL(h->ws.out_flags.reserve(size_t(N)));
@@ -1078,26 +1061,15 @@ int kfac_accumulate(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, i
               LGNN_HIP_CHECK(hipGetLastError());
               LGNN_CALL(compact_flags(h->ws.out_flags.as<uint8_t>(), N, h->ws.out_list.as<int32_t>(),
                                       h->ws.out_count.as<int32_t>(), h->ws.select_tmp, s));
-              int32_t na2 = 0;
-              LGNN_HIP_CHECK(hipMemcpyAsync(&na2, h->ws.out_count.p, 4, hipMemcpyDeviceToHost, s));
-              LGNN_HIP_CHECK(hipStreamSynchronize(s));
-              second_rows = na2;
             }
             GemmEpilogue ep;
-            const int64_t na2 = second ? second_rows : N;
-            if (second && dout % 4 == 0 && d % 2 == 0 && na2 > 0 && na2 * 2 < N) {
-              // g W_l on the listed rows only: gather them, one GEMM over cc * na2 rows, scatter into the zeroed planes
-              LGNN_CALL(h->ws.jac.reserve(size_t(cc) * na2 * (dout + 2 * d) * 4));
-              float* ga = h->ws.jac.as<float>();
-              float* gc = ga + cc * na2 * dout;
-              const dim3 gg{unsigned(std::min<int64_t>(cdiv(na2 * dout / 4, 256), 4096)), unsigned(cc)};
-              hipLaunchKernelGGL(plane_rows_by_list_kernel, gg, dim3(256), 0, s, g, ga, h->ws.out_list.as<int32_t>(), na2, N, dout, 0);
-              LGNN_CALL(launch_gemm(ga, dout, h->W[l], 2 * d, gc, 2 * d, cc * na2, dout, 2 * d, ep, s));
+            if (second) {
+              // g W_l on the listed rows only, straight from and into the planes (the kernel gathers the A rows and scatters
+              // the C rows through the list and reads the list's length on the device: no host round trip); the other rows
+              // of dcat are zero
               LGNN_HIP_CHECK(hipMemsetAsync(ping, 0, size_t(cc) * N * 2 * d * 4, s));
-              const dim3 gs{unsigned(std::min<int64_t>(cdiv(na2 * 2 * d / 4, 256), 4096)), unsigned(cc)};
-              hipLaunchKernelGGL(plane_rows_by_list_kernel, gs, dim3(256), 0, s, gc, ping, h->ws.out_list.as<int32_t>(), na2, N,
-                                 2 * d, 1);
-              LGNN_HIP_CHECK(hipGetLastError());
+              LGNN_CALL(launch_gemm_listed(g, dout, h->Wback(l), 2 * d, ping, 2 * d, cc, N, h->ws.out_list.as<int32_t>(),
+                                           h->ws.out_count.as<int32_t>(), dout, 2 * d, ep, s));
             } else {
               // (with res: W_l + [Wr_l | 0] -- the Linear's output gradient is also res.{l}'s, base_gnn.py:141-144)
               LGNN_CALL(launch_gemm(g, dout, h->Wback(l), 2 * d, ping, 2 * d, cc * N, dout, 2 * d, ep, s));

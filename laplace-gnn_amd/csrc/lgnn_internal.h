@@ -288,6 +288,10 @@ struct GemmEpilogue {
 };
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t R,
                 int64_t K, int64_t Nout, const GemmEpilogue& ep, hipStream_t s);
+// the same on the listed nodes of every plane ([plane][plane_rows][.] in A and C), list length read on the device
+int launch_gemm_listed(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t planes,
+                       int64_t plane_rows, const int32_t* list, const int32_t* na_dev, int64_t K, int64_t Nout,
+                       const GemmEpilogue& ep, hipStream_t s);
 
 // scratch[D, D] (upper sub-tiles) += X[0:R, col0:col0+D)^T X[...]; X row-major with ld
 int launch_gram(const float* X, int64_t ld, int64_t R, int64_t D, float* scratch, hipStream_t s);
