@@ -62,14 +62,21 @@ __global__ __launch_bounds__(256) void sddmm_planes_kernel(const int32_t* __rest
       const bool ok = p < e;
       const int64_t b = ok ? col[p] : 0;
       float acc = 0.f;
-      for (int64_t c = 0; c < nplanes; ++c) {
+      // (small graphs with many planes -- the (sample, class) planes of the res / norm diagonal route: blockIdx.y splits the
+      //  planes so that the launch fills the device; the parts meet in out[p] through float atomics)
+      const int64_t cper = (nplanes + gridDim.y - 1) / gridDim.y;
+      const int64_t cb = int64_t(blockIdx.y) * cper, ce = cb + cper < nplanes ? cb + cper : nplanes;
+      for (int64_t c = cb; c < ce; ++c) {
         const float* __restrict__ lrow = Lp + c * l_stride + a * l_ld;
         const float* __restrict__ rrow = Rp + c * r_stride + b * r_ld;
         for (int64_t k = sl; k < width; k += LPR) acc += ok ? lrow[k] * rrow[k] : 0.f;
       }
 #pragma unroll
       for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-      if (ok && sl == 0) out[p] += acc;  // one wave owns row a: a single writer per entry inside a launch
+      if (ok && sl == 0) {
+        if (gridDim.y > 1) atomicAdd(&out[p], acc);
+        else out[p] += acc;  // one wave owns row a: a single writer per entry inside a launch
+      }
     }
   }
 }
@@ -78,9 +85,11 @@ int launch_sddmm(const Csr& m, int64_t nrows, const int32_t* rows, const int32_t
                  int64_t l_stride, const float* R, int64_t r_ld, int64_t r_stride, int64_t width, int64_t nplanes,
                  float* out, hipStream_t s) {
   if (nrows <= 0 || width <= 0 || nplanes <= 0) return 0;
-  const unsigned grid = unsigned(std::min<int64_t>(cdiv(nrows, 4), 8192));
+  const unsigned gx = unsigned(std::min<int64_t>(cdiv(nrows, 4), 8192));
+  const unsigned gy = unsigned(std::max<int64_t>(1, std::min<int64_t>({nplanes, cdiv(2048, gx), int64_t(1024)})));
+  const dim3 grid{gx, gy, 1};
 #define LGNN_SDDMM(LPRV)                                                                                           \
-  hipLaunchKernelGGL(sddmm_planes_kernel<LPRV>, dim3(grid), dim3(256), 0, s, m.rowptr, m.col, nrows, rows, nrows_dev, \
+  hipLaunchKernelGGL(sddmm_planes_kernel<LPRV>, grid, dim3(256), 0, s, m.rowptr, m.col, nrows, rows, nrows_dev, \
                      L, l_ld, l_stride, R, r_ld, r_stride, width, nplanes, out)
   if (width <= 8) LGNN_SDDMM(8);
   else if (width <= 16) LGNN_SDDMM(16);
@@ -1060,34 +1069,43 @@ __global__ void plane_bias_kernel(float* __restrict__ Y, int64_t rows, int64_t W
   }
 }
 
-// Diagonal posterior, per sample m of the chunk (one workgroup): p = softmax(f_n);  K = J_m diag(gamma) J_m^T  [C, C];
-// out_bar[n] += Lambda (diag K - 2 K p) + loss_scale (p - onehot(y));   probs[m] = p (kept for the R kernel)
-__global__ __launch_bounds__(256) void diag_ext_sample_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
-                                                              int64_t N, int64_t C, int64_t P, const float* __restrict__ J,
-                                                              const float* __restrict__ gamma, const float* __restrict__ logits,
-                                                              float loss_scale, float* __restrict__ probs,
-                                                              float* __restrict__ out_bar) {
-  extern __shared__ float sh[];  // K [C*C] | p [C] | red [4]
+// Diagonal posterior: K_m = J_m diag(gamma) J_m^T [C, C] of every sample of the chunk; one workgroup per (sample, a <= b)
+__global__ __launch_bounds__(256) void diag_ext_gram_kernel(int64_t C, int64_t P, const float* __restrict__ J,
+                                                            const float* __restrict__ gamma, float* __restrict__ Kout) {
+  __shared__ float red[4];
+  const int64_t m = blockIdx.x;
+  // pair index -> (a, b), a <= b
+  int64_t a = 0, rest = blockIdx.y;
+  while (rest >= C - a) { rest -= C - a; ++a; }
+  const int64_t b = a + rest;
+  const float* __restrict__ Ja = J + (m * C + a) * P;
+  const float* __restrict__ Jb = J + (m * C + b) * P;
+  float acc = 0.f;
+  for (int64_t p = threadIdx.x; p < P; p += 256) acc += Ja[p] * gamma[p] * Jb[p];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = red[0] + red[1] + red[2] + red[3];
+    Kout[(m * C + a) * C + b] = v;
+    Kout[(m * C + b) * C + a] = v;
+  }
+}
+
+// per sample m of the chunk (one wave): p = softmax(f_n);  out_bar[n] += Lambda (diag K - 2 K p) + loss_scale (p - onehot(y));
+// probs[m] = p (kept for the direction kernel)
+__global__ __launch_bounds__(64) void diag_ext_sample_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ y,
+                                                             int64_t N, int64_t C, const float* __restrict__ Kin,
+                                                             const float* __restrict__ logits, float loss_scale,
+                                                             float* __restrict__ probs, float* __restrict__ out_bar) {
+  extern __shared__ float sh[];  // K [C*C] | p [C]
   float* Ks = sh;
   float* ps = sh + C * C;
-  float* red = ps + C;
   const int64_t m = blockIdx.x;
   const int64_t n = idx[m];
   if (n < 0 || n >= N) return;
-  const float* __restrict__ Jm = J + m * C * P;
-  for (int64_t cc = 0; cc < C * C; ++cc) {
-    const int64_t a = cc / C, b = cc - a * C;
-    if (b < a) continue;  // symmetric
-    float acc = 0.f;
-    for (int64_t p = threadIdx.x; p < P; p += 256) acc += Jm[a * P + p] * gamma[p] * Jm[b * P + p];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { const float v = red[0] + red[1] + red[2] + red[3]; Ks[a * C + b] = v; Ks[b * C + a] = v; }
-  }
-  __syncthreads();
+  for (int64_t q = threadIdx.x; q < C * C; q += 64) Ks[q] = Kin[m * C * C + q];
   if (threadIdx.x == 0) {
     float mx = -INFINITY, sum = 0.f;
     for (int64_t c = 0; c < C; ++c) mx = fmaxf(mx, logits[n * C + c]);
@@ -1095,8 +1113,7 @@ __global__ __launch_bounds__(256) void diag_ext_sample_kernel(const int64_t* __r
     for (int64_t c = 0; c < C; ++c) { ps[c] /= sum; probs[m * C + c] = ps[c]; }
   }
   __syncthreads();
-  if (threadIdx.x < C) {
-    const int64_t c = threadIdx.x;
+  for (int64_t c = threadIdx.x; c < C; c += 64) {
     // t = diag K - 2 K p;  (Lambda t)_c = p_c (t_c - <p, t>)
     float pt = 0.f, tc = 0.f;
     for (int64_t a = 0; a < C; ++a) {
@@ -1332,18 +1349,20 @@ int diag_adjgrad_batch_ext(lgnn_ctx* h, const int64_t* idx, const void* y, int64
   LGNN_REQUIRE(chunk * C < (int64_t(1) << 31), "diag adjacency gradient: chunk too large");
   LGNN_CALL(h->ws.jac.reserve(size_t(chunk) * C * P * 4));
   LGNN_CALL(h->ws.adj_dir.reserve(size_t(chunk) * C * P * 4));
-  LGNN_CALL(h->ws.probs.reserve(size_t(chunk) * C * 4));
+  LGNN_CALL(h->ws.probs.reserve(size_t(chunk) * (C + C * C) * 4));
   LGNN_CALL(h->ws.planes_c.reserve(size_t(chunk) * C * N * (3 * H + C) * 4));
   float* J = h->ws.jac.as<float>();
   float* R = h->ws.adj_dir.as<float>();
   float* probs = h->ws.probs.as<float>();
+  float* Kn = probs + chunk * C;  // K_n [chunk][C][C]
   const int64_t* yy = static_cast<const int64_t*>(y);
   for (int64_t m0 = 0; m0 < M; m0 += chunk) {
     const int64_t mc = std::min(chunk, M - m0);
     const int64_t Q = mc * C;
     LGNN_CALL(jacobians(h, idx + m0, mc, J, nullptr, s));
-    hipLaunchKernelGGL(diag_ext_sample_kernel, dim3(unsigned(mc)), dim3(256), size_t(C * C + C + 4) * 4, s, idx + m0, yy + m0, N,
-                       C, P, J, gamma, h->fc.out.as<float>(), loss_scale, probs, out_bar);
+    hipLaunchKernelGGL(diag_ext_gram_kernel, dim3(unsigned(mc), unsigned(C * (C + 1) / 2)), dim3(256), 0, s, C, P, J, gamma, Kn);
+    hipLaunchKernelGGL(diag_ext_sample_kernel, dim3(unsigned(mc)), dim3(64), size_t(C * C + C) * 4, s, idx + m0, yy + m0, N, C,
+                       Kn, h->fc.out.as<float>(), loss_scale, probs, out_bar);
     hipLaunchKernelGGL(diag_ext_direction_kernel, dim3(unsigned(std::min<int64_t>(cdiv(mc * P, 256), 8192))), dim3(256), 0, s, J,
                        gamma, probs, mc, C, P, R);
     LGNN_HIP_CHECK(hipGetLastError());
