@@ -355,6 +355,29 @@ def test_batched_symeig_matches_float64_eigh():
         assert (Qd.T @ Qd - torch.eye(n, dtype=torch.float64)).abs().max() < 1e-4
         recon = (Qd * lam.double().cpu()) @ Qd.T
         assert rel(recon.numpy(), H.double().cpu().numpy()) < 1e-5
+    # 256 < n <= 512 (round 4): the streaming tridiagonalisation of the first n - 256 columns in front of the register-resident
+    # kernel -- full rank, rank deficient (a block of exactly dependent columns), a decoupled diagonal block (tau = 0 columns),
+    # n = 260 (a 4-column streaming phase) and a partial last panel (n = 300)
+    big = []
+    for n, rank in ((512, 512), (512, 300), (384, 384), (260, 260), (300, 120)):
+        R = torch.randn(max(rank, 1), n, generator=gen) * torch.logspace(0, -2, n).unsqueeze(0)
+        big.append((R.T @ R / rank).cuda())
+    Hd = torch.zeros(512, 512)
+    Hd[:100, :100] = torch.diag(torch.rand(100, generator=gen) + 0.1)
+    Rd = torch.randn(600, 412, generator=gen)
+    Hd[100:, 100:] = Rd.T @ Rd / 600
+    big.append(Hd.cuda())
+    for H in big:
+        (lam, Q), = symeig_batched_hip([H])
+        n = H.shape[0]
+        ref = torch.linalg.eigvalsh(H.double().cpu()).clamp(min=0).numpy()
+        assert lam.shape == (n,) and Q.shape == (n, n)
+        assert np.abs(lam.cpu().numpy() - ref).max() < 1e-5 * ref.max(), n
+        assert (lam >= 0).all() and (lam[1:] >= lam[:-1]).all()
+        Qd = Q.double().cpu()
+        assert (Qd.T @ Qd - torch.eye(n, dtype=torch.float64)).abs().max() < 1e-4, n
+        recon = (Qd * lam.double().cpu()) @ Qd.T
+        assert rel(recon.numpy(), H.double().cpu().numpy()) < 1e-5, n
     # Kron.decompose uses it for CUDA factors and keeps the [[B, A], [B]] sharing
     K = lg.Kron([[mats[2], mats[1]], [mats[2].clone()], [mats[3], mats[2]], [mats[3].clone()]])
     dec = K.decompose()

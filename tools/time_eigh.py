@@ -29,3 +29,25 @@ for path in ("hand-written, side streams", "hand-written, one stream", "library"
         errs.append((float((lam.double() - ref).abs().max() / ref.max()), float((rec - H).norm() / H.norm()),
                      float((Q.T @ Q - torch.eye(H.shape[0], device=dev)).abs().max())))
     print(path, f"{dt * 1e3:.2f} ms", " ".join(f"[lam {a:.1e} rec {b:.1e} orth {c:.1e}]" for a, b, c in errs))
+
+
+# ---- round 4: 256 < n <= 512 (streaming tridiagonalisation + the register-resident kernel) vs the library, one factor per call
+os.environ.pop("LGNN_EIGH_LIBRARY", None)
+os.environ.pop("LGNN_EIGH_ONE_STREAM", None)
+for n in (512, 384, 1433):
+    G = torch.randn(4000, n, device=dev, dtype=torch.float64) * torch.logspace(0, -3, n, device=dev, dtype=torch.float64)
+    H = (G.T @ G / 4000).float()
+    for path in ("hand-written", "library"):
+        if path == "library":
+            os.environ["LGNN_EIGH_LIBRARY"] = "1"
+        else:
+            os.environ.pop("LGNN_EIGH_LIBRARY", None)
+        ts = []
+        for rep in range(6):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            (lam, Q), = symeig_batched_hip([H])
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        ref = torch.linalg.eigvalsh(H.double()).clamp(min=0)
+        rec = (Q * lam) @ Q.T
+        print(f"n = {n} {path}: {1e3 * sorted(ts)[len(ts) // 2]:.2f} ms  lam {float((lam.double() - ref).abs().max() / ref.max()):.1e} "
+              f"rec {float((rec - H).norm() / H.norm()):.1e} orth {float((Q.T @ Q - torch.eye(n, device=dev)).abs().max()):.1e}")
