@@ -397,7 +397,7 @@ int graph_update(lgnn_ctx* h, const int64_t* fi, const int64_t* fj, const uint8_
     // everything cached from the graph
     h->fc.valid = false; h->fc.aux_valid = false; h->fc.px_valid = false;
     for (int l = 0; l < kMaxLayers; ++l) h->fc.gram_valid[l] = (l == 0 && h->kind == LGNN_KIND_GCN) ? h->fc.gram_valid[0] : false;
-    h->n_long = -1; h->n_long_fwd = -1; h->n_top_multi = 0; h->n_top_slices = 0; h->n_long_tasks = 0; h->two_hop = -1.0;
+    h->n_long = -1; h->n_long_fwd = -1; h->n_top_multi = 0; h->n_top_slices = 0; h->n_long_tasks = 0; h->two_hop = -1.0; h->two_hop_max = -1.0;
     h->ws.planes_a_zero_ptr = nullptr;
     LGNN_HIP_CHECK(hipStreamSynchronize(s));  // temporaries are released below
     return 0;

@@ -173,6 +173,7 @@ struct lgnn_ctx {
   int64_t ws_limit = int64_t(32) << 30;  // backward planes (ping + pong) per class chunk: 288 GB of HBM, keep chunks large
   // rows of P^T with more than kLongRow stored entries (hubs), built once on first use (longrows.hip)
   bool last_route_paths = false;   // the last KFAC accumulate took the two-hop path route
+  double two_hop_max = -1.0;       // largest number of 2-hop paths starting at one node (same count pass)
   double two_hop = -1.0;           // number of 2-hop paths n <- v <- m of the graph (-1: not counted yet; paths.hip)
   int64_t n_long = -1;             // -1: not looked at yet
   int64_t n_long_tasks = 0;

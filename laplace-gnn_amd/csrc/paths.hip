@@ -1172,6 +1172,21 @@ __global__ void two_hop_count_kernel(const int32_t* __restrict__ rp, const int32
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
+
+// max over m of the paths n <- k <- m that START at m: sum over the entries k of row m of P of the entries of row k of P.
+// M times this bounds a batch's path count from the host (duplicated batch nodes share their paths).
+__global__ void two_hop_max_kernel(const int32_t* __restrict__ rp, const int32_t* __restrict__ col, int64_t N,
+                                   unsigned long long* __restrict__ out) {
+  unsigned long long best = 0;
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t m = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; m < N; m += stride) {
+    unsigned long long acc = 0;
+    for (int32_t p = rp[m]; p < rp[m + 1]; ++p) { const int32_t k = col[p]; acc += (unsigned long long)(rp[k + 1] - rp[k]); }
+    best = acc > best ? acc : best;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(best, o); best = t > best ? t : best; }
+  if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
+}
 }  // namespace
 
 // The path route's cost grows with the batch's number of 2-hop paths (about 1 ns each at C = 40 on top of the per-node Gram),
@@ -1185,17 +1200,20 @@ int two_hop_ensure(lgnn_ctx* h, hipStream_t s) {
   if (h->nnz <= 0) return 0;
   DevBuf acc;
   LGNN_CALL(acc.reserve(64));
-  unsigned long long host = 0;
+  unsigned long long host[2] = {0, 0};
   int rc = 0;
-  if (hipMemsetAsync(acc.p, 0, 8, s) != hipSuccess) rc = 1;
+  if (hipMemsetAsync(acc.p, 0, 16, s) != hipSuccess) rc = 1;
   if (!rc) {
     hipLaunchKernelGGL(two_hop_count_kernel, dim3(unsigned(std::min<int64_t>(cdiv(h->N, 256), 1024))), dim3(256), 0, s,
                        h->P.rowptr, h->PT.rowptr, h->N, acc.as<unsigned long long>());
-    if (hipMemcpyAsync(&host, acc.p, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = 1;
+    hipLaunchKernelGGL(two_hop_max_kernel, dim3(unsigned(std::min<int64_t>(cdiv(h->N, 256), 1024))), dim3(256), 0, s,
+                       h->P.rowptr, h->P.col, h->N, acc.as<unsigned long long>() + 1);
+    if (hipMemcpyAsync(host, acc.p, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = 1;
   }
   acc.release();
   if (rc) { set_error("two-hop path count failed"); return 1; }
-  h->two_hop = double(host);
+  h->two_hop = double(host[0]);
+  h->two_hop_max = double(host[1]);
   return 0;
 }
 bool paths_pay(const lgnn_ctx* h, int64_t M) {
@@ -1359,8 +1377,11 @@ int kfac_paths_first_layer(lgnn_ctx* h, const int64_t* idx, int64_t M, int seed_
     LGNN_HIP_CHECK(hipGetLastError());
     if (h->timing) { LGNN_CALL(record_event(h, s)); h->ev_planes += R; }
   }
-  // the overflow route: gated on the device (the host cannot know whether a batch needs it without a synchronisation), so its
-  // planes -- sized under the workspace cap -- exist from the first call on
+  // the overflow route: gated on the device (the host cannot know a batch's path count without a synchronisation).  What the
+  // host does know is a bound: M times the largest number of paths that start at one node (counted once per graph beside the
+  // graph's total).  If that fits the list, no batch can overflow: no planes, no launches (arxiv shape: 10 000 x 726 paths
+  // against a cap of 10 M entries -- the 6.9 GB of planes are never reserved).
+  if (h->two_hop_max >= 0 && double(M) * h->two_hop_max <= double(cap)) return 0;
   const int64_t per_class = N * H * 4;
   const int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ce - cb, 64),
                                                                 h->ws_limit / std::max<int64_t>(per_class, 1)));

@@ -42,7 +42,12 @@ def kfac_plan(kind: str, dims: Sequence[int], num_nodes: int, nnz: int, act: str
               workspace_limit: int = 32 << 30, paths: bool | None = None) -> dict:
     """Which kernels ``lgnn_kfac_accumulate`` would run for a model of this shape (host-only query, no GPU work):
     per backward step l = L-1 .. 1 whether the fused SpMM^T -> Gram kernel and the compacted backward GEMM are used,
-    whether the second plane buffer is needed and how many class planes fit one chunk of the workspace."""
+    whether the second plane buffer is needed and how many class planes fit one chunk of the workspace.
+
+    ``paths`` (and with it ``fused`` / ``backgemm`` / ``need_pong`` of the first level) says what the SHAPE allows: whether a call
+    really takes the path route also depends on the graph and the call -- the expected number of 2-hop paths per node of the batch
+    (hub-heavy graphs keep the class planes), a Fisher-type seed, ``res`` / ``norm``.  ``GraphEngine.last_kfac_used_paths`` /
+    ``lgnn_kfac_last_route`` report what the last call did."""
     lib = _lib.load()
     L = len(dims) - 1
     out = (C.c_int64 * (4 + L))()
