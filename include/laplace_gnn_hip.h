@@ -19,8 +19,8 @@
  *       lgnn_check_async_errors                 by design (reports the sticky error flags);
  *       the FIRST KFAC / adjacency-gradient call on a graph, once per graph: the list of rows with
  *         more than 64 stored entries (hubs) and the graph's number of 2-hop paths;
- *       lgnn_kfac_adjgrad_batch on GraphSAGE models, once per batch: the active-row count sizes a
- *         library GEMM;   lgnn_glm_variance(_mapped), once per call: the size of the rotated-row table.
+ *       lgnn_glm_variance(_mapped), once per call: the size of the rotated-row table;
+ *       lgnn_update_adjacency: the new number of stored entries.
  *     Everything else -- KFAC of GCN / GraphSAGE models of any depth, diagonal and last-layer GGN, forward,
  *     Jacobians -- enqueue only; workspaces grow on first use of a shape and are reused after;
  *   - every function returns 0 on success, non-zero on error; the message is available

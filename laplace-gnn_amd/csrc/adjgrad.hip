@@ -860,10 +860,10 @@ int sage_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   hipLaunchKernelGGL(sage_index_active_kernel, dim3(unsigned(cdiv(N, 256))), dim3(256), 0, s, h->ws.act_list.as<int32_t>(),
                      h->ws.act_count.as<int32_t>(), widx);
   LGNN_HIP_CHECK(hipGetLastError());
-  int32_t na = 0;  // the GEMM over the active rows needs its row count on the host: one small synchronous copy per batch
-  LGNN_HIP_CHECK(hipMemcpyAsync(&na, h->ws.act_count.p, 4, hipMemcpyDeviceToHost, s));
-  LGNN_HIP_CHECK(hipStreamSynchronize(s));
-  if (na > 0) {
+  // the number of active rows stays on the device: buffers and grids are sized for the bound N, the kernels and the GEMM over
+  // the active rows read the count themselves (no host round trip per batch)
+  const int64_t na = N;
+  {
     // class chunks: G0 and g0bar [na * cc, H] under the workspace cap
     const int64_t per_class = int64_t(na) * H * 4 * 2;
     const int64_t cc_max = std::max<int64_t>(1, std::min<int64_t>(C, h->ws_limit / std::max<int64_t>(per_class, 1)));
@@ -880,7 +880,7 @@ int sage_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
                          h->PT.rowptr, h->PT.col, h->PT.val, h->ws.act_list.as<int32_t>(), h->ws.act_count.as<int32_t>(),
                          h->ws.pos.as<int32_t>(), dcat, dact, C, H, c0, cc, G0);
       LGNN_HIP_CHECK(hipGetLastError());
-      LGNN_CALL(sgemm_rm(s, int64_t(na) * cc, H, H, 2.f, G0, H, gamma_B0, H, 0.f, G0B, H));
+      LGNN_CALL(launch_gemm_devrows(G0, H, gamma_B0, H, G0B, H, na * cc, h->ws.act_count.as<int32_t>(), cc, H, H, 2.f, s));
       if (K > 0)
         hipLaunchKernelGGL(sage_cand_kernel, dim3(unsigned(cdiv(K, 4))), dim3(256), 0, s, cand_a, cand_b, K,
                            h->ws.pos.as<int32_t>(), widx, dcat, G0B, dact, C, H, c0, cc, grad_cand);
@@ -895,8 +895,6 @@ int sage_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
     hipLaunchKernelGGL(sage_vbar_kernel, dim3(unsigned(cdiv(M * CC, 256))), dim3(256), 0, s, idx, M, N, CC,
                        h->ws.pos.as<int32_t>(), g1b, vbar);
     LGNN_HIP_CHECK(hipGetLastError());
-  } else {
-    LGNN_HIP_CHECK(hipMemsetAsync(vbar, 0, size_t(M) * CC * 4, s));  // every index was out of range (flagged)
   }
   LGNN_REQUIRE(size_t(4) * 8 * C * 4 <= 64 * 1024, "too many classes for the seed adjoint kernel");
   hipLaunchKernelGGL(seed_adjoint_kernel, dim3(unsigned(cdiv(M, 4))), dim3(256), size_t(4) * 8 * C * 4, s,

@@ -221,6 +221,8 @@ struct GemmArgs {
   // length is read on the device (no host round trip): workgroup blockIdx.x = plane * tiles_per_plane + tile, tiles
   // beyond the list exit at once
   const int32_t* row_list; const int32_t* na_dev; int64_t plane_rows; int64_t tiles_per_plane;
+  // dense instance with the row count on the device: R = *r_dev * r_mul (<= the R the grid was sized for); alpha scales A B
+  const int32_t* r_dev; int64_t r_mul; float alpha;
 };
 
 template <bool LIST>
@@ -232,6 +234,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int64_t row0 = LIST ? 0 : int64_t(blockIdx.x) * GBM, col0 = int64_t(blockIdx.y) * GBN;
+  const int64_t R = (!LIST && g.r_dev) ? int64_t(*g.r_dev) * g.r_mul : g.R;
+  if (!LIST && row0 >= R) return;
   if (LIST) {
     const int64_t plane = int64_t(blockIdx.x) / g.tiles_per_plane, t0 = (int64_t(blockIdx.x) % g.tiles_per_plane) * GBM;
     const int64_t na = *g.na_dev;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       const int r = (tid >> 3) + 32 * it, k4 = (tid & 7) * 4;
       const int64_t grow = LIST ? rowsh[r] : row0 + r;
       float x[4] = {0.f, 0.f, 0.f, 0.f};
-      if (LIST ? grow >= 0 : grow < g.R) {
+      if (LIST ? grow >= 0 : grow < R) {
         const float* src = g.A + grow * g.lda + k0 + k4;
         if (g.vecA && k4 + 4 <= kvalid) {
           float4 t = *reinterpret_cast<const float4*>(src);
@@ -322,11 +326,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int lr = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         const int64_t row = LIST ? rowsh[lr] : row0 + lr;
-        if (LIST ? row < 0 : row >= g.R) continue;
+        if (LIST ? row < 0 : row >= R) continue;
         int64_t hr = LIST ? row % g.plane_rows : hbase + lr;
         if (wrap) { while (hr >= g.hact_row_mod) hr -= g.hact_row_mod; }
         if (g.row_active && !g.row_active[hr]) continue;
-        float v = acc[m][n][r] + bias;
+        float v = acc[m][n][r] * g.alpha + bias;
         if (g.hact) v *= act_deriv_from_out(g.hact[hr * g.hact_ld + col], g.act);
         if (g.out_act >= 0) v = act_apply(v, g.out_act);
         if (g.k_chunk > 0) atomicAdd(&g.C[row * g.ldc + col], v);
@@ -486,6 +490,7 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float*
   g.bias = ep.bias; g.hact = ep.hact; g.hact_ld = ep.hact_ld; g.hact_row_mod = ep.hact_row_mod; g.act = ep.act;
   g.out_act = ep.out_act;
   g.row_active = ep.row_active;
+  g.alpha = 1.f;
   g.vecA = (lda % 4 == 0) && aligned16(A);
   g.vecB = (ldb % 4 == 0) && aligned16(B);
   if (K <= 64 && Nout <= 256 && R >= GBM) {
@@ -521,6 +526,25 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float*
   return 0;
 }
 
+// C[0 : R) = alpha * A[0 : R) @ B with R = *r_dev * r_mul read on the device (R <= rows_bound, which sizes the grid and the
+// caller's buffers): the rows past R are neither read nor written.  No host round trip for a count that lives on the device.
+int launch_gemm_devrows(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t rows_bound,
+                        const int32_t* r_dev, int64_t r_mul, int64_t K, int64_t Nout, float alpha, hipStream_t s) {
+  if (rows_bound <= 0 || Nout <= 0) return 0;
+  LGNN_REQUIRE(K > 0 && r_dev && r_mul > 0, "gemm with a device-side row count: empty K or no count");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.R = rows_bound; g.K = K; g.Nout = Nout;
+  g.out_act = -1;
+  g.vecA = (lda % 4 == 0) && aligned16(A);
+  g.vecB = (ldb % 4 == 0) && aligned16(B);
+  g.r_dev = r_dev; g.r_mul = r_mul; g.alpha = alpha;
+  LGNN_REQUIRE(cdiv(rows_bound, GBM) < (int64_t(1) << 31), "gemm: too many row tiles");
+  const dim3 grid{unsigned(cdiv(rows_bound, GBM)), unsigned(cdiv(Nout, GBN)), 1};
+  hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, s, g);
+  LGNN_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 // C[p][n][:] = A[p][n][:] @ B for the nodes n = list[0 .. *na_dev) of every plane p (planes of `plane_rows` rows); the other
 // rows of C are not touched.  The list's length stays on the device: the grid covers the worst case (all rows listed) and the
 // workgroups past the end leave at once.
@@ -535,6 +559,7 @@ int launch_gemm_listed(const float* A, int64_t lda, const float* B, int64_t ldb,
   g.hact = ep.hact; g.hact_ld = ep.hact_ld; g.act = ep.act; g.out_act = ep.out_act;
   g.vecA = (lda % 4 == 0) && aligned16(A);
   g.vecB = (ldb % 4 == 0) && aligned16(B);
+  g.alpha = 1.f;
   g.row_list = list; g.na_dev = na_dev; g.plane_rows = plane_rows; g.tiles_per_plane = cdiv(plane_rows, GBM);
   LGNN_REQUIRE(planes * g.tiles_per_plane < (int64_t(1) << 31), "listed gemm: too many row tiles");
   const dim3 grid{unsigned(planes * g.tiles_per_plane), unsigned(cdiv(Nout, GBN)), 1};

@@ -289,6 +289,9 @@ struct GemmEpilogue {
 };
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t R,
                 int64_t K, int64_t Nout, const GemmEpilogue& ep, hipStream_t s);
+// C[0 : R) = alpha A[0 : R) B with R = *r_dev * r_mul (<= rows_bound) read on the device
+int launch_gemm_devrows(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t rows_bound,
+                        const int32_t* r_dev, int64_t r_mul, int64_t K, int64_t Nout, float alpha, hipStream_t s);
 // the same on the listed nodes of every plane ([plane][plane_rows][.] in A and C), list length read on the device
 int launch_gemm_listed(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t planes,
                        int64_t plane_rows, const int32_t* list, const int32_t* na_dev, int64_t K, int64_t Nout,
