@@ -341,7 +341,10 @@ LGNN_API int lgnn_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float*
  * form of the diagonal GGN exists; gamma covers the res.{l} parameters too (after W_1, b_1), e_bar is left untouched, and per
  * (sample, class) the kernel chain runs one tangent forward pass along R = 2 Lambda J diag(gamma) and its reverse pass
  * (d sum_p gamma_p H_p = <K, d Lambda> + <R, d J>, K = J diag(gamma) J^T).  Workspace per sample of a chunk: 2 C P floats
- * (Jacobian rows and directions) + C N (3 H + C) floats of planes -- sized for graphs of a few hundred to a few thousand nodes. */
+ * (Jacobian rows and directions) + C N (3 H + C) floats of planes -- sized for graphs of a few hundred to a few thousand nodes.
+ * Plain 2-layer GraphSAGE models (STEGraphSAGE + DiagLaplace; the driver offers the pair, gnn/utils.py:55-59, 81): the same identity,
+ * evaluated locally -- everything of a (sample, class) pair lives on the rows {n} + N(n), one workgroup per pair, no planes; e_bar
+ * [N, F + 1] carries the adjoint of P X in its first F columns, h1_bar the direct adjoint of H_1; workspace 2 C P floats per sample. */
 LGNN_API int lgnn_diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, const float* gamma,
                             float loss_scale, float* grad_P, float* out_bar, float* h1_bar, float* e_bar,
                             const int32_t* cand_a, const int32_t* cand_b, int64_t num_cand, float* grad_cand, void* stream);

@@ -905,9 +905,13 @@ int sage_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
   return 0;
 }
 
+// (diagonal posterior: gamma_A0 / gamma_A1 are null; h1_bar [N, H] = direct adjoint of H1, px_bar [N, px_ld] = of P X)
+__global__ void add_strided_kernel(float* __restrict__ x, int64_t ldx, const float* __restrict__ y, int64_t ldy, int64_t rows,
+                                   int64_t width);
 int sage_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0, const float* gamma_A1, float a_scale,
                         float* grad_P, float* grad_adj, const int32_t* cand_a, const int32_t* cand_b, int64_t K,
-                        float* grad_cand, float* grad_cand_adj, hipStream_t s) {
+                        float* grad_cand, float* grad_cand_adj, hipStream_t s, const float* h1_bar = nullptr,
+                        const float* px_bar = nullptr, int64_t px_ld = 0) {
   const int64_t N = h->N, C = h->dims[2], H = h->dims[1], F = h->dims[0];
   LGNN_CALL(forward_ensure_aux(h, s));
   LGNN_CALL(ensure_wt(h, s));
@@ -921,7 +925,12 @@ int sage_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0
   float* XNb = Z0b + N * H;                 // [N, F]
   // T1 = outbar W1 + 2 a cat1 Gamma_A1: the self half feeds H1bar directly, the neighbour half is HNbar
   LGNN_CALL(sgemm_rm(s, N, 2 * H, C, 1.f, out_bar, C, h->W[1], 2 * H, 0.f, T1, 2 * H));
-  LGNN_CALL(sgemm_rm(s, N, 2 * H, 2 * H, 2.f * a_scale, cat1, 2 * H, gamma_A1, 2 * H, 1.f, T1, 2 * H));
+  if (gamma_A1) LGNN_CALL(sgemm_rm(s, N, 2 * H, 2 * H, 2.f * a_scale, cat1, 2 * H, gamma_A1, 2 * H, 1.f, T1, 2 * H));
+  if (h1_bar) {  // joins the self half before the mask
+    hipLaunchKernelGGL(add_strided_kernel, dim3(unsigned(std::min<int64_t>(cdiv(N * H, 256), 4096))), dim3(256), 0, s, T1, 2 * H,
+                       h1_bar, H, N, H);
+    LGNN_HIP_CHECK(hipGetLastError());
+  }
   LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, T1 + H, 2 * H, 0, cat1, 2 * H, 0, H, 1, grad_P, s));
   LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, T1 + H, 2 * H, 0, cat1, 2 * H, 0, H, 1, nullptr, grad_cand, s));
   // Z0bar = mask * (T1_self + P^T T1_neigh)
@@ -936,7 +945,12 @@ int sage_adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0
   LGNN_HIP_CHECK(hipGetLastError());
   // XNbar = Z0bar W0[:, F:] + 2 a (cat0 Gamma_A0)[:, F:]
   LGNN_CALL(sgemm_rm(s, N, F, H, 1.f, Z0b, H, h->W[0] + F, 2 * F, 0.f, XNb, F));
-  LGNN_CALL(sgemm_rm(s, N, F, 2 * F, 2.f * a_scale, cat0, 2 * F, gamma_A0 + F, 2 * F, 1.f, XNb, F));
+  if (gamma_A0) LGNN_CALL(sgemm_rm(s, N, F, 2 * F, 2.f * a_scale, cat0, 2 * F, gamma_A0 + F, 2 * F, 1.f, XNb, F));
+  if (px_bar) {
+    hipLaunchKernelGGL(add_strided_kernel, dim3(unsigned(std::min<int64_t>(cdiv(N * F, 256), 4096))), dim3(256), 0, s, XNb, F, px_bar,
+                       px_ld, N, F);
+    LGNN_HIP_CHECK(hipGetLastError());
+  }
   LGNN_CALL(launch_sddmm(h->P, N, nullptr, nullptr, XNb, F, 0, cat0, 2 * F, 0, F, 1, grad_P, s));
   LGNN_CALL(launch_sddmm_coo(cand_a, cand_b, K, XNb, F, 0, cat0, 2 * F, 0, F, 1, nullptr, grad_cand, s));
   // mean_agg backward + the straight-through binarisation (P has the pattern and the row order of A)
@@ -1413,6 +1427,163 @@ int diag_adjgrad_batch_ext(lgnn_ctx* h, const int64_t* idx, const void* y, int64
     }
   }
   h->ws.planes_a_zero_ptr = nullptr;
+  return 0;
+}
+}  // namespace
+
+namespace {
+// ---------------------------------------------------------------------------------------------------------------------------
+// Diagonal posterior, 2-layer GraphSAGE (STEGraphSAGE + DiagLaplace: the driver offers the pair, gnn/utils.py:55-59, 81):
+//     s = [X | P X] W0^T + b0,  H1 = relu(s),  out = [H1 | P H1] W1^T + b1.
+// Same identity as diag_adjgrad_batch_ext -- d sum_p gamma_p H_p = sum_n <K_n, d Lambda_n> + sum_{n,c} <R_n[c,:], d J_n[c,:]> --
+// but everything of a (sample n, class c) pair is local to the rows {n} + N(n), so there are no planes: one workgroup per pair
+// runs the tangent along R = (dW0, db0, dW1, db1) and its reverse on those rows,
+//     h1dot[b] = act'(h1[b]) * ([X | P X][b] dW0^T + db0)                     (neighbours b of n)
+//     gradP[(n, b)] += <h1dot[b], W1n[c]> + <H1[b], dW1n[c]>                   (W1 = [W1s | W1n]: self / neighbour halves)
+//     h1_bar[b] += P[n, b] dW1n[c],  h1_bar[n] += dW1s[c]
+//     px_bar[r] += (act'(h1[r]) * coef_r) dW0n,  coef_b = P[n, b] W1n[c],  coef_n = W1s[c]        (adjoint of P X, dW0 = [dW0s | dW0n])
+// candidate pairs (n, b') get the same first line for their b'.
+__global__ __launch_bounds__(256) void sage_diag_pair_kernel(const int64_t* __restrict__ idx, int64_t N, int64_t C, int64_t H,
+                                                             int64_t F, int64_t P, const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                             const float* __restrict__ cat0, const float* __restrict__ cat1,
+                                                             const float* __restrict__ dact, const float* __restrict__ W1,
+                                                             const float* __restrict__ R, const int32_t* __restrict__ ca,
+                                                             const int32_t* __restrict__ cb, int64_t K,
+                                                             float* __restrict__ grad_P, float* __restrict__ grad_cand,
+                                                             float* __restrict__ h1_bar, float* __restrict__ px_bar,
+                                                             int64_t px_ld) {
+  extern __shared__ float sh[];  // w1s | w1n | dw1s | dw1n | cv | hd  [H each] | red [4]
+  float* w1s = sh;
+  float* w1n = w1s + H;
+  float* dw1s = w1n + H;
+  float* dw1n = dw1s + H;
+  float* cv = dw1n + H;
+  float* hd = cv + H;
+  float* red = hd + H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t q = blockIdx.x;
+  const int64_t m = q / C, c = q - m * C;
+  const int64_t n = idx[m];
+  if (n < 0 || n >= N) return;
+  const float* __restrict__ Rq = R + q * P;
+  const float* __restrict__ dW0 = Rq;                  // [H][2F]
+  const float* __restrict__ db0 = Rq + H * 2 * F;      // [H]
+  const float* __restrict__ dW1c = db0 + H + c * 2 * H;  // row c of dW1 [C][2H]
+  for (int64_t j = tid; j < H; j += 256) {
+    w1s[j] = W1[c * 2 * H + j]; w1n[j] = W1[c * 2 * H + H + j];
+    dw1s[j] = dW1c[j]; dw1n[j] = dW1c[H + j];
+  }
+  __syncthreads();
+  // h1dot of row b -> hd[], then the pair's dot product (all threads get it)
+  auto pair_dot = [&](int64_t b) -> float {
+    for (int64_t j = wave; j < H; j += 4) {
+      const float* __restrict__ wrow = dW0 + j * 2 * F;
+      const float* __restrict__ xrow = cat0 + b * 2 * F;
+      float acc = 0.f;
+      for (int64_t i = lane; i < 2 * F; i += 64) acc += xrow[i] * wrow[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      if (lane == 0) hd[j] = dact[b * H + j] * (acc + db0[j]);
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int64_t j = tid; j < H; j += 256) part += hd[j] * w1n[j] + cat1[b * 2 * H + j] * dw1n[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();  // hd / red are rewritten by the next row
+    return tot;
+  };
+  // rows {n} + N(n): slot -1 = the node itself
+  const int32_t s0 = rowptr[n], s1 = rowptr[n + 1];
+  for (int32_t p = s0 - 1; p < s1; ++p) {
+    const bool self = p < s0;
+    const int64_t row = self ? n : int64_t(col[p]);
+    const float pv = self ? 1.f : val[p];
+    for (int64_t j = tid; j < H; j += 256) {
+      cv[j] = dact[row * H + j] * pv * (self ? w1s[j] : w1n[j]);
+      atomicAdd(&h1_bar[row * H + j], pv * (self ? dw1s[j] : dw1n[j]));
+    }
+    __syncthreads();
+    for (int64_t f = tid; f < F; f += 256) {
+      float acc = 0.f;
+      for (int64_t j = 0; j < H; ++j) acc += cv[j] * dW0[j * 2 * F + F + f];
+      atomicAdd(&px_bar[row * px_ld + f], acc);
+    }
+    if (!self) {
+      const float d = pair_dot(row);  // (starts with a barrier-free phase on hd, ends with barriers)
+      if (tid == 0) atomicAdd(&grad_P[p], d);
+    } else {
+      __syncthreads();
+    }
+  }
+  // candidate pairs that start at n (a = n in the propagation matrix's coordinates)
+  for (int64_t k0 = 0; k0 < K; k0 += 256) {
+    const int64_t k = k0 + tid;
+    const bool mine = k < K && ca[k] == n;
+    // every wave walks its own matches; the dot product needs the whole workgroup, so collect the matches first
+    __shared__ int32_t match[256];
+    __shared__ int nmatch;
+    if (tid == 0) nmatch = 0;
+    __syncthreads();
+    if (mine) match[atomicAdd(&nmatch, 1)] = int32_t(k);
+    __syncthreads();
+    const int nm = nmatch;
+    for (int i = 0; i < nm; ++i) {
+      const int32_t kk = match[i];
+      const float d = pair_dot(cb[kk]);
+      if (tid == 0) atomicAdd(&grad_cand[kk], d);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void add_strided_kernel(float* __restrict__ x, int64_t ldx, const float* __restrict__ y, int64_t ldy, int64_t rows,
+                                   int64_t width) {
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < rows * width; t += stride) {
+    const int64_t r = t / width, j = t - r * width;
+    x[r * ldx + j] += y[r * ldy + j];
+  }
+}
+
+int diag_adjgrad_batch_sage(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M, const float* gamma, float loss_scale,
+                            float* grad_P, float* out_bar, float* h1_bar, float* e_bar, const int32_t* cand_a,
+                            const int32_t* cand_b, int64_t K, float* grad_cand, hipStream_t s) {
+  LGNN_REQUIRE(h->L == 2 && !h->extras(), "adjacency gradient, diagonal posterior, GraphSAGE: plain 2-layer models");
+  LGNN_REQUIRE(h->act == LGNN_ACT_RELU && h->lik == LGNN_LIK_CLASSIFICATION, "adjacency gradient: ReLU, classification");
+  LGNN_REQUIRE(M > 0 && idx && y && gamma && grad_P && out_bar && h1_bar && e_bar, "empty batch or null pointers");
+  LGNN_CALL(forward_ensure_aux(h, s));
+  const int64_t N = h->N, C = h->dims[2], H = h->dims[1], F = h->dims[0], P = h->n_params;
+  LGNN_REQUIRE(P == H * 2 * F + H + C * 2 * H + C, "internal: parameter count");
+  LGNN_REQUIRE(h->fc.lin_in_ld[0] == 2 * F && h->fc.lin_in_ld[1] == 2 * H, "internal: unexpected cat row stride");
+  LGNN_REQUIRE(size_t(C * C + C) * 4 <= 64 * 1024 && size_t(6 * H + 4) * 4 <= 60 * 1024, "too many classes / hidden units");
+  const int64_t per_sample = C * 2 * P * 4;
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(M, h->ws_limit / std::max<int64_t>(per_sample, 1)));
+  LGNN_CALL(h->ws.jac.reserve(size_t(chunk) * C * P * 4));
+  LGNN_CALL(h->ws.adj_dir.reserve(size_t(chunk) * C * P * 4));
+  LGNN_CALL(h->ws.probs.reserve(size_t(chunk) * (C + C * C) * 4));
+  float* J = h->ws.jac.as<float>();
+  float* R = h->ws.adj_dir.as<float>();
+  float* probs = h->ws.probs.as<float>();
+  float* Kn = probs + chunk * C;
+  const int64_t* yy = static_cast<const int64_t*>(y);
+  for (int64_t m0 = 0; m0 < M; m0 += chunk) {
+    const int64_t mc = std::min(chunk, M - m0);
+    LGNN_CALL(jacobians(h, idx + m0, mc, J, nullptr, s));
+    hipLaunchKernelGGL(diag_ext_gram_kernel, dim3(unsigned(mc), unsigned(C * (C + 1) / 2)), dim3(256), 0, s, C, P, J, gamma, Kn);
+    hipLaunchKernelGGL(diag_ext_sample_kernel, dim3(unsigned(mc)), dim3(64), size_t(C * C + C) * 4, s, idx + m0, yy + m0, N, C,
+                       Kn, h->fc.out.as<float>(), loss_scale, probs, out_bar);
+    hipLaunchKernelGGL(diag_ext_direction_kernel, dim3(unsigned(std::min<int64_t>(cdiv(mc * P, 256), 8192))), dim3(256), 0, s, J,
+                       gamma, probs, mc, C, P, R);
+    hipLaunchKernelGGL(sage_diag_pair_kernel, dim3(unsigned(mc * C)), dim3(256), size_t(6 * H + 4) * 4, s, idx + m0, N, C, H, F, P,
+                       h->P.rowptr, h->P.col, h->P.val, h->fc.lin_in_p[0], h->fc.lin_in_p[1], h->fc.dact0.as<float>(), h->W[1], R,
+                       cand_a, cand_b, K, grad_P, grad_cand, h1_bar, e_bar, F + 1);
+    LGNN_HIP_CHECK(hipGetLastError());
+  }
   return 0;
 }
 }  // namespace
@@ -1922,6 +2093,9 @@ int diag_adjgrad_batch(lgnn_ctx* h, const int64_t* idx, const void* y, int64_t M
                        float* grad_P, float* out_bar, float* h1_bar, float* e_bar, const int32_t* cand_a, const int32_t* cand_b,
                        int64_t K, float* grad_cand, hipStream_t s) {
   LGNN_REQUIRE(K == 0 || (cand_a && cand_b && grad_cand), "candidate pairs without their buffers");
+  if (h->kind == LGNN_KIND_SAGE)  // (e_bar [N, F + 1] carries the adjoint of P X in its first F columns)
+    return diag_adjgrad_batch_sage(h, idx, y, M, gamma, loss_scale, grad_P, out_bar, h1_bar, e_bar, cand_a, cand_b, K, grad_cand,
+                                   s);
   if (h->extras())  // res / norm: no closed form, (sample, class) planes (e_bar stays untouched)
     return diag_adjgrad_batch_ext(h, idx, y, M, gamma, loss_scale, grad_P, out_bar, h1_bar, cand_a, cand_b, K, grad_cand, s);
   LGNN_CALL(check_model(h));
@@ -1977,8 +2151,10 @@ int adjgrad_finish(lgnn_ctx* h, const float* out_bar, const float* gamma_A0, con
   if (h->extras()) LGNN_CALL(check_model_ext(h));
   else LGNN_CALL(check_model(h));
   LGNN_REQUIRE(out_bar && (gamma_A1 || (h1_bar && e_bar)) && grad_P && grad_adj, "null pointers");
-  LGNN_REQUIRE(!(h1_bar || e_bar) || h->kind == LGNN_KIND_GCN, "adjacency gradient, diagonal posterior: GCN models");
   if (h->kind == LGNN_KIND_SAGE) {
+    if (h1_bar && e_bar)  // diagonal posterior
+      return sage_adjgrad_finish(h, out_bar, nullptr, nullptr, 0.f, grad_P, grad_adj, cand_a, cand_b, K, grad_cand, grad_cand_adj, s,
+                                 h1_bar, e_bar, h->dims[0] + 1);
     LGNN_REQUIRE(gamma_A0 != nullptr, "GraphSAGE: the first layer's input covariance depends on the adjacency (gamma_A[0])");
     return sage_adjgrad_finish(h, out_bar, gamma_A0, gamma_A1, a1_scale, grad_P, grad_adj, cand_a, cand_b, K, grad_cand,
                                grad_cand_adj, s);

@@ -402,13 +402,25 @@ class ParametricLaplace(BaseLaplace):
             fast = self._glm_variance_matrix_free(x)
             if fast is not None:
                 return fast
-        Js, f_mu = self.backend.jacobians(x, enable_backprop=False)
-        if Js.shape[1:] != (self.n_outputs, self.n_params):
-            raise ValueError("Invalid Jacobians shape for Laplace posterior approx.")
-        f_var = self.functional_variance(Js)
-        if diagonal_output:
-            f_var = torch.diagonal(f_var, dim1=-2, dim2=-1)
-        return f_mu, f_var
+        # Jacobian route (models with res / norm, deeper models, full posteriors): the reference forms Js [M, C, P] for all
+        # evaluation nodes at once (laplace/baselaplace.py:1123-1158), which cannot exist at scale; here the nodes go in chunks
+        # whose Jacobians stay under _JACOBIAN_BYTES_MAX -- the same numbers, any M
+        per_node = max(1, self.n_outputs * self.n_params * 4)
+        chunk = max(1, min(int(x.shape[0]), self._JACOBIAN_BYTES_MAX // per_node))
+        mus, fvars = [], []
+        for s0 in range(0, max(int(x.shape[0]), 1), chunk):
+            Js, f_mu = self.backend.jacobians(x[s0:s0 + chunk], enable_backprop=False)
+            if Js.shape[1:] != (self.n_outputs, self.n_params):
+                raise ValueError("Invalid Jacobians shape for Laplace posterior approx.")
+            f_var = self.functional_variance(Js)
+            if diagonal_output:
+                f_var = torch.diagonal(f_var, dim1=-2, dim2=-1)
+            mus.append(f_mu)
+            fvars.append(f_var)
+            del Js
+        if len(mus) == 1:
+            return mus[0], fvars[0]
+        return torch.cat(mus), torch.cat(fvars)
 
     def _glm_forward_call(self, x, link_approx, n_samples, diagonal_output, generator, eps):
         """laplace/baselaplace.py:570-665 (classification branches)."""
@@ -1025,7 +1037,8 @@ class DiagLaplace(ParametricLaplace):
         leaves in ``model.adj.grad`` when the structure-learning loop runs with ``hessian_structure="diag"``, the shipped
         STE-GCN configuration (gnn/configs/original/stegcn_config.yaml:7; gnn/marglik_training.py:197-216; the fork's
         Jacobians keep the graph, laplace/curvature/curvature.py:89-130).  Same return values and candidate pairs as
-        ``KronLaplace.neg_marglik_adj_grad``.  2-layer GCN (STEGCN), classification; the diagonal GGN is a sum over samples, so
+        ``KronLaplace.neg_marglik_adj_grad``.  2-layer GCN (STEGCN, also with res / norm) and plain 2-layer GraphSAGE (STEGraphSAGE),
+        classification; the diagonal GGN is a sum over samples, so
         the loader's batch boundaries do not matter and the ranks of a job split every batch by samples."""
         if self.H is None or not self.n_data:
             raise AttributeError("Laplace not fitted. Run fit() first.")
@@ -1034,8 +1047,8 @@ class DiagLaplace(ParametricLaplace):
         if self.likelihood != "classification":
             raise NotImplementedError("adjacency gradient: classification likelihood")
         eng = getattr(self.backend, "engine", None)
-        if eng is None or not hasattr(eng, "diag_adjgrad_batch") or eng.kind != "gcn":
-            raise NotImplementedError("adjacency gradient under a diagonal posterior: 2-layer GCN on the HIP backend")
+        if eng is None or not hasattr(eng, "diag_adjgrad_batch") or eng.kind not in ("gcn", "sage"):
+            raise NotImplementedError("adjacency gradient under a diagonal posterior: 2-layer GCN / GraphSAGE on the HIP backend")
         value = -self.log_marginal_likelihood()
         f = self._H_factor
         gamma = (0.5 * f / self.posterior_precision).to(torch.float32).contiguous()  # d(1/2 logdet P) / dH_p

@@ -364,6 +364,22 @@ def make_case(ns, torch, name, kind, n, f, h, c, layers, n_edges, n_train, batch
         pick = np.random.default_rng(seed + 7).choice(len(ner), size=min(200, len(ner)), replace=False)
         out["adjgrad_ne_row"], out["adjgrad_ne_col"] = ner[pick], nec[pick]
         out["adjgrad_ne_val"] = gr[ner[pick], nec[pick]].astype(np.float32)
+        if kind == "sage" and not extras:
+            # hessian_structure="diag" with STEGraphSAGE (the driver offers the pair, gnn/utils.py:55-59, 81; no shipped config)
+            torch.manual_seed(seed)
+            ste_d = ns.gnn_models.STEGraphSAGE(f, h, c, layers, X, adj0.clone(), num_sampled_nodes_per_hop=None, dropout_p=0.5,
+                                               threshold=0.5, symmetric=symmetric)
+            ste_d.eval()
+            for a, b in zip(ste_d.convs, model.convs):
+                assert torch.equal(a.lin.weight, b.lin.weight) and torch.equal(a.lin.bias, b.lin.bias)
+            ld_ = bl.DiagLaplace(ste_d, "classification", prior_precision=0.7)
+            ld_.fit(loader)
+            negd = -ld_.log_marginal_likelihood()
+            negd.backward()
+            grd = ste_d.adj.grad.detach().numpy()
+            out["adjgrad_diag_neg_marglik"] = np.float64(float(negd))
+            out["adjgrad_diag_vals"] = grd[out["adj_nz_row"], out["adj_nz_col"]].astype(np.float32)
+            out["adjgrad_diag_ne_val"] = grd[ner[pick], nec[pick]].astype(np.float32)
         if kind == "gcn":
             # The same with hessian_structure="diag" -- what the shipped STE-GCN config runs (gnn/configs/original/
             # stegcn_config.yaml:7): DiagLaplace.fit keeps the graph through torch.func.jacrev (the fork's

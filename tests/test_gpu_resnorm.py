@@ -7,6 +7,8 @@ import pytest
 import torch
 
 import gnn_laplace_oracle as O
+import os
+
 from gpu_utils import kfac_fit_engine, oracle_from_arrays, rel
 from test_gpu_scale import _make
 
@@ -150,3 +152,33 @@ def test_rebinding_drops_and_restores_the_extras():
     eng.bind(X.cuda(), cw, cb)
     assert torch.equal(eng.forward_all(), plain)
     eng.close()
+
+
+def test_glm_predictive_of_a_res_norm_model_in_chunks_of_evaluation_nodes():
+    """Models with res / norm take the Jacobian route of the GLM predictive; its evaluation nodes go in chunks whose Jacobians
+    [chunk, C, P] stay under a byte budget (the reference forms all M at once, laplace/baselaplace.py:1123-1158): the chunked
+    result equals the single-pass one, diagonal and full covariance."""
+    import laplace_gnn_amd as lg
+
+    from test_gpu_frontend import model_from_golden
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gcn_resln_small_3batch_s1.npz"))
+    model = model_from_golden(g)
+    loader = lg.TensorBatchLoader(torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda(),
+                                  batch_size=int(g["batch_size"]))
+    la = lg.KronLaplace(model, "classification")
+    la.fit(loader)
+    idx = torch.arange(int(g["num_nodes"])).cuda()
+    mu1, var1 = la._glm_predictive_distribution(idx)
+    _, d1 = la._glm_predictive_distribution(idx, diagonal_output=True)
+    old = type(la)._JACOBIAN_BYTES_MAX
+    try:
+        type(la)._JACOBIAN_BYTES_MAX = 7 * la.n_outputs * la.n_params * 4  # 7 nodes per chunk: 64 = 9 chunks + 1
+        mu2, var2 = la._glm_predictive_distribution(idx)
+        _, d2 = la._glm_predictive_distribution(idx, diagonal_output=True)
+        probs = la(idx)
+    finally:
+        type(la)._JACOBIAN_BYTES_MAX = old
+    assert torch.equal(mu1, mu2) and mu2.shape == (idx.numel(), la.n_outputs)
+    assert rel(var2.cpu().numpy(), var1.cpu().numpy()) < 1e-6 and rel(d2.cpu().numpy(), d1.cpu().numpy()) < 1e-6
+    assert probs.shape == (idx.numel(), la.n_outputs) and torch.allclose(probs.sum(dim=1), torch.ones_like(probs[:, 0]), atol=1e-5)
