@@ -273,6 +273,11 @@ LGNN_API int lgnn_lastlayer_pairs_place(lgnn_ctx* h, const float* S_pairs, const
  * samples contribute nothing and a sticky flag is raised.  This call synchronises `stream`, reports the flag
  * (non-zero return + message) and clears it; call it once per fit, not per batch.                          */
 LGNN_API int lgnn_check_async_errors(lgnn_ctx* h, void* stream);
+/* The same report WITHOUT synchronising: the flags are sticky words in pinned host memory, so this sees the errors of every kernel
+ * that has finished; errors of work still in flight are reported by the next peek or check.  For callers that queue fit after fit
+ * (a replayed hipGraph of a whole fit, DiagLaplace.fit_graph) and must not stall the stream once per fit; the reference's own
+ * index errors on a CUDA / HIP device are asynchronous device-side asserts as well.                                          */
+LGNN_API int lgnn_peek_async_errors(lgnn_ctx* h);
 
 /* ---- timing hook (bench.py roofline) -----------------------------------------------------------
  * While enabled, every launch of the dominant kernel of the path in use -- KFAC: the fused SpMM^T -> Gram kernel of

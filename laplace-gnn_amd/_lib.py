@@ -54,6 +54,7 @@ SIGNATURES = {
     "lgnn_lastlayer_pairs_accumulate": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "lgnn_lastlayer_pairs_place": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "lgnn_check_async_errors": (_i32, [_vp, _vp]),
+    "lgnn_peek_async_errors": (_i32, [_vp]),
     "lgnn_enable_kernel_timing": (_i32, [_vp, _i32]),
     "lgnn_kernel_timing_read": (_i32, [_vp, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "lgnn_kernel_timing_launches": (_i32, [_vp, _vp, _i64, _vp]),

@@ -457,6 +457,20 @@ extern "C" int lgnn_check_async_errors(lgnn_ctx* h, void* stream) {
   return 0;
 }
 
+extern "C" int lgnn_peek_async_errors(lgnn_ctx* h) {
+  if (!h) { set_error("null context"); return 2; }
+  if (!h->ws.flags.p) return 0;
+  // no synchronisation: whatever the kernels that have FINISHED stored into the pinned flags (sticky until a raising read)
+  volatile int* dev = h->ws.flags.as<int>();
+  int flags[4];
+  for (int i = 0; i < 4; ++i) flags[i] = dev[i];
+  if (flags[0] == 0 && flags[1] == 0 && flags[2] == 0) return 0;
+  for (int i = 0; i < 4; ++i) dev[i] = 0;
+  LGNN_REQUIRE(flags[1] == 0 && flags[0] != 1 && flags[2] == 0, "a batch contained a node index outside [0, num_nodes)");
+  LGNN_REQUIRE(flags[0] != 2, "a batch contained a label outside [0, num_classes)");
+  return 0;
+}
+
 extern "C" int lgnn_enable_kernel_timing(lgnn_ctx* h, int enable) {
   if (!h) { set_error("null context"); return 2; }
   h->timing = enable != 0;

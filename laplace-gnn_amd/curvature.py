@@ -256,6 +256,9 @@ class HipCurvatureInterface:
     def check_async_errors(self):
         self.engine.check_async_errors()
 
+    def peek_async_errors(self):
+        self.engine.peek_async_errors()
+
     def jacobians(self, x: torch.Tensor, enable_backprop: bool = False):
         """(Js [M, C, P], f [M, C]) as CurvatureInterface.jacobians (laplace/curvature/curvature.py:89-130); the
         M * C backward passes run as planes through the HIP engine (csrc/jacobian.hip).  No autograd graph."""

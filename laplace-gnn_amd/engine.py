@@ -611,9 +611,14 @@ class GraphEngine:
         """Synchronise and raise if any batch since the last check contained an invalid node id or label."""
         _lib.check(self.lib.lgnn_check_async_errors(self._h, _stream(self.device)), "lgnn_check_async_errors")
 
+    def peek_async_errors(self):
+        """The same report without synchronising: errors of the kernels that have finished (lgnn_peek_async_errors)."""
+        _lib.check(self.lib.lgnn_peek_async_errors(self._h), "lgnn_peek_async_errors")
+
     # -- timing hook ----------------------------------------------------------------------------
     def enable_kernel_timing(self, on: bool = True):
         _lib.check(self.lib.lgnn_enable_kernel_timing(self._h, int(on)), "lgnn_enable_kernel_timing")
+        self._timing_on = bool(on)  # (event records around the dominant kernel: such a fit is not captured into a graph)
 
     def kernel_timing_launches(self):
         """Durations [ms] of the dominant kernel's launches since timing was enabled, in launch order."""

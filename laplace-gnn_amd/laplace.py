@@ -31,6 +31,7 @@ from torch import nn
 from torch.nn.utils import parameters_to_vector
 
 from .curvature import HipGGN
+from .data import TensorBatchLoader
 from .matrix import Kron, KronDecomposed
 
 
@@ -221,8 +222,8 @@ class ParametricLaplace(BaseLaplace):
         # invalid node ids / labels are flagged on the device; one sync per fit.  (Deferring this check until the
         # decomposition is queued was measured: 94.9 -> 95.9 ms per arxiv-shaped fit, the host running ahead costs more
         # than the ~1 ms of launches it hides.)
-        if hasattr(self.backend, "check_async_errors"):
-            self.backend.check_async_errors()
+        if hasattr(self.backend, "check_async_errors") and not getattr(self, "_capturing", False):
+            self.backend.check_async_errors()  # (a graph capture cannot hold the synchronisation: _fit_graph_try checks after the replay)
         if world > 1:
             phase = getattr(self, "_on_phase", None)  # measurement hook (bench.py): brackets the factor all-reduce
             if phase is not None:
@@ -994,7 +995,82 @@ class DiagLaplace(ParametricLaplace):
             return [self._hl]
         return [self.H]
 
+    # ---- a whole fit as ONE graph launch ---------------------------------------------------------------------------------
+    # A Cora-shaped diagonal fit is ~12 kernels of 3-40 us each: the gaps between their launches (host work of this front,
+    # dispatch latency) are a quarter of its wall time.  ``fit_graph = True`` (or LGNN_FIT_GRAPH=1) lets a fit that is repeated
+    # unchanged -- the reference's structure-learning and hyper-parameter loops refit after every step
+    # (gnn/marglik_training.py:197-224) -- be captured into a hipGraph (torch.cuda.CUDAGraph) on its second identical call and
+    # replayed afterwards: the same kernels on the same buffers, forward pass included (it is recomputed on every replay, as the
+    # reference recomputes it per batch), one launch.  "Identical" is an exact key: the loader object and its tensors, every
+    # parameter's storage, the feature tensor's binding -- values may change (they are read by the kernels), pointers and shapes
+    # may not; anything else falls back to the ordinary path.  After a replay ``H`` / ``loss`` / ``mean`` are the tensors of the
+    # captured fit (overwritten by the next replay).  Single process, override=True, in-place HIP backend, classification.
+    fit_graph = os.environ.get("LGNN_FIT_GRAPH", "") not in ("", "0")
+    _FIT_GRAPH_WARM = 1  # ordinary fits with the same key before the capture (the workspaces reach their final size in one)
+
+    def _fit_graph_key(self, train_loader, override, process_group):
+        eng = getattr(self.backend, "engine", None)
+        if (not self.fit_graph or not override or eng is None or _dist_info(process_group)[1] != 1
+                or self.likelihood != "classification" or not isinstance(train_loader, TensorBatchLoader)
+                or getattr(eng, "_timing_on", False) or getattr(self, "_on_phase", None) is not None):
+            return None
+        ts = (train_loader.indices, train_loader.labels)
+        if any((not t.is_cuda) for t in ts):
+            return None
+        return (id(train_loader), tuple((t.data_ptr(), tuple(t.shape)) for t in ts), getattr(train_loader, "batch_size", None),
+                tuple((p.data_ptr(), tuple(p.shape)) for p in self.params), eng.feature_token() if hasattr(eng, "feature_token")
+                else None, float(self.backend.factor))
+
+    def _fit_graph_try(self, train_loader, key) -> bool:
+        st = self.__dict__.setdefault("_fit_graph_state", {"key": None, "seen": 0, "graph": None, "off": False})
+        if st["off"]:
+            return False
+        if st["key"] != key:
+            st.update(key=key, seen=0, graph=None, out=None)
+        if st["graph"] is None:
+            st["seen"] += 1
+            if st["seen"] <= self._FIT_GRAPH_WARM or not self._inplace_backend():
+                return False
+            eng = self.backend.engine
+            try:
+                torch.cuda.synchronize()
+                eng.invalidate()  # the captured fit always contains its forward pass
+                g = torch.cuda.CUDAGraph()
+                self._capturing = True
+                with torch.cuda.graph(g):
+                    self._fit_plain(train_loader)
+                st["graph"] = g
+                st["out"] = {k: getattr(self, k) for k in ("H", "_hl", "loss", "mean", "n_data", "n_outputs")}
+            except Exception as exc:  # capture not possible here (e.g. a workspace still had to grow): ordinary path from now on
+                st["off"] = True
+                torch.cuda.synchronize()
+                import warnings
+                warnings.warn(f"fit_graph: capture failed, falling back to the ordinary path ({exc})")
+                return False
+            finally:
+                self._capturing = False
+        st["graph"].replay()
+        for k, v in st["out"].items():
+            setattr(self, k, v)
+        hook = getattr(self, "_on_accumulated", None)
+        if hook is not None:
+            hook()
+        # invalid ids / labels: the replay is not waited for (that round trip per fit is what the graph is there to save) -- the
+        # sticky flags of everything that has finished are read; what this replay raises is reported by the next fit at the
+        # latest, or by backend.check_async_errors()
+        if hasattr(self.backend, "peek_async_errors"):
+            self.backend.peek_async_errors()
+        elif hasattr(self.backend, "check_async_errors"):
+            self.backend.check_async_errors()
+        return True
+
     def fit(self, train_loader, override: bool = True, progress_bar: bool = False, process_group=None) -> None:
+        key = self._fit_graph_key(train_loader, override, process_group)
+        if key is not None and self._fit_graph_try(train_loader, key):
+            return
+        self._fit_plain(train_loader, override=override, progress_bar=progress_bar, process_group=process_group)
+
+    def _fit_plain(self, train_loader, override: bool = True, progress_bar: bool = False, process_group=None) -> None:
         if not override and getattr(self, "_hl", None) is not None:
             slot = self._hl[self.n_params:]
             if torch.is_tensor(self.loss) and self.loss.data_ptr() == slot.data_ptr():

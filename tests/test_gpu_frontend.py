@@ -788,3 +788,38 @@ def test_early_decomposition_of_a_large_input_factor_matches_the_late_one():
     # override=False adds to fitted factors: nothing is known early, the late path runs
     early.fit(loader, override=False)
     assert not early._early_ok
+
+
+def test_diag_fit_as_one_graph_replay_equals_the_ordinary_fit():
+    """``DiagLaplace.fit_graph``: a repeated, unchanged fit is captured into a hipGraph on its second call and replayed after:
+    H / loss / marginal likelihood equal the ordinary path's; an in-place weight update is seen by the next replay (the kernels
+    read the weights; the forward pass is part of the graph); a different loader or re-bound parameters fall back."""
+    import laplace_gnn_amd as lg
+
+    g = np.load(os.path.join(GOLDEN, "gcn_mid_3batch_sym_s1.npz"))
+    model = model_from_golden(g)
+    idx, y = torch.from_numpy(g["train_idx"]).cuda(), torch.from_numpy(g["train_y"]).cuda()
+    loader = lg.TensorBatchLoader(idx, y, batch_size=int(g["batch_size"]))
+    ref = lg.DiagLaplace(model, "classification")
+    ref.fit(loader)
+    H0, l0 = ref.H.clone(), float(ref.loss)
+    la = lg.DiagLaplace(model, "classification")
+    la.fit_graph = True
+    for k in range(4):  # ordinary, capture + replay, replay, replay
+        la.fit(loader)
+        assert rel(la.H.cpu().numpy(), g["diag_H"]) < 1e-4, k
+        assert rel(la.H.cpu().numpy(), H0.cpu().numpy()) < 1e-6 and abs(float(la.loss) - l0) <= 1e-6 * abs(l0), k
+        assert la.n_data == int(g["n_data"])
+    assert la._fit_graph_state["graph"] is not None and not la._fit_graph_state["off"]
+    assert abs(float(la.log_marginal_likelihood()) - float(ref.log_marginal_likelihood())) <= 1e-6 * abs(float(ref.log_marginal_likelihood()))
+    with torch.no_grad():
+        model.convs[0].lin.weight.mul_(1.5)  # in place: same storage, the replay reads the new values
+    la.fit(loader)
+    ref.fit(loader)
+    assert rel(la.H.cpu().numpy(), ref.H.cpu().numpy()) < 1e-6 and rel(la.H.cpu().numpy(), H0.cpu().numpy()) > 1e-3
+    assert rel(la.mean.cpu().numpy(), ref.mean.cpu().numpy()) == 0.0
+    other = lg.TensorBatchLoader(idx[:100].clone(), y[:100].clone(), batch_size=50)
+    la.fit(other)  # a different key: ordinary path (and a fresh warm-up count)
+    ref.fit(other)
+    assert rel(la.H.cpu().numpy(), ref.H.cpu().numpy()) < 1e-6 and la.n_data == 100
+    model.engine.check_async_errors()
