@@ -163,6 +163,7 @@ class GraphEngine:
                                                       _dev_ptr(cols, torch.int64, "cols"),
                                                       _dev_ptr(state, torch.uint8, "state"), rows.numel(),
                                                       _stream(self.device)), "lgnn_update_adjacency")
+        self._graph_edits = getattr(self, "_graph_edits", 0) + 1  # (the CSR buffers may have moved: captured graphs are stale)
 
     def export_propagation(self):
         nnz = self.nnz

@@ -1019,7 +1019,8 @@ class DiagLaplace(ParametricLaplace):
             return None
         return (id(train_loader), tuple((t.data_ptr(), tuple(t.shape)) for t in ts), getattr(train_loader, "batch_size", None),
                 tuple((p.data_ptr(), tuple(p.shape)) for p in self.params), eng.feature_token() if hasattr(eng, "feature_token")
-                else None, float(self.backend.factor))
+                else None, getattr(eng, "_graph_edits", 0), getattr(eng, "_ws_limit", None), float(self.backend.factor),
+                tuple(p for p, _ in eng._param_versions()) if hasattr(eng, "_param_versions") else None)
 
     def _fit_graph_try(self, train_loader, key) -> bool:
         st = self.__dict__.setdefault("_fit_graph_state", {"key": None, "seen": 0, "graph": None, "off": False})
