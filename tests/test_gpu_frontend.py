@@ -823,3 +823,29 @@ def test_diag_fit_as_one_graph_replay_equals_the_ordinary_fit():
     ref.fit(other)
     assert rel(la.H.cpu().numpy(), ref.H.cpu().numpy()) < 1e-6 and la.n_data == 100
     model.engine.check_async_errors()
+
+
+def test_symeig_sizes_around_the_hand_written_ranges():
+    """n = 257 .. 515 around the edges of the streaming route (256 < n <= 512, n % 4 == 0): sizes that are not a multiple of 4 and
+    n > 512 take the library; every size returns the same decomposition semantics (ascending, clamped, orthonormal)."""
+    from laplace_gnn_amd.matrix import symeig_batched_hip
+
+    gen = torch.Generator().manual_seed(3)
+    for n in (257, 258, 260, 264, 288, 508, 512, 513, 516):
+        R = torch.randn(n + 50, n, generator=gen) * torch.logspace(0, -2, n).unsqueeze(0)
+        H = (R.T @ R / (n + 50)).cuda()
+        (lam, Q), = symeig_batched_hip([H])
+        ref = torch.linalg.eigvalsh(H.double().cpu()).clamp(min=0).numpy()
+        assert np.abs(lam.cpu().numpy() - ref).max() < 1e-5 * ref.max(), n
+        Qd = Q.double().cpu()
+        assert (Qd.T @ Qd - torch.eye(n, dtype=torch.float64)).abs().max() < 1e-4, n
+        assert rel(((Qd * lam.double().cpu()) @ Qd.T).numpy(), H.double().cpu().numpy()) < 1e-5, n
+    # several mid-size factors in one fit-like call (one C call each), twice: nothing left over between calls
+    mats = [((torch.randn(600, n, generator=gen).T @ torch.randn(600, n, generator=gen)) / 600) for n in (320, 512, 384)]
+    mats = [(M + M.T).cuda() @ (M + M.T).cuda().T / 4 for M in mats]
+    a = symeig_batched_hip(mats)
+    b = symeig_batched_hip(mats)
+    for (la_, Qa), (lb, Qb), H in zip(a, b, mats):
+        assert torch.equal(la_, lb) and torch.equal(Qa, Qb)
+        ref = torch.linalg.eigvalsh(H.double().cpu()).clamp(min=0).numpy()
+        assert np.abs(la_.cpu().numpy() - ref).max() < 1e-5 * ref.max()

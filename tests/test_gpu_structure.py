@@ -139,3 +139,50 @@ def test_structure_learning_loop_matches_the_reference(name):
     last = float(-la.log_marginal_likelihood())
     assert abs(last - float(g["neg_marglik"][-1])) <= 2e-5 * abs(float(g["neg_marglik"][-1]))
     model.engine.check_async_errors()
+
+
+def test_update_adjacency_edge_cases():
+    """No flips, flips that are all no-ops, removing every edge of a node and adding them back, an engine whose graph becomes
+    empty and grows again: each state equals a fresh ingest of the same edge list."""
+    import laplace_gnn_amd as lg
+
+    g = torch.Generator().manual_seed(11)
+    N, F, H, C = 60, 6, 8, 3
+    ei = torch.randint(0, N, (2, 120), generator=g)
+    X = torch.randn(N, F, generator=g)
+    torch.manual_seed(0)
+    model = lg.GCN(F, H, C, 2, X, ei, symmetric=False).cuda().eval()
+    eng = model.engine
+
+    def same_as_fresh():
+        r, c = eng.export_adj()
+        off = r != c
+        fresh = lg.GCN(F, H, C, 2, X, torch.stack([r[off].cpu(), c[off].cpu()]), symmetric=False).cuda().eval()
+        fr, fc = fresh.engine.export_adj()
+        assert torch.equal(r, fr) and torch.equal(c, fc)
+        pr, pc, pv = eng.export_propagation()
+        qr, qc, qv = fresh.engine.export_propagation()
+        assert torch.equal(pr, qr) and torch.equal(pc, qc) and torch.equal(pv, qv)
+        with torch.no_grad():
+            for a_, b_ in zip(fresh.parameters(), model.parameters()):
+                a_.copy_(b_)
+        idx = torch.arange(N).cuda()
+        assert torch.allclose(model(idx), fresh(idx), atol=1e-6)
+        fresh.engine.close()
+
+    empty = torch.zeros(0, dtype=torch.int64)
+    eng.update_adjacency(empty, empty, torch.zeros(0, dtype=torch.bool))  # nothing
+    same_as_fresh()
+    r, c = eng.export_adj()
+    off = (r != c).cpu()
+    r, c = r.cpu()[off], c.cpu()[off]
+    eng.update_adjacency(r[:10], c[:10], torch.ones(10, dtype=torch.bool))  # already stored: no-ops
+    same_as_fresh()
+    eng.update_adjacency(r, c, torch.zeros(r.numel(), dtype=torch.bool))  # every off-diagonal edge removed: self loops only
+    rr, cc = eng.export_adj()
+    assert torch.equal(rr, cc) and rr.numel() == N
+    same_as_fresh()
+    eng.update_adjacency(r[::2], c[::2], torch.ones(r[::2].numel(), dtype=torch.bool))  # half of them back
+    same_as_fresh()
+    eng.check_async_errors()
+    eng.close()
