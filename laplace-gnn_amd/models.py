@@ -6,7 +6,7 @@ sparse adjacency held by the HIP engine instead of a dense N x N ``nn.Parameter`
 Inference (eval mode) runs on the GPU through the C ABI; training the weights is outside the
 accelerated path.  ``res=True`` (``res.{i}`` Linears, base_gnn.py:97-113) and
 ``norm="layer"|"batch"`` (``norms.{i}``, base_gnn.py:86-95) are part of the HIP forward / backward (csrc/resnorm.hip).
-Unsupported reference options raise immediately: neighbour sampling (``num_sampled_nodes_per_hop``).
+Neighbour sampling (``num_sampled_nodes_per_hop``) needs an explicit ``sample_seed`` (the reference's sampler is unseeded).
 """
 from __future__ import annotations
 
@@ -177,17 +177,63 @@ class GCN(BaseGNN):
 
 
 class GraphSAGE(BaseGNN):
-    """gnn/models/models.py:37-62 with ``num_sampled_nodes_per_hop=None`` (no sampling: the reference's
-    sampler is unseeded, gnn/models/utils.py:115-131)."""
+    """gnn/models/models.py:37-62.  ``num_sampled_nodes_per_hop=k``: the reference multiplies the adjacency by a fresh random
+    subgraph -- at most k of every row's neighbours, ``torch.randperm`` from the GLOBAL, unseeded generator -- on EVERY call of
+    ``forward_adj`` (gnn/models/utils.py:115-131; its ``seed`` argument is commented out), so the three forward passes and the
+    backward passes of one KFAC batch each see a different graph and no two runs agree: there is nothing to pin.  Here the draw
+    is explicit: ``sample_seed`` (required with k) selects ONE subgraph -- every row keeps ``min(deg, k)`` of its neighbours,
+    uniformly, from a generator seeded with it -- that all passes of a fit share; ``resample(seed)`` draws another.  The sampled
+    graph is directed (a row's choice is its own), whatever ``symmetric`` says about the full one.  Parity unpinned by
+    construction (tests hold the distributional properties and the equality with a model built on the sampled edge list)."""
     kind = "sage"
     _mult = 2
 
     def __init__(self, in_channels, hidden_channels, out_channels, num_layers, X, init_adj,
-                 num_sampled_nodes_per_hop=None, **kwargs):
+                 num_sampled_nodes_per_hop=None, sample_seed=None, **kwargs):
         if num_sampled_nodes_per_hop is not None:
-            raise NotImplementedError("neighbour sampling is not supported (unseeded in the reference)")
+            if sample_seed is None:
+                raise NotImplementedError("neighbour sampling: the reference's sampler is unseeded (a new graph per forward "
+                                          "call); pass sample_seed=<int> for one seeded draw per fit")
+            if int(num_sampled_nodes_per_hop) < 1:
+                raise ValueError("num_sampled_nodes_per_hop must be >= 1")
         super().__init__(in_channels, hidden_channels, out_channels, num_layers, X, init_adj, **kwargs)
-        self.num_sampled_nodes_per_hop = None
+        self.num_sampled_nodes_per_hop = None if num_sampled_nodes_per_hop is None else int(num_sampled_nodes_per_hop)
+        self.sample_seed = sample_seed
+
+    def resample(self, seed: int):
+        """Draw another subgraph (the engine is rebuilt on next use; fitted posteriors belong to the previous graph)."""
+        self.sample_seed = int(seed)
+        self._engine = None
+
+    def sampled_edge_index(self, device) -> torch.Tensor:
+        """The seeded draw: [2, E'] int64, row-major sorted, at most k entries per row of the full 0/1 adjacency."""
+        full = GraphEngine(self.edge_index.to(device), self.num_nodes, kind=self.kind, symmetric=self.symmetric)
+        rows, cols = full.export_adj()
+        full.close()
+        gen = torch.Generator(device="cpu").manual_seed(int(self.sample_seed))
+        key = torch.rand(rows.numel(), generator=gen).to(device)
+        order = torch.argsort(key)                       # random order ...
+        order = order[torch.argsort(rows[order], stable=True)]  # ... within every row
+        r_sorted = rows[order]
+        start = torch.searchsorted(r_sorted, r_sorted)  # first position of the entry's row
+        keep = (torch.arange(rows.numel(), device=device) - start) < self.num_sampled_nodes_per_hop
+        sel = torch.sort(order[keep]).values             # back to row-major order
+        return torch.stack([rows[sel], cols[sel]]).contiguous()
+
+    @property
+    def engine(self) -> GraphEngine:
+        if self.num_sampled_nodes_per_hop is None:
+            return BaseGNN.engine.fget(self)
+        dev = self.convs[0].lin.weight.device
+        if self._engine is None:
+            if dev.type != "cuda":
+                raise RuntimeError("the HIP engine needs the model on a GPU: call model.to('cuda') first "
+                                   "(there is no CPU fallback)")
+            eng = GraphEngine(self.sampled_edge_index(dev), self.num_nodes, kind=self.kind, symmetric=False)
+            eng.bind(self.X.to(dev).contiguous(), [c.lin.weight for c in self.convs],
+                     [c.lin.bias for c in self.convs], act=self.act_name, **self._extras())
+            self._engine = eng
+        return self._engine
 
 
 class STEGCN(GCN):

@@ -849,3 +849,57 @@ def test_symeig_sizes_around_the_hand_written_ranges():
         assert torch.equal(la_, lb) and torch.equal(Qa, Qb)
         ref = torch.linalg.eigvalsh(H.double().cpu()).clamp(min=0).numpy()
         assert np.abs(la_.cpu().numpy() - ref).max() < 1e-5 * ref.max()
+
+
+def test_graphsage_neighbour_sampling_with_an_explicit_seed():
+    """``num_sampled_nodes_per_hop`` (gnn/models/models.py:54-58, gnn/models/utils.py:115-131): the reference draws an unseeded
+    random subgraph at every forward call -- parity unpinned by construction.  The seeded draw here: every row keeps
+    min(deg, k) of its own neighbours, the same seed gives the same graph, another seed another one, and the model equals one
+    built directly on the sampled edge list (forward, KFAC factors)."""
+    import laplace_gnn_amd as lg
+
+    gen = torch.Generator().manual_seed(5)
+    N, F, H, C, E, k = 300, 10, 16, 4, 2500, 3
+    ei = torch.randint(0, N, (2, E), generator=gen)
+    X = torch.randn(N, F, generator=gen)
+    with pytest.raises(NotImplementedError, match="sample_seed"):
+        lg.GraphSAGE(F, H, C, 2, X, ei, num_sampled_nodes_per_hop=k)
+    torch.manual_seed(0)
+    full = lg.GraphSAGE(F, H, C, 2, X, ei, symmetric=True).cuda().eval()
+    fr, fc = full.engine.export_adj()
+    deg = torch.bincount(fr, minlength=N)
+    torch.manual_seed(0)
+    m1 = lg.GraphSAGE(F, H, C, 2, X, ei, symmetric=True, num_sampled_nodes_per_hop=k, sample_seed=7).cuda().eval()
+    r1, c1 = m1.engine.export_adj()
+    assert torch.equal(torch.bincount(r1, minlength=N), deg.clamp(max=k))  # min(deg, k) per row
+    fkeys = set((fr * N + fc).cpu().tolist())
+    assert all(int(q) in fkeys for q in (r1 * N + c1).cpu().tolist())       # a subgraph of the full adjacency
+    torch.manual_seed(0)
+    m2 = lg.GraphSAGE(F, H, C, 2, X, ei, symmetric=True, num_sampled_nodes_per_hop=k, sample_seed=7).cuda().eval()
+    r2, c2 = m2.engine.export_adj()
+    assert torch.equal(r1, r2) and torch.equal(c1, c2)
+    m2.resample(8)
+    r3, c3 = m2.engine.export_adj()
+    assert torch.equal(torch.bincount(r3, minlength=N), deg.clamp(max=k)) and not (torch.equal(r1, r3) and torch.equal(c1, c3))
+    # every neighbour is kept about k / deg of the time: over 40 seeds the kept fraction of the rows with deg = 2 k is ~ 1/2
+    rows2k = (deg == 2 * k).nonzero().squeeze(1)
+    if rows2k.numel() >= 5:
+        kept = 0
+        for s in range(40):
+            m2.resample(100 + s)
+            rs, _ = m2.engine.export_adj()
+            kept += int(torch.isin(rs, rows2k).sum())
+        frac = kept / (40 * rows2k.numel() * 2 * k)
+        assert abs(frac - 0.5) < 1e-9  # exactly k of 2 k per row, always
+    torch.manual_seed(0)
+    direct = lg.GraphSAGE(F, H, C, 2, X, torch.stack([r1.cpu(), c1.cpu()]), symmetric=False).cuda().eval()
+    idx = torch.arange(N).cuda()
+    assert torch.equal(m1(idx), direct(idx))
+    y = torch.randint(0, C, (120,), generator=gen).cuda()
+    loader = lg.TensorBatchLoader(idx[:120], y, batch_size=50)
+    la, lb = lg.KronLaplace(m1, "classification"), lg.KronLaplace(direct, "classification")
+    la.fit(loader)
+    lb.fit(loader)
+    for Fa, Fb in zip(la.H_facs.kfacs, lb.H_facs.kfacs):
+        for a_, b_ in zip(Fa, Fb):
+            assert rel(a_.cpu().numpy(), b_.cpu().numpy()) < 1e-5
